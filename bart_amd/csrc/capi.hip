@@ -1,0 +1,292 @@
+// extern "C" boundary of libbartrt.so (include/bartrt.h).
+#include <cstring>
+#include <string>
+
+#include "../../include/bartrt.h"
+#include "engine.hpp"
+#include "step.hpp"
+
+using namespace bartrt;
+
+static Engine *g_eng = nullptr;
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &m) {
+  g_err = m;
+  return code;
+}
+
+template <class F>
+static int guarded(F &&f) {
+  try {
+    return f();
+  } catch (const IoError &e) {
+    return fail(BARTRT_EIO, e.msg);
+  } catch (const HipError &e) {
+    return fail(BARTRT_ENODEV, std::string(e.what) + ": " + hipGetErrorString(e.e));
+  } catch (const std::exception &e) {
+    return fail(BARTRT_EINVAL, e.what());
+  }
+}
+
+#define NEED_ENGINE() \
+  if (!g_eng) return fail(BARTRT_EINVAL, "engine not initialised: call bartrt_init first")
+
+extern "C" {
+
+const char *bartrt_last_error(void) { return g_err.c_str(); }
+
+int bartrt_init(int argc, const char **argv) {
+  if (argc < 1 || !argv) return fail(BARTRT_EINVAL, "bartrt_init: empty argv");
+  return guarded([&] {
+    delete g_eng;
+    g_eng = nullptr;
+    Engine *e = new Engine();
+    try {
+      e->init(argc, argv);
+    } catch (...) {
+      delete e;
+      throw;
+    }
+    g_eng = e;
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_free_memory(void) {
+  return guarded([&] {
+    if (g_eng) (void)hipDeviceSynchronize();
+    delete g_eng;
+    g_eng = nullptr;
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_get_no_samples(void) {
+  NEED_ENGINE();
+  return g_eng->Wfull;
+}
+
+int bartrt_get_waveno_arr(double *out, int n) {
+  NEED_ENGINE();
+  if (!out || n != g_eng->Wfull) return fail(BARTRT_EINVAL, "get_waveno_arr: n must equal get_no_samples()");
+  std::memcpy(out, g_eng->wn_full.data(), sizeof(double) * n);
+  return BARTRT_OK;
+}
+
+int bartrt_set_radius(double r_km) {
+  NEED_ENGINE();
+  if (!(r_km > 0)) return fail(BARTRT_EINVAL, "set_radius: radius must be positive");
+  g_eng->refradius = r_km * 1e5;
+  return BARTRT_OK;
+}
+
+int bartrt_set_cloudtop(double logp) {
+  NEED_ENGINE();
+  g_eng->has_cloud = 1;
+  g_eng->cloudtop = std::pow(10.0, logp) * 1e6;
+  return BARTRT_OK;
+}
+
+int bartrt_set_scattering(int flag, double value) {
+  NEED_ENGINE();
+  if (flag < 0 || flag > 2) return fail(BARTRT_EINVAL, "set_scattering: flag must be 0, 1 or 2");
+  g_eng->scat_flag = flag;
+  g_eng->scat_value = value;
+  return BARTRT_OK;
+}
+
+int bartrt_get_nlayers(void) { NEED_ENGINE(); return g_eng->L; }
+int bartrt_get_nspecies(void) { NEED_ENGINE(); return g_eng->S; }
+int bartrt_get_nprof(void) { NEED_ENGINE(); return (g_eng->S + 1) * g_eng->L; }
+
+int bartrt_get_local_range(int *lo, int *hi) {
+  NEED_ENGINE();
+  if (lo) *lo = g_eng->lo;
+  if (hi) *hi = g_eng->hi;
+  return BARTRT_OK;
+}
+
+int bartrt_get_species(char *buf, int buflen) {
+  NEED_ENGINE();
+  std::string s;
+  for (auto &n : g_eng->atm.species) s += (s.empty() ? "" : " ") + n;
+  if (!buf || (int)s.size() + 1 > buflen) return fail(BARTRT_EINVAL, "get_species: buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return BARTRT_OK;
+}
+
+int bartrt_get_pressure(double *out, int n) {
+  NEED_ENGINE();
+  if (!out || n != g_eng->L) return fail(BARTRT_EINVAL, "get_pressure: n must equal the layer count");
+  std::memcpy(out, g_eng->atm.press.data(), sizeof(double) * n);
+  return BARTRT_OK;
+}
+
+int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
+                             double *spec, int nwave, unsigned char *ok) {
+  NEED_ENGINE();
+  Engine *e = g_eng;
+  if (!prof || !spec || nwalkers < 0) return fail(BARTRT_EINVAL, "run_transit: null buffer");
+  if (nprof != (e->S + 1) * e->L)
+    return fail(BARTRT_EINVAL, "run_transit: profile length must be (nspecies+1)*nlayers");
+  const int Wl = e->W();
+  if (nwave != Wl && nwave != e->Wfull)
+    return fail(BARTRT_EINVAL, "run_transit: nwave must equal get_no_samples() (or the shard size)");
+  if (nwalkers == 0) return BARTRT_OK;
+  return guarded([&] {
+    e->ensure_walkers(nwalkers);
+    const size_t pb = sizeof(double) * (size_t)nwalkers * nprof;
+    const size_t sb = sizeof(double) * (size_t)nwalkers * Wl;
+    e->ensure_pin(pb + sb + nwalkers);
+    std::memcpy(e->h_pin, prof, pb);
+    HIPCHK(hipMemcpyAsync(e->d_prof, e->h_pin, pb, hipMemcpyHostToDevice, e->stream));
+    e->run_dev(e->d_prof, nwalkers, e->d_spec, e->d_ok, e->stream, false);
+    double *hs = e->h_pin + (size_t)nwalkers * nprof;
+    unsigned char *hok = reinterpret_cast<unsigned char *>(hs + (size_t)nwalkers * Wl);
+    HIPCHK(hipMemcpyAsync(hs, e->d_spec, sb, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(hok, e->d_ok, nwalkers, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t off = nwave == Wl ? 0 : (size_t)e->lo;
+    for (int w = 0; w < nwalkers; w++)
+      std::memcpy(spec + (size_t)w * nwave + off, hs + (size_t)w * Wl, sizeof(double) * Wl);
+    if (ok) std::memcpy(ok, hok, nwalkers);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_run_transit(const double *prof, int nprof, double *spec, int nwave) {
+  return bartrt_run_transit_batch(prof, 1, nprof, spec, nwave, nullptr);
+}
+
+int bartrt_run_transit_batch_dev(const double *d_prof, int nwalkers, double *d_spec,
+                                 unsigned char *d_ok, void *stream) {
+  NEED_ENGINE();
+  if (!d_prof || !d_spec || nwalkers < 0) return fail(BARTRT_EINVAL, "run_transit_batch_dev: null buffer");
+  return guarded([&] {
+    hipStream_t st = stream ? (hipStream_t)stream : g_eng->stream;
+    g_eng->run_dev(d_prof, nwalkers, d_spec, d_ok, st, false);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
+  NEED_ENGINE();
+  Engine *e = g_eng;
+  if (!tau || nwave != e->W() || nlayers != e->L)
+    return fail(BARTRT_EINVAL, "get_tau: shape must be [local samples][nlayers]");
+  return guarded([&] {
+    // re-run the most recent single profile (still in d_prof[0]) with the
+    // optical-depth output enabled
+    e->run_dev(e->d_prof, 1, e->d_spec, e->d_ok, e->stream, true);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(tau, e->d_tau, sizeof(double) * (size_t)nwave * nlayers, hipMemcpyDeviceToHost));
+    if (last) HIPCHK(hipMemcpy(last, e->d_last, sizeof(int) * (size_t)nwave, hipMemcpyDeviceToHost));
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_timing_begin(void) {
+  NEED_ENGINE();
+  g_eng->timing = true;
+  g_eng->ev_used = 0;
+  return BARTRT_OK;
+}
+
+int bartrt_timing_end(double *kernel_ms, int *nlaunch) {
+  NEED_ENGINE();
+  return guarded([&] {
+    Engine *e = g_eng;
+    double tot = 0.0;
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i + 1 < e->ev_used; i += 2) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+      tot += ms;
+    }
+    if (kernel_ms) *kernel_ms = tot;
+    if (nlaunch) *nlaunch = e->ev_used / 2;
+    e->timing = false;
+    e->ev_used = 0;
+    return BARTRT_OK;
+  });
+}
+
+double bartrt_algorithmic_bytes(int nwalkers) {
+  if (!g_eng) return 0.0;
+  Engine *e = g_eng;
+  const double L = e->L, W = e->W(), M = e->M, C = e->C, S = e->S;
+  return nwalkers * (2.0 * L * W * M * 8.0 + 2.0 * L * W * C * 8.0 + (S + 1) * L * 8.0 + W * 8.0);
+}
+
+// ---- per-step converters (step.hip) ------------------------------------
+int bartrt_step_setup(const double *ptargs5, int tint_thorngren, int pttype,
+                      double tmin, double tmax,
+                      const double *abund, int nmolfit, const int *imol,
+                      int nfilters, const int *idx0, const int *npts,
+                      const double *nifilter, const double *istarfl,
+                      double rprs, int solution) {
+  NEED_ENGINE();
+  return guarded([&] {
+    step_setup(*g_eng, ptargs5, tint_thorngren, pttype, tmin, tmax, abund, nmolfit, imol,
+               nfilters, idx0, npts, nifilter, istarfl, rprs, solution);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_step_set_ebalance(int on, double e_in, double e_fac) {
+  NEED_ENGINE();
+  return guarded([&] {
+    step_set_ebalance(*g_eng, on, e_in, e_fac);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_step_profiles_dev(const double *d_params, int nwalkers, int npars,
+                             double *d_prof, int *d_status, void *stream) {
+  NEED_ENGINE();
+  if (!g_eng->step) return fail(BARTRT_EINVAL, "step_profiles: call bartrt_step_setup first");
+  if (!d_params || !d_prof || !d_status) return fail(BARTRT_EINVAL, "step_profiles: null buffer");
+  return guarded([&] {
+    hipStream_t st = stream ? (hipStream_t)stream : g_eng->stream;
+    step_profiles_dev(*g_eng, d_params, nwalkers, npars, d_prof, d_status, st);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_step_bandflux_dev(const double *d_spec_full, int nwalkers, int *d_status,
+                             double *d_bandflux, void *stream) {
+  NEED_ENGINE();
+  if (!g_eng->step) return fail(BARTRT_EINVAL, "step_bandflux: call bartrt_step_setup first");
+  if (!d_spec_full || !d_bandflux || !d_status) return fail(BARTRT_EINVAL, "step_bandflux: null buffer");
+  return guarded([&] {
+    hipStream_t st = stream ? (hipStream_t)stream : g_eng->stream;
+    step_bandflux_dev(*g_eng, d_spec_full, nwalkers, d_status, d_bandflux, st);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_step_batch_dev(const double *d_params, int nwalkers, int npars,
+                          double *d_bandflux, int *d_status, double *d_spec,
+                          void *stream) {
+  NEED_ENGINE();
+  if (!g_eng->step) return fail(BARTRT_EINVAL, "step_batch: call bartrt_step_setup first");
+  return guarded([&] {
+    hipStream_t st = stream ? (hipStream_t)stream : g_eng->stream;
+    step_run_dev(*g_eng, d_params, nwalkers, npars, d_bandflux, d_status, d_spec, st);
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_step_batch(const double *params, int nwalkers, int npars,
+                      double *bandflux, int *status) {
+  NEED_ENGINE();
+  if (!g_eng->step) return fail(BARTRT_EINVAL, "step_batch: call bartrt_step_setup first");
+  if (!params || !bandflux || nwalkers < 0) return fail(BARTRT_EINVAL, "step_batch: null buffer");
+  return guarded([&] {
+    step_run_host(*g_eng, params, nwalkers, npars, bandflux, status);
+    return BARTRT_OK;
+  });
+}
+
+}  // extern "C"

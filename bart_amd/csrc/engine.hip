@@ -1,0 +1,343 @@
+// Host-side engine: reads the transit inputs, places the tables in HBM and
+// drives the kernels.  One engine per process (one process per GPU).
+#include "engine.hpp"
+#include "step.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace bartrt {
+
+template <class T>
+static T *dev_upload(const std::vector<T> &v) {
+  T *d = nullptr;
+  size_t n = std::max<size_t>(v.size(), 1);
+  HIPCHK(hipMalloc(&d, n * sizeof(T)));
+  if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+static std::vector<std::string> split_commas(const std::string &s) {
+  std::vector<std::string> out;
+  std::string cur;
+  for (char ch : s) {
+    if (ch == ',' || ch == ' ' || ch == '\t') {
+      if (!cur.empty()) out.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(ch);
+    }
+  }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+
+Engine::~Engine() {
+  delete step;
+  auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_dlnp); fr(d_mass);
+  fr(d_tgrid); fr(d_cia_temp); fr(d_opmol); fr(d_prof); fr(d_coef); fr(d_spec);
+  fr(d_idx); fr(d_kstop); fr(d_ok); fr(d_tau); fr(d_last);
+  if (h_pin) (void)hipHostFree(h_pin);
+  for (auto e : ev) (void)hipEventDestroy(e);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Engine::init(int argc, const char **argv) {
+  std::string cfile;
+  int shard_rank = 0, shard_n = 1;
+  device = -1;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    if ((a == "-c" || a == "--config_file") && i + 1 < argc) cfile = argv[++i];
+    else if (a == "--shard" && i + 2 < argc) { shard_rank = std::atoi(argv[++i]); shard_n = std::atoi(argv[++i]); }
+    else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+  }
+  if (cfile.empty()) throw IoError{"transit_init: no '-c <configuration file>' in argv"};
+  if (shard_n < 1 || shard_rank < 0 || shard_rank >= shard_n)
+    throw IoError{"transit_init: bad --shard rank/nranks"};
+  cfg = read_tcfg(cfile);
+  if (!cfg_has(cfg, "atm")) throw IoError{"transit cfg: missing 'atm'"};
+  if (!cfg_has(cfg, "molfile")) throw IoError{"transit cfg: missing 'molfile'"};
+  std::string sol = cfg_has(cfg, "solution") ? cfg["solution"] : "eclipse";
+  if (sol != "eclipse")
+    throw IoError{"solution '" + sol + "' is not built yet: only 'eclipse' (SURVEY.md 8f-1)"};
+  atm = read_atm(cfg["atm"]);
+  mol = read_molfile(cfg["molfile"]);
+  L = (int)atm.press.size();
+  S = (int)atm.species.size();
+  mass.resize(S);
+  for (int s = 0; s < S; s++) {
+    int j = mol.find_name(atm.species[s]);
+    if (j < 0) throw IoError{"species '" + atm.species[s] + "' is not in the molecule file"};
+    mass[s] = mol.mass[j];
+    if (atm.species[s] == "H2") iH2 = s;
+    if (atm.species[s] == "He") iHe = s;
+  }
+  for (int l = 0; l + 1 < L; l++)
+    if (!(atm.press[l] > atm.press[l + 1]))
+      throw IoError{"atmosphere file: layers must run bottom -> top (decreasing pressure)"};
+
+  // ---- wavenumber grid and opacity table
+  OpacityHeader oh;
+  const bool have_table = cfg_has(cfg, "opacityfile");
+  if (have_table) {
+    oh = read_opacity_header(cfg["opacityfile"]);
+    if (oh.nlayer != L) throw IoError{"opacity file: layer count differs from the atmosphere file"};
+    for (int l = 0; l < L; l++)
+      if (std::fabs(oh.press[l] - atm.press[l]) > 1e-9 * atm.press[l])
+        throw IoError{"opacity file: pressure layers differ from the atmosphere file"};
+    wn_full = oh.wn;
+    tgrid = oh.temp;
+    M = (int)oh.nmol;
+    Nt = (int)oh.ntemp;
+    if (M > kMaxMol) throw IoError{"opacity file: too many molecules"};
+    opmol.resize(M);
+    for (int m = 0; m < M; m++) {
+      int j = mol.find_id(oh.molid[m]);
+      if (j < 0) throw IoError{"opacity file: molecule ID not in the molecule file"};
+      auto it = std::find(atm.species.begin(), atm.species.end(), mol.name[j]);
+      if (it == atm.species.end())
+        throw IoError{"opacity file: molecule '" + mol.name[j] + "' is not in the atmosphere file"};
+      opmol[m] = (int)(it - atm.species.begin());
+    }
+  } else {
+    if (cfg_has(cfg, "linedb"))
+      throw IoError{"line-by-line (TLI) extinction is not built yet: give an 'opacityfile'"};
+    double lo_wn, hi_wn;
+    double wnfct = cfg_num(cfg, "wnfct", 1.0), wlfct = cfg_num(cfg, "wlfct", 1e-4);
+    if (cfg_has(cfg, "wnlow") && cfg_has(cfg, "wnhigh")) {
+      lo_wn = cfg_num(cfg, "wnlow", 0) * wnfct;
+      hi_wn = cfg_num(cfg, "wnhigh", 0) * wnfct;
+    } else if (cfg_has(cfg, "wllow") && cfg_has(cfg, "wlhigh")) {
+      lo_wn = 1.0 / (cfg_num(cfg, "wlhigh", 0) * wlfct);
+      hi_wn = 1.0 / (cfg_num(cfg, "wllow", 0) * wlfct);
+    } else {
+      throw IoError{"transit cfg: no spectral range (wnlow/wnhigh or wllow/wlhigh)"};
+    }
+    double d = cfg_num(cfg, "wndelt", 1.0) * wnfct;
+    if (!(d > 0) || !(hi_wn > lo_wn)) throw IoError{"transit cfg: bad spectral sampling"};
+    long n = (long)std::floor((hi_wn - lo_wn) / d + 1e-9) + 1;
+    wn_full.resize(n);
+    for (long i = 0; i < n; i++) wn_full[i] = lo_wn + d * i;
+    M = 0; Nt = 2; tgrid = {0.0, 1.0};
+  }
+  Wfull = (int)wn_full.size();
+  lo = (int)((long)Wfull * shard_rank / shard_n);
+  hi = (int)((long)Wfull * (shard_rank + 1) / shard_n);
+  if (hi <= lo) throw IoError{"--shard leaves this rank without wavenumber samples"};
+  const int Wl = W();
+
+  // ---- geometry, hydrostatic reference
+  angles = cfg_list(cfg, "raygrid");
+  if (angles.empty()) angles = {0, 20, 40, 60, 80};
+  A = (int)angles.size();
+  if (A > kMaxAngles) throw IoError{"raygrid: too many angles"};
+  for (int a = 0; a < A; a++)
+    if (angles[a] < 0 || angles[a] >= 90 || (a && angles[a] <= angles[a - 1]))
+      throw IoError{"raygrid: angles must increase within [0, 90)"};
+  toomuch = cfg_num(cfg, "toomuch", 20.0);
+  if (!cfg_has(cfg, "gsurf") || !cfg_has(cfg, "refpress") || !cfg_has(cfg, "refradius"))
+    throw IoError{"transit cfg: gsurf, refpress and refradius are required"};
+  gsurf = cfg_num(cfg, "gsurf", 0);
+  refpress = cfg_num(cfg, "refpress", 0) * 1e6;      // bar -> barye
+  refradius = cfg_num(cfg, "refradius", 0) * 1e5;    // km -> cm
+  if (cfg_has(cfg, "cloudtop")) { has_cloud = 1; cloudtop = std::pow(10.0, cfg_num(cfg, "cloudtop", 0)) * 1e6; }
+  if (cfg_has(cfg, "scattering")) { scat_flag = 1; scat_value = cfg_num(cfg, "scattering", 0); }
+
+  // ---- device
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw HipError{hipErrorNoDevice, "no HIP device: libbartrt computes on the GPU only"};
+  if (device < 0) {
+    const char *lr = std::getenv("LOCAL_RANK");
+    device = lr ? std::atoi(lr) % ndev : 0;
+  }
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+  // ---- tables to HBM
+  std::vector<double> wn_loc(wn_full.begin() + lo, wn_full.begin() + hi);
+  d_wn = dev_upload(wn_loc);
+  d_wn_full = dev_upload(wn_full);
+  if (M > 0) {
+    size_t n = (size_t)L * Nt * M * Wl;
+    double *h = nullptr;
+    HIPCHK(hipHostMalloc(&h, n * sizeof(double), hipHostMallocDefault));
+    try {
+      read_opacity_block(cfg["opacityfile"], oh, lo, hi, h);
+    } catch (...) { (void)hipHostFree(h); throw; }
+    HIPCHK(hipMalloc(&d_kappa, n * sizeof(double)));
+    HIPCHK(hipMemcpy(d_kappa, h, n * sizeof(double), hipMemcpyHostToDevice));
+    (void)hipHostFree(h);
+  }
+  // CIA: resample on the local grid (linear in wn, zero outside the file) and
+  // lay out nt+1 planes per pair (the extra plane repeats the last one so the
+  // kernel may always read planes j and j+1).
+  std::vector<double> cia_planes, cia_temp;
+  PrepArgs &pa = prep;
+  if (cfg_has(cfg, "csfile")) {
+    auto files = split_commas(cfg["csfile"]);
+    if ((int)files.size() > kMaxCia) throw IoError{"csfile: too many cross-section files"};
+    for (auto &fn : files) {
+      Cia c = read_cia(fn);
+      int cc = C++;
+      auto f1 = std::find(atm.species.begin(), atm.species.end(), c.s1);
+      auto f2 = std::find(atm.species.begin(), atm.species.end(), c.s2);
+      if (f1 == atm.species.end() || f2 == atm.species.end())
+        throw IoError{"cross-section file '" + fn + "': species not in the atmosphere file"};
+      pa.cia_s1[cc] = (int)(f1 - atm.species.begin());
+      pa.cia_s2[cc] = (int)(f2 - atm.species.begin());
+      pa.cia_nt[cc] = (int)c.temp.size();
+      pa.cia_toff[cc] = (int)cia_temp.size();
+      const size_t nw = c.wn.size();
+      for (size_t t = 0; t <= c.temp.size(); t++) {
+        size_t tt = std::min(t, c.temp.size() - 1);
+        const double *al = c.alpha.data() + tt * nw;
+        for (int i = 0; i < Wl; i++) {
+          double x = wn_loc[i], v = 0.0;
+          if (x >= c.wn.front() && x <= c.wn.back()) {
+            size_t j = std::upper_bound(c.wn.begin(), c.wn.end(), x) - c.wn.begin();
+            if (j >= nw) j = nw - 1;
+            if (j == 0) j = 1;
+            double x0 = c.wn[j - 1], x1 = c.wn[j];
+            // np.interp form: slope * (x - x0) + y0
+            v = (al[j] - al[j - 1]) / (x1 - x0) * (x - x0) + al[j - 1];
+            if (x == x1) v = al[j];
+          }
+          cia_planes.push_back(v);
+        }
+      }
+      cia_temp.insert(cia_temp.end(), c.temp.begin(), c.temp.end());
+    }
+  }
+  d_cia = dev_upload(cia_planes);
+  d_cia_temp = dev_upload(cia_temp);
+
+  std::vector<double> dlnp(std::max(L - 1, 1), 0.0);
+  for (int l = 0; l + 1 < L; l++) dlnp[l] = std::log(atm.press[l] / atm.press[l + 1]);
+  d_press = dev_upload(atm.press);
+  d_dlnp = dev_upload(dlnp);
+  d_mass = dev_upload(mass);
+  d_tgrid = dev_upload(tgrid);
+  d_opmol = dev_upload(opmol);
+
+  // hydrostatic reference layer (makeatm.py:229-247)
+  {
+    int ix = 0;
+    double best = std::fabs(atm.press[0] - refpress);
+    for (int i = 1; i < L; i++) {
+      double d = std::fabs(atm.press[i] - refpress);
+      if (d < best) { best = d; ix = i; }
+    }
+    pa.ref_idx = ix;
+    pa.ref_exact = atm.press[ix] == refpress;
+    pa.ref_ib = ix < L - 1 ? ix : ix - 1;
+    pa.ref_f = ix < L - 1 ? 0.0 : 1.0;
+    if (L == 1) { pa.ref_ib = 0; pa.ref_f = 0.0; }
+    double lp0 = std::log10(refpress);
+    for (int i = 0; i + 1 < L; i++) {
+      double la = std::log10(atm.press[i]), lb = std::log10(atm.press[i + 1]);
+      if ((lp0 <= la && lp0 >= lb) || (lp0 >= la && lp0 <= lb)) {
+        pa.ref_ib = i;
+        pa.ref_f = (lp0 - la) / (lb - la);
+        break;
+      }
+    }
+    pa.ref_lnp = std::log(refpress / atm.press[ix]);
+  }
+  pa.L = L; pa.S = S; pa.M = M; pa.Nt = Nt; pa.C = C;
+  pa.press = d_press; pa.dlnp = d_dlnp; pa.mass = d_mass; pa.tgrid = d_tgrid;
+  pa.opmol = d_opmol; pa.cia_temp = d_cia_temp;
+  pa.iH2 = iH2; pa.iHe = iHe;
+
+  RtArgs &r = rt;
+  r.L = L; r.M = M; r.Nt = Nt; r.C = C; r.A = A; r.W = Wl;
+  r.kappa = d_kappa; r.cia = d_cia; r.wn = d_wn;
+  for (int a = 0; a < A; a++) {
+    double lo_a = a == 0 ? 0.0 : 0.5 * (angles[a - 1] + angles[a]);
+    double hi_a = a == A - 1 ? 90.0 : 0.5 * (angles[a] + angles[a + 1]);
+    double sl = std::sin(lo_a * kPI / 180.0), sh = std::sin(hi_a * kPI / 180.0);
+    r.wgt[a] = kPI * (sh * sh - sl * sl);
+    r.invmu[a] = 1.0 / std::cos(angles[a] * kPI / 180.0);
+  }
+  HIPCHK(hipMalloc(&d_tau, sizeof(double) * (size_t)Wl * L));
+  HIPCHK(hipMalloc(&d_last, sizeof(int) * (size_t)Wl));
+  ensure_walkers(16);
+}
+
+void Engine::ensure_walkers(int n) {
+  if (n <= cap_walkers) return;
+  int cap = std::max(n, cap_walkers * 2);
+  HIPCHK(hipDeviceSynchronize());
+  auto re = [&](auto *&p, size_t count) {
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(*p)));
+  };
+  re(d_prof, (size_t)cap * (S + 1) * L);
+  re(d_coef, (size_t)cap * L * coef_stride(M, C));
+  re(d_idx, (size_t)cap * L * idx_stride(C));
+  re(d_kstop, (size_t)cap);
+  re(d_ok, (size_t)cap);
+  re(d_spec, (size_t)cap * W());
+  cap_walkers = cap;
+}
+
+void Engine::ensure_pin(size_t bytes) {
+  if (bytes <= h_pin_bytes) return;
+  if (h_pin) HIPCHK(hipHostFree(h_pin));
+  h_pin = nullptr;
+  HIPCHK(hipHostMalloc(&h_pin, bytes, hipHostMallocDefault));
+  h_pin_bytes = bytes;
+}
+
+void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
+                     unsigned char *d_okp, hipStream_t st, bool want_tau) {
+  if (n <= 0) return;
+  // coefficient workspaces are sized by cap_walkers; the caller's profile and
+  // spectrum buffers are used in place
+  if (n > cap_walkers) {
+    // grow coef/idx only (d_prof/d_spec of the caller are separate buffers)
+    ensure_walkers(n);
+  }
+  PrepArgs pa = prep;
+  pa.nwalkers = n;
+  pa.prof = d_prof_in;
+  pa.gsurf = gsurf; pa.refradius = refradius;
+  pa.scat_flag = scat_flag; pa.scat_value = scat_value;
+  pa.has_cloud = has_cloud; pa.cloudtop = cloudtop;
+  pa.coef = d_coef; pa.idx = d_idx; pa.kstop = d_kstop;
+  pa.ok = d_okp ? d_okp : d_ok;
+  HIPCHK(launch_prep(pa, st));
+
+  RtArgs r = rt;
+  r.nwalkers = n;
+  r.coef = d_coef; r.idx = d_idx; r.kstop = d_kstop;
+  r.cloud_on = has_cloud;
+  r.toomuch = toomuch;
+  r.spec = d_spec_out;
+  r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;
+  r.last_out = (want_tau && n == 1) ? d_last : nullptr;
+  int block = 256;
+  if ((long)((r.W + 255) / 256) * n < 512) block = 64;
+  r.ntiles = (r.W + block - 1) / block;
+  if (timing) {
+    while ((int)ev.size() < ev_used + 2) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      ev.push_back(e);
+    }
+    HIPCHK(hipEventRecord(ev[ev_used], st));
+  }
+  HIPCHK(launch_rt(r, block, st));
+  if (timing) {
+    HIPCHK(hipEventRecord(ev[ev_used + 1], st));
+    ev_used += 2;
+  }
+  if (want_tau && n == 1) tau_valid = true;
+}
+
+}  // namespace bartrt

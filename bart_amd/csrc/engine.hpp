@@ -1,0 +1,76 @@
+// Host-side engine state: parsed inputs, HBM-resident tables, workspaces.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "io.hpp"
+#include "kernels.hpp"
+
+namespace bartrt {
+
+hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
+hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st);
+
+struct StepArgs;  // converters around the engine (step.hip)
+
+struct Engine {
+  // configuration
+  TCfg cfg;
+  Atm atm;
+  MolInfo mol;
+  int L = 0, S = 0, M = 0, Nt = 0, C = 0, A = 0;
+  int Wfull = 0, lo = 0, hi = 0;  // this process holds [lo, hi) of the grid
+  int W() const { return hi - lo; }
+  std::vector<double> wn_full, tgrid, mass, angles;
+  std::vector<int> opmol;
+  double toomuch = 20.0, gsurf = 0, refpress = 0, refradius = 0;
+  int scat_flag = 0, iH2 = -1, iHe = -1, has_cloud = 0;
+  double scat_value = 0, cloudtop = 0;
+  int device = 0;
+  // device-resident inputs
+  double *d_kappa = nullptr, *d_cia = nullptr, *d_wn = nullptr, *d_wn_full = nullptr;
+  double *d_press = nullptr, *d_dlnp = nullptr, *d_mass = nullptr, *d_tgrid = nullptr;
+  double *d_cia_temp = nullptr;
+  int *d_opmol = nullptr;
+  PrepArgs prep{};  // static part filled at init
+  RtArgs rt{};
+  // workspaces (grown on demand, never inside a timed launch sequence twice)
+  int cap_walkers = 0;
+  double *d_prof = nullptr, *d_coef = nullptr, *d_spec = nullptr;
+  int *d_idx = nullptr, *d_kstop = nullptr;
+  unsigned char *d_ok = nullptr;
+  double *d_tau = nullptr;  // [W][L] of the last single-walker run
+  int *d_last = nullptr;
+  bool tau_valid = false;
+  double *h_pin = nullptr;  // pinned staging
+  size_t h_pin_bytes = 0;
+  hipStream_t stream = nullptr;
+  // timing of RT launches
+  bool timing = false;
+  std::vector<hipEvent_t> ev;
+  int ev_used = 0;
+  // per-step converters
+  StepArgs *step = nullptr;
+
+  ~Engine();
+  void init(int argc, const char **argv);
+  void ensure_walkers(int n);
+  void ensure_pin(size_t bytes);
+  // d_prof_in -> d_spec_out ([n][W]); records events when timing
+  void run_dev(const double *d_prof_in, int n, double *d_spec_out, unsigned char *d_okp,
+               hipStream_t st, bool want_tau);
+};
+
+struct HipError {
+  hipError_t e;
+  const char *what;
+};
+#define HIPCHK(x)                                  \
+  do {                                             \
+    hipError_t _e = (x);                           \
+    if (_e != hipSuccess) throw HipError{_e, #x};  \
+  } while (0)
+
+}  // namespace bartrt

@@ -1,0 +1,223 @@
+// Host-side readers for the engine's input files (transit formats).
+#include "io.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace bartrt {
+
+static std::vector<std::string> split_ws(const std::string &s) {
+  std::vector<std::string> out;
+  std::istringstream is(s);
+  std::string t;
+  while (is >> t) out.push_back(t);
+  return out;
+}
+
+static std::string trim(const std::string &s) {
+  size_t a = s.find_first_not_of(" \t\r\n");
+  if (a == std::string::npos) return "";
+  size_t b = s.find_last_not_of(" \t\r\n");
+  return s.substr(a, b - a + 1);
+}
+
+static double to_num(const std::string &s, const std::string &what) {
+  char *end = nullptr;
+  double v = std::strtod(s.c_str(), &end);
+  if (end == s.c_str()) throw IoError{"cannot parse number '" + s + "' in " + what};
+  return v;
+}
+
+TCfg read_tcfg(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw IoError{"cannot open transit configuration file '" + path + "'"};
+  TCfg c;
+  std::string line;
+  while (std::getline(f, line)) {
+    line = trim(line);
+    if (line.empty() || line[0] == '#' || line[0] == ';') continue;
+    size_t sp = line.find_first_of(" \t");
+    std::string key = line.substr(0, sp);
+    std::string val = sp == std::string::npos ? "" : trim(line.substr(sp));
+    c[key] = val;
+  }
+  return c;
+}
+
+bool cfg_has(const TCfg &c, const std::string &k) {
+  auto it = c.find(k);
+  return it != c.end() && !it->second.empty();
+}
+
+double cfg_num(const TCfg &c, const std::string &k, double dflt) {
+  if (!cfg_has(c, k)) return dflt;
+  return to_num(split_ws(c.at(k))[0], "key " + k);
+}
+
+std::vector<double> cfg_list(const TCfg &c, const std::string &k) {
+  std::vector<double> out;
+  if (!cfg_has(c, k)) return out;
+  for (auto &t : split_ws(c.at(k))) out.push_back(to_num(t, "key " + k));
+  return out;
+}
+
+Atm read_atm(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw IoError{"cannot open atmosphere file '" + path + "'"};
+  Atm a;
+  double ur = 1e5, up = 1e6, ut = 1.0;  // defaults: km, bar, K
+  std::string line;
+  bool in_data = false;
+  while (std::getline(f, line)) {
+    std::string s = trim(line);
+    if (in_data) {
+      if (s.empty()) break;
+      auto t = split_ws(s);
+      size_t S = a.species.size();
+      if (t.size() != S + 3)
+        throw IoError{"atmosphere file '" + path + "': expected radius, pressure, "
+                      "temperature and " + std::to_string(S) + " abundances per row"};
+      a.radius.push_back(to_num(t[0], path) * ur);
+      a.press.push_back(to_num(t[1], path) * up);
+      a.temp.push_back(to_num(t[2], path) * ut);
+      for (size_t i = 0; i < S; i++) a.abund.push_back(to_num(t[3 + i], path));
+      continue;
+    }
+    auto t = split_ws(s);
+    if (t.size() == 2 && t[0] == "ur") ur = to_num(t[1], path);
+    else if (t.size() == 2 && t[0] == "up") up = to_num(t[1], path);
+    else if (t.size() == 2 && t[0] == "ut") ut = to_num(t[1], path);
+    else if (t.size() == 2 && t[0] == "q") {
+      if (t[1] != "number") throw IoError{"atmosphere file: only 'q number' abundances are supported"};
+    } else if (s == "#SPECIES") {
+      if (!std::getline(f, line)) break;
+      a.species = split_ws(line);
+    } else if (s == "#TEADATA") {
+      std::getline(f, line);  // column header
+      in_data = true;
+    }
+  }
+  if (a.species.empty() || a.press.empty())
+    throw IoError{"atmosphere file '" + path + "': no #SPECIES / #TEADATA content"};
+  return a;
+}
+
+int MolInfo::find_name(const std::string &n) const {
+  for (size_t i = 0; i < name.size(); i++)
+    if (name[i] == n) return (int)i;
+  return -1;
+}
+int MolInfo::find_id(int v) const {
+  for (size_t i = 0; i < id.size(); i++)
+    if (id[i] == v) return (int)i;
+  return -1;
+}
+
+MolInfo read_molfile(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw IoError{"cannot open molecule file '" + path + "'"};
+  MolInfo m;
+  std::string line;
+  while (std::getline(f, line)) {
+    size_t h = line.find('#');
+    if (h != std::string::npos) line = line.substr(0, h);
+    auto t = split_ws(line);
+    if (t.size() < 4) continue;
+    m.id.push_back((int)to_num(t[0], path));
+    m.name.push_back(t[1]);
+    m.mass.push_back(to_num(t[2], path));
+    m.diam.push_back(to_num(t[3], path));
+  }
+  if (m.id.empty()) throw IoError{"molecule file '" + path + "' holds no entries"};
+  return m;
+}
+
+OpacityHeader read_opacity_header(const std::string &path) {
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) throw IoError{"cannot open opacity file '" + path + "'"};
+  OpacityHeader h;
+  long dims[4];
+  bool ok = std::fread(dims, sizeof(long), 4, fp) == 4;
+  if (ok) {
+    h.nmol = dims[0]; h.ntemp = dims[1]; h.nlayer = dims[2]; h.nwave = dims[3];
+    ok = h.nmol > 0 && h.ntemp > 1 && h.nlayer > 0 && h.nwave > 0 &&
+         h.nmol < 4096 && h.ntemp < 100000 && h.nlayer < 100000;
+  }
+  if (ok) {
+    h.molid.resize(h.nmol); h.temp.resize(h.ntemp);
+    h.press.resize(h.nlayer); h.wn.resize(h.nwave);
+    ok = std::fread(h.molid.data(), sizeof(int), h.nmol, fp) == (size_t)h.nmol &&
+         std::fread(h.temp.data(), sizeof(double), h.ntemp, fp) == (size_t)h.ntemp &&
+         std::fread(h.press.data(), sizeof(double), h.nlayer, fp) == (size_t)h.nlayer &&
+         std::fread(h.wn.data(), sizeof(double), h.nwave, fp) == (size_t)h.nwave;
+    h.data_offset = std::ftell(fp);
+  }
+  if (ok) {
+    std::fseek(fp, 0, SEEK_END);
+    long need = h.data_offset + 8L * h.nlayer * h.ntemp * h.nmol * h.nwave;
+    ok = std::ftell(fp) >= need;
+  }
+  std::fclose(fp);
+  if (!ok) throw IoError{"opacity file '" + path + "' is truncated or not an opacity grid"};
+  return h;
+}
+
+void read_opacity_block(const std::string &path, const OpacityHeader &h, long lo,
+                        long hi, double *dst) {
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) throw IoError{"cannot open opacity file '" + path + "'"};
+  const long nrows = h.nlayer * h.ntemp * h.nmol, w = hi - lo;
+  bool ok = true;
+  if (lo == 0 && hi == h.nwave) {
+    std::fseek(fp, h.data_offset, SEEK_SET);
+    ok = std::fread(dst, sizeof(double), (size_t)nrows * w, fp) == (size_t)nrows * w;
+  } else {
+    for (long r = 0; r < nrows && ok; r++) {
+      std::fseek(fp, h.data_offset + 8L * (r * h.nwave + lo), SEEK_SET);
+      ok = std::fread(dst + r * w, sizeof(double), w, fp) == (size_t)w;
+    }
+  }
+  std::fclose(fp);
+  if (!ok) throw IoError{"short read from opacity file '" + path + "'"};
+}
+
+Cia read_cia(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw IoError{"cannot open cross-section file '" + path + "'"};
+  Cia c;
+  std::string line, mode;
+  std::vector<std::vector<double>> rows;
+  while (std::getline(f, line)) {
+    std::string s = trim(line);
+    if (s.empty() || s[0] == '#') continue;
+    if (s[0] == '@') { mode = s; continue; }
+    auto t = split_ws(s);
+    if (mode == "@SPECIES" && c.s1.empty()) {
+      if (t.size() != 2) throw IoError{"cross-section file '" + path + "': @SPECIES needs two names"};
+      c.s1 = t[0]; c.s2 = t[1];
+    } else if (mode == "@TEMPERATURES" && c.temp.empty()) {
+      for (auto &x : t) c.temp.push_back(to_num(x, path));
+    } else if (mode == "@DATA") {
+      if (t.size() != c.temp.size() + 1)
+        throw IoError{"cross-section file '" + path + "': row width does not match @TEMPERATURES"};
+      std::vector<double> r;
+      for (auto &x : t) r.push_back(to_num(x, path));
+      rows.push_back(r);
+    }
+  }
+  if (c.s1.empty() || c.temp.empty() || rows.size() < 2)
+    throw IoError{"cross-section file '" + path + "' is incomplete"};
+  size_t nw = rows.size(), nt = c.temp.size();
+  c.wn.resize(nw);
+  c.alpha.resize(nt * nw);
+  for (size_t i = 0; i < nw; i++) {
+    c.wn[i] = rows[i][0];
+    for (size_t t = 0; t < nt; t++) c.alpha[t * nw + i] = rows[i][1 + t];
+  }
+  return c;
+}
+
+}  // namespace bartrt

@@ -1,0 +1,77 @@
+// Device-side argument blocks shared by the kernels and the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bartrt {
+
+// Physical constants, cgs.  H, LS, KB: the values BART copies from transit
+// (reference code/constants.py:13-16).
+constexpr double kH = 6.6260755e-27;
+constexpr double kLS = 2.99792458e10;
+constexpr double kKB = 1.380658e-16;
+constexpr double kAMU = 1.66053886e-24;
+constexpr double kAMAGAT = 2.68679e19;
+constexpr double kPI = 3.141592653589793;
+constexpr double kRaySigma0 = 2.52e-28, kRayLambda0 = 7.5e-5;
+constexpr double kPolH2 = 0.8059e-24, kPolHe = 0.2051e-24;
+
+constexpr int kMaxAngles = 16;
+constexpr int kMaxCia = 4;
+constexpr int kMaxMol = 16;
+
+// Per-layer coefficient record produced by prep_profiles, consumed by the RT
+// kernel from LDS.  Layer order is top -> bottom (k = 0 is the top layer).
+//   [0]            dr_k   = r_{k-1} - r_k (cm), 0 for k = 0
+//   [1]            c2/T_k = (h c / k_B) / T_k  (cm)
+//   [2 .. 2+2M)    (rho_m (1-f), rho_m f) per table molecule
+//   [.. +2C)       (n1 n2 (1-f), n1 n2 f) / amagat^2 per CIA table
+//   [last]         Rayleigh coefficient (multiplies wn^4)
+__host__ __device__ inline int coef_stride(int M, int C) { return 3 + 2 * M + 2 * C; }
+// Integer record: [0] table temperature index, [1+c] first CIA plane of pair c.
+__host__ __device__ inline int idx_stride(int C) { return 1 + C; }
+
+struct PrepArgs {
+  int L, S, M, Nt, C, nwalkers;
+  const double *prof;      // [nw][(S+1)][L]
+  const double *press;     // [L] barye, atm order (0 = bottom)
+  const double *dlnp;      // [L-1] log(p[i]/p[i+1])
+  const double *mass;      // [S] amu
+  const double *tgrid;     // [Nt]
+  const int *opmol;        // [M] species index
+  int cia_s1[kMaxCia], cia_s2[kMaxCia], cia_nt[kMaxCia], cia_toff[kMaxCia];
+  const double *cia_temp;  // concatenated
+  // hydrostatic reference (code/makeatm.py:183-263)
+  int ref_idx;             // layer closest to refpress
+  int ref_exact;           // press[ref_idx] == refpress
+  int ref_ib;              // bracket [ib, ib+1] holding refpress in log10 p
+  double ref_f;            // interpolation fraction inside the bracket
+  double ref_lnp;          // log(refpress / press[ref_idx])
+  double gsurf, refradius;
+  // scattering / cloud
+  int scat_flag, iH2, iHe, has_cloud;
+  double scat_value, cloudtop;
+  // outputs
+  double *coef;            // [nw][L][coef_stride]
+  int *idx;                // [nw][L][idx_stride]
+  int *kstop;              // [nw] deepest layer index k to integrate to
+  unsigned char *ok;       // [nw]
+};
+
+struct RtArgs {
+  int L, M, Nt, C, A, W, nwalkers, ntiles;
+  const double *kappa;     // [L][Nt][M][W]
+  const double *cia;       // [planes][W]
+  const double *wn;        // [W]
+  const double *coef;
+  const int *idx;
+  const int *kstop;
+  int cloud_on;            // kstop marks a cloud deck (adds surface emission)
+  double toomuch;
+  double invmu[kMaxAngles];
+  double wgt[kMaxAngles];  // pi (sin^2 hi - sin^2 lo)
+  double *spec;            // [nw][W]
+  double *tau_out;         // optional [W][L] (single walker), may be null
+  int *last_out;           // optional [W]
+};
+
+}  // namespace bartrt

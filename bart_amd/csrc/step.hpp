@@ -1,0 +1,53 @@
+// Input/output converters of the per-step callable (reference
+// code/BARTfunc.py:309-399), batched over walkers on the device.
+#pragma once
+#include "engine.hpp"
+
+namespace bartrt {
+
+enum { PT_LINE = 0, PT_ISO = 1 };
+
+struct StepArgs {
+  int pttype = PT_LINE, nPT = 5;
+  double ptargs[5] = {0, 0, 0, 0, 0};  // R_star[m], T_star[K], T_int[K], sma[m], g[cm s-2]
+  int tint_thorngren = 0;
+  double tmin = 400, tmax = 3000;
+  int nmolfit = 0, nfilters = 0, solution = 0;
+  double rprs = 0;
+  int ebalance = 0;
+  double e_in = 0, e_fac = 0;  // reject when trapz(spec) * e_fac > e_in
+  int iH2 = -1, iHe = -1;
+  int nwin = 0;                // total filter samples
+  // device
+  double *d_abund = nullptr;   // [L][S] base abundances
+  double *d_ratio = nullptr;   // [L] H2/He of the base abundances
+  double *d_pbar = nullptr;    // [L] pressure in bar, atm order
+  int *d_imol = nullptr;       // [nmolfit]
+  unsigned char *d_metal = nullptr;  // [S] 1 for metals
+  int *d_idx0 = nullptr, *d_npts = nullptr, *d_woff = nullptr;  // [F]
+  double *d_nifilter = nullptr, *d_istarfl = nullptr;          // [nwin]
+  // workspaces
+  int cap = 0;
+  double *d_params = nullptr, *d_prof = nullptr, *d_spec = nullptr, *d_band = nullptr;
+  int *d_status = nullptr;
+  ~StepArgs();
+};
+
+void step_setup(Engine &e, const double *ptargs5, int tint_thorngren, int pttype,
+                double tmin, double tmax, const double *abund, int nmolfit,
+                const int *imol, int nfilters, const int *idx0, const int *npts,
+                const double *nifilter, const double *istarfl, double rprs, int solution);
+void step_set_ebalance(Engine &e, int on, double e_in, double e_fac);
+void step_ensure(Engine &e, int n);
+// params[n][npars] -> prof[n][(S+1)][L], status[n]
+void step_profiles_dev(Engine &e, const double *d_params, int n, int npars, double *d_prof,
+                       int *d_status, hipStream_t st);
+// full-grid spectra [n][Wfull] -> bandflux[n][F]; may flip status to 3 (energy)
+void step_bandflux_dev(Engine &e, const double *d_spec_full, int n, int *d_status,
+                       double *d_bandflux, hipStream_t st);
+void step_run_dev(Engine &e, const double *d_params, int n, int npars, double *d_bandflux,
+                  int *d_status, double *d_spec, hipStream_t st);
+void step_run_host(Engine &e, const double *params, int n, int npars, double *bandflux,
+                   int *status);
+
+}  // namespace bartrt

@@ -1,0 +1,214 @@
+"""Batched / device-resident front end of libbartrt.so.
+
+``transit_module`` keeps the reference's one-profile-per-call shape; this
+module adds what the MI355X build needs on top of the same engine: walker
+batches, HBM-resident tensors (torch is used only as the owner of device
+memory, streams and the RCCL process group), wavenumber-block sharding with an
+all-gather that reassembles each spectrum, and the per-step
+converters of code/BARTfunc.py:309-399 on the device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import transit_module as trm
+
+_check, _ptr = trm.check, trm._ptr
+
+
+def init(tcfg: str, shard: tuple[int, int] | None = None, device: int | None = None) -> None:
+    argv = ["transit", "-c", tcfg]
+    if shard is not None:
+        argv += ["--shard", str(shard[0]), str(shard[1])]
+    if device is not None:
+        argv += ["--device", str(device)]
+    trm.transit_init(len(argv), argv)
+
+
+def nlayers() -> int:
+    return _check(trm.lib().bartrt_get_nlayers())
+
+
+def nspecies() -> int:
+    return _check(trm.lib().bartrt_get_nspecies())
+
+
+def nprof() -> int:
+    return _check(trm.lib().bartrt_get_nprof())
+
+
+def species() -> list[str]:
+    buf = C.create_string_buffer(4096)
+    _check(trm.lib().bartrt_get_species(buf, 4096))
+    return buf.value.decode().split()
+
+
+def pressure() -> np.ndarray:
+    out = np.zeros(nlayers())
+    _check(trm.lib().bartrt_get_pressure(_ptr(out), out.size))
+    return out
+
+
+def local_range() -> tuple[int, int]:
+    lo, hi = C.c_int(), C.c_int()
+    _check(trm.lib().bartrt_get_local_range(C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def run_batch(profiles: np.ndarray, want_ok: bool = False):
+    """profiles [nwalkers, (S+1)*L] (host) -> spectra [nwalkers, local samples]."""
+    prof = np.ascontiguousarray(profiles, np.double)
+    prof = prof.reshape(-1, nprof())
+    lo, hi = local_range()
+    spec = np.zeros((prof.shape[0], hi - lo))
+    ok = np.zeros(prof.shape[0], np.uint8)
+    _check(trm.lib().bartrt_run_transit_batch(_ptr(prof), prof.shape[0], prof.shape[1],
+                                              _ptr(spec), hi - lo, _ptr(ok)))
+    return (spec, ok) if want_ok else spec
+
+
+def get_tau():
+    """Optical depth of the last single-profile run: (tau[W_local, L], last[W_local]),
+    layer index 0 = top (the tau.dat convention, code/cf.py:68-94)."""
+    lo, hi = local_range()
+    tau = np.zeros((hi - lo, nlayers()))
+    last = np.zeros(hi - lo, np.int32)
+    _check(trm.lib().bartrt_get_tau(_ptr(tau), _ptr(last), hi - lo, nlayers()))
+    return tau, last
+
+
+# ---- device-resident (torch tensors own the memory) ----------------------
+def _stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def run_batch_dev(d_prof, d_spec=None, stream=None):
+    """d_prof: float64 CUDA tensor [nwalkers, (S+1)*L]; returns [nwalkers, W_local]
+    on the same device.  Asynchronous on torch's current stream."""
+    import torch
+    assert d_prof.is_cuda and d_prof.dtype == torch.float64 and d_prof.is_contiguous()
+    n = d_prof.shape[0]
+    lo, hi = local_range()
+    if d_spec is None:
+        d_spec = torch.empty((n, hi - lo), dtype=torch.float64, device=d_prof.device)
+    _check(trm.lib().bartrt_run_transit_batch_dev(
+        C.c_void_p(d_prof.data_ptr()), n, C.c_void_p(d_spec.data_ptr()), None,
+        _stream_ptr(stream)))
+    return d_spec
+
+
+def run_batch_sharded(d_prof, group=None):
+    """Every rank holds one wavenumber block of the tables and the full (tiny)
+    profile batch; each computes spec[nwalkers, W/G] and one RCCL all-gather
+    reassembles spec[nwalkers, W] on every rank."""
+    import torch
+    import torch.distributed as dist
+    local = run_batch_dev(d_prof)
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    return allgather_blocks(local, group)
+
+
+def allgather_blocks(local, group=None):
+    """local [n, W_r] on rank r (block sizes may differ by one sample) ->
+    [n, sum_r W_r] on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = local.shape[0]
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device),
+                    group=group)
+    sizes = [int(s.item()) for s in sizes]
+    wmax = max(sizes)
+    send = local
+    if local.shape[1] != wmax:
+        send = torch.zeros((n, wmax), dtype=local.dtype, device=local.device)
+        send[:, :local.shape[1]] = local
+    out = torch.empty((world, n, wmax), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    return torch.cat([out[r, :, :sizes[r]] for r in range(world)], dim=1)
+
+
+# ---- per-step converters --------------------------------------------------
+def step_setup(ptargs5, tmin, tmax, abund, imol, idx0, npts, nifilter, istarfl,
+               rprs, solution=0, pttype=0, tint_thorngren=False):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    ptargs5 = a(ptargs5 if ptargs5 is not None else np.zeros(5), np.double)
+    abund = a(abund, np.double)
+    imol = a(imol, np.int32)
+    idx0 = a(idx0, np.int32)
+    npts = a(npts, np.int32)
+    nif = a(nifilter, np.double)
+    star = a(istarfl, np.double) if istarfl is not None else None
+    _check(trm.lib().bartrt_step_setup(
+        _ptr(ptargs5), int(bool(tint_thorngren)), int(pttype), float(tmin), float(tmax),
+        _ptr(abund), imol.size, _ptr(imol), idx0.size, _ptr(idx0), _ptr(npts), _ptr(nif),
+        _ptr(star) if star is not None else None, float(rprs), int(solution)))
+
+
+def step_set_ebalance(on, e_in, e_fac):
+    _check(trm.lib().bartrt_step_set_ebalance(int(bool(on)), float(e_in), float(e_fac)))
+
+
+def step_batch(params: np.ndarray, nfilters: int):
+    p = np.ascontiguousarray(params, np.double)
+    p = p.reshape(-1, p.shape[-1])
+    band = np.zeros((p.shape[0], nfilters))
+    status = np.zeros(p.shape[0], np.int32)
+    _check(trm.lib().bartrt_step_batch(_ptr(p), p.shape[0], p.shape[1], _ptr(band), _ptr(status)))
+    return band, status
+
+
+def step_batch_dev(d_params, nfilters, want_spec=False, stream=None):
+    import torch
+    n, npars = d_params.shape
+    dev = d_params.device
+    band = torch.empty((n, nfilters), dtype=torch.float64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    spec = None
+    if want_spec:
+        spec = torch.empty((n, trm.get_no_samples()), dtype=torch.float64, device=dev)
+    _check(trm.lib().bartrt_step_batch_dev(
+        C.c_void_p(d_params.data_ptr()), n, npars, C.c_void_p(band.data_ptr()),
+        C.c_void_p(status.data_ptr()), C.c_void_p(spec.data_ptr()) if want_spec else None,
+        _stream_ptr(stream)))
+    return (band, status, spec) if want_spec else (band, status)
+
+
+def step_batch_sharded(d_params, nfilters, group=None, stream=None):
+    """Per-step callable on a wavenumber-sharded node: profiles on every rank,
+    RT on the local block, all-gather, band integration on the full grid."""
+    import torch
+    n, npars = d_params.shape
+    dev = d_params.device
+    prof = torch.empty((n, nprof()), dtype=torch.float64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    _check(trm.lib().bartrt_step_profiles_dev(
+        C.c_void_p(d_params.data_ptr()), n, npars, C.c_void_p(prof.data_ptr()),
+        C.c_void_p(status.data_ptr()), _stream_ptr(stream)))
+    spec = run_batch_sharded(prof, group)
+    band = torch.empty((n, nfilters), dtype=torch.float64, device=dev)
+    _check(trm.lib().bartrt_step_bandflux_dev(
+        C.c_void_p(spec.data_ptr()), n, C.c_void_p(status.data_ptr()),
+        C.c_void_p(band.data_ptr()), _stream_ptr(stream)))
+    return band, status, spec
+
+
+def timing_begin():
+    _check(trm.lib().bartrt_timing_begin())
+
+
+def timing_end():
+    ms, n = C.c_double(), C.c_int()
+    _check(trm.lib().bartrt_timing_end(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
+def algorithmic_bytes(nwalkers: int) -> float:
+    return trm.lib().bartrt_algorithmic_bytes(int(nwalkers))

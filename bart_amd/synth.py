@@ -1,0 +1,264 @@
+"""Synthetic inputs in the file formats the engine reads at ``transit_init``.
+
+The reference ships none of the engine's inputs (no ``.atm``, ``molecules.dat``,
+CIA file, TLI or opacity table: SURVEY.md Appendix B), so tests, ``smoke()`` and
+``bench.py`` generate seeded stand-ins with the writers below.  Formats:
+
+* atmosphere file -- what ``makeatm.makeRadius`` + ``makeatm.reformat`` write
+  (reference code/makeatm.py:551-603, 841-896): ``ur/up/q`` unit lines,
+  ``#SPECIES``, ``#TEADATA``, a column header, rows bottom->top of
+  ``radius[km] pressure[bar] temp[K] abundances...``.
+* transit configuration file -- ``key value`` lines
+  (reference examples/demo/transit_demo.cfg:1-66, code/makecfg.py:91-108).
+* opacity grid, CIA and molecule files -- layouts of DESIGN.md "File formats"
+  (restated from the published Transit description; unverified against source).
+"""
+from __future__ import annotations
+
+import os
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# name -> (ID, mass [amu], collision diameter [Angstrom])
+MOLECULES = {
+    "H2":  (105, 2.01588, 2.89),
+    "He":  (106, 4.002602, 2.60),
+    "H2O": (101, 18.01528, 3.20),
+    "CO":  (102, 28.0101, 3.69),
+    "CO2": (103, 44.0095, 3.30),
+    "CH4": (104, 16.0425, 3.80),
+    "N2":  (107, 28.0134, 3.64),
+    "NH3": (108, 17.03052, 2.60),
+    "H":   (109, 1.00794, 2.50),
+    "C2H2": (110, 26.0373, 3.30),
+    "C2H4": (111, 28.0532, 3.90),
+    "HCN": (112, 27.0253, 3.63),
+    "TiO": (113, 63.8664, 3.50),
+    "VO":  (114, 66.9409, 3.50),
+    "H-":  (115, 1.00849, 2.50),
+    "e-":  (116, 0.000548579909, 1.00),
+}
+
+
+def write_molfile(path: str, names=None) -> None:
+    names = list(MOLECULES) if names is None else names
+    with open(path, "w") as f:
+        f.write("# Molecule file: ID  name  mass(amu)  diameter(Angstrom)\n")
+        for n in names:
+            i, m, d = MOLECULES[n]
+            f.write(f"{i:4d}  {n:6s} {m:.9g}  {d:.3f}\n")
+
+
+def write_atm(path: str, species, press_bar, temp, abund, radius_km) -> None:
+    """Rows are written in the order given (must be bottom->top, as
+    makeatm.reformat leaves them: makeatm.py:880-883)."""
+    press_bar = np.asarray(press_bar, float)
+    with open(path, "w") as f:
+        f.write("# Synthetic atmosphere file (bart_amd.synth), transit layout.\n")
+        f.write("# Units: pressure (bar), temperature (K), abundance (unitless).\n\n")
+        f.write("#Values units:\nur 1e5\nup 1e6\nq number\n")
+        f.write("#SPECIES\n" + " ".join(species) + "\n\n")
+        f.write("#TEADATA\n")
+        f.write("#Radius".ljust(11) + "Pressure".ljust(11) + "Temp".ljust(8)
+                + "".join(s.ljust(14) for s in species) + "\n")
+        for i in range(len(press_bar)):
+            f.write("%10.3f %10.4e %7.2f " % (radius_km[i], press_bar[i], temp[i]))
+            f.write(" ".join("%1.4e" % a for a in abund[i]) + " \n")
+
+
+def write_tcfg(path: str, keys: dict) -> None:
+    with open(path, "w") as f:
+        f.write("# transit configuration file (key value), generated\n")
+        for k, v in keys.items():
+            if v is None:
+                continue
+            if isinstance(v, (list, tuple, np.ndarray)):
+                v = " ".join(str(x) for x in v)
+            f.write(f"{k} {v}\n")
+
+
+def write_opacity(path: str, mol_ids, temps, press_barye, wn, kappa=None,
+                  plane_fn=None) -> None:
+    """Opacity grid: 4 x int64 (Nmol, Ntemp, Nlayer, Nwave); int32 molID[Nmol];
+    f64 temp[Ntemp]; f64 press[Nlayer] (barye); f64 wn[Nwave];
+    f64 o[Nlayer][Ntemp][Nmol][Nwave] in cm2/g.  ``plane_fn(l)`` may supply the
+    [Ntemp][Nmol][Nwave] slab of one layer at a time for big tables."""
+    mol_ids = np.asarray(mol_ids, np.int32)
+    temps = np.asarray(temps, np.float64)
+    press_barye = np.asarray(press_barye, np.float64)
+    wn = np.asarray(wn, np.float64)
+    with open(path, "wb") as f:
+        f.write(struct.pack("=4q", len(mol_ids), len(temps), len(press_barye), len(wn)))
+        f.write(mol_ids.tobytes())
+        f.write(temps.tobytes())
+        f.write(press_barye.tobytes())
+        f.write(wn.tobytes())
+        if kappa is not None:
+            k = np.ascontiguousarray(kappa, np.float64)
+            assert k.shape == (len(press_barye), len(temps), len(mol_ids), len(wn))
+            f.write(k.tobytes())
+        else:
+            for l in range(len(press_barye)):
+                s = np.ascontiguousarray(plane_fn(l), np.float64)
+                assert s.shape == (len(temps), len(mol_ids), len(wn))
+                f.write(s.tobytes())
+
+
+def write_cia(path: str, s1: str, s2: str, temps, wn, alpha) -> None:
+    """Cross-section (CIA) text file: ``@SPECIES`` pair, ``@TEMPERATURES`` row,
+    ``@DATA`` rows of ``wn  alpha(T1) alpha(T2) ...`` in cm-1 amagat-2."""
+    alpha = np.asarray(alpha, float)
+    with open(path, "w") as f:
+        f.write("# Synthetic collision-induced-absorption file (bart_amd.synth)\n")
+        f.write("@SPECIES\n%s %s\n\n" % (s1, s2))
+        f.write("@TEMPERATURES\n" + " ".join("%.1f" % t for t in temps) + "\n\n")
+        f.write("# wavenumber (cm-1), absorption (cm-1 amagat-2)\n@DATA\n")
+        for i, w in enumerate(wn):
+            f.write("%.4f " % w + " ".join("%.9e" % a for a in alpha[:, i]) + "\n")
+
+
+def write_filter(path: str, wl_um, transm) -> None:
+    """Two-column filter file, wavelength in microns (read by wine.readfilter,
+    reference code/wine.py:16-66)."""
+    with open(path, "w") as f:
+        f.write("# synthetic filter: wavelength(um) response\n")
+        for w, t in zip(wl_um, transm):
+            f.write("%.6f %.6e\n" % (w, t))
+
+
+# ---------------------------------------------------------------------------
+@dataclass
+class Case:
+    """A generated engine input set (paths + the arrays behind them)."""
+    dir: str
+    tcfg: str
+    atm: str
+    molfile: str
+    opacity: str
+    cia: list
+    species: list
+    opmol: list
+    press_bar: np.ndarray      # [L] bottom->top
+    temp0: np.ndarray          # [L]
+    abund0: np.ndarray         # [L][S]
+    radius_km: np.ndarray
+    wn: np.ndarray
+    tgrid: np.ndarray
+    keys: dict = field(default_factory=dict)
+
+    def profiles(self, temp=None, abund=None) -> np.ndarray:
+        """The (S+1, L) array BARTfunc.py:213-222 builds."""
+        t = self.temp0 if temp is None else temp
+        a = self.abund0 if abund is None else abund
+        p = np.zeros((len(self.species) + 1, len(self.press_bar)))
+        p[0] = t
+        p[1:] = np.asarray(a).T
+        return p
+
+
+def kappa_layer(seed, l, L, temps, M, wn, press_bar_l):
+    """Seeded synthetic opacity slab [Nt][M][W] for layer l, cm2/g: log-normal
+    line forest per molecule, smooth (exponential) in T, weak pressure trend.
+    Median ~1 cm2/g puts the photosphere near 0.01-1 bar for 1e-4 abundances."""
+    W = len(wn)
+    out = np.empty((len(temps), M, W))
+    for m in range(M):
+        rng = np.random.default_rng([seed, m])      # same per-wn pattern in every layer
+        g = rng.normal(0.0, 2.5, W) + np.log(2.0) - 0.6 * m
+        a = rng.normal(0.0, 0.6, W)
+        b = 0.15 * rng.random(W)
+        tt = (np.asarray(temps)[:, None] - 1500.0) / 1000.0
+        out[:, m, :] = np.exp(g[None, :] + a[None, :] * tt
+                              + b[None, :] * np.log10(press_bar_l))
+    return out
+
+
+def hydrostatic_radius_km(press_bar, temp, mu, p0_bar, r0_km, g_cgs):
+    """Initial radii for the atm file (constant-g barometric estimate; the
+    engine recomputes radii from gsurf/refpress/refradius on every call)."""
+    from math import log
+    kb, amu = 1.380658e-16, 1.66053886e-24
+    n = len(press_bar)
+    r = np.zeros(n)
+    i0 = int(np.argmin(np.abs(np.asarray(press_bar) - p0_bar)))
+    r[i0] = r0_km * 1e5
+    for i in range(i0 - 1, -1, -1):
+        h = 0.5 * (temp[i] / mu[i] + temp[i + 1] / mu[i + 1]) * kb / amu / g_cgs
+        r[i] = r[i + 1] - h * log(press_bar[i] / press_bar[i + 1])
+    for i in range(i0 + 1, n):
+        h = 0.5 * (temp[i] / mu[i] + temp[i - 1] / mu[i - 1]) * kb / amu / g_cgs
+        r[i] = r[i - 1] + h * log(press_bar[i - 1] / press_bar[i])
+    return r / 1e5
+
+
+def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
+              opmol=("H2O", "CO", "CO2", "CH4"),
+              species=("He", "H2", "CO", "CO2", "CH4", "H2O"),
+              abund=(0.15, 0.85, 1e-4, 1e-4, 1e-4, 1e-4),
+              tlow=400.0, thigh=3000.0, tempdelt=100.0, seed=20260101,
+              cia=True, raygrid=(0, 20, 40, 60, 80), toomuch=10.0,
+              refpress=0.1, tep_rp_rjup=1.35, tep_mp_mjup=0.66,
+              ptop=1e-5, pbottom=100.0, extra_keys=None) -> Case:
+    """Write a full seeded input set: SURVEY.md section 8(d) headline shape by
+    default (L=100, W=1e4, M=4, Nt=27, H2-H2 CIA, 5 angles)."""
+    os.makedirs(outdir, exist_ok=True)
+    species = list(species)
+    opmol = list(opmol)
+    L, W = nlayers, nwave
+    # bottom->top pressures; written with 5 significant digits like makeatm
+    press = np.array([float("%.4e" % p) for p in np.logspace(np.log10(pbottom), np.log10(ptop), L)])
+    temp0 = np.array([float("%.2f" % t) for t in
+                      1100.0 + 500.0 * (np.log10(press) + 5.0) / 7.0])
+    ab = np.tile(np.asarray(abund, float), (L, 1))
+    mass = np.array([MOLECULES[s][1] for s in species])
+    mu = ab @ mass
+    # planet constants as makecfg.makeTransit derives them (makecfg.py:76-85)
+    rjup, mjup, G = 7.1492e7, 1.8983e27, 6.67430e-11
+    rp = tep_rp_rjup * rjup
+    gsurf = float("%.1f" % (100.0 * G * tep_mp_mjup * mjup / rp ** 2))
+    refradius = float("%.2f" % (rp * 1e-3))
+    rad = hydrostatic_radius_km(press, temp0, mu, refpress, refradius, gsurf)
+    wn = wnlow + wndelt * np.arange(W)
+    tgrid = np.arange(tlow, thigh + 0.5 * tempdelt, tempdelt)
+
+    p = lambda n: os.path.join(outdir, n)
+    write_molfile(p("molecules.dat"))
+    write_atm(p("synth.atm"), species, press, temp0, ab, rad)
+    ids = [MOLECULES[m][0] for m in opmol]
+    if len(opmol):
+        write_opacity(p("opacity.dat"), ids, tgrid, press * 1e6, wn,
+                      plane_fn=lambda l: kappa_layer(seed, l, L, tgrid, len(opmol), wn, press[l]))
+    cia_files = []
+    if cia:
+        rng = np.random.default_rng(seed + 1)
+        ct = np.arange(400.0, 3000.1, 200.0)
+        cw = np.arange(wn[0] - 20.0, wn[-1] + 20.1, 10.0)
+        base = 1e-7 * np.exp(-((cw - 0.4 * (wn[0] + wn[-1])) / (0.6 * (wn[-1] - wn[0]))) ** 2)
+        al = base[None, :] * (1.0 + 0.3 * (ct[:, None] - 400.0) / 2600.0) \
+            * np.exp(0.2 * rng.normal(size=(1, len(cw))))
+        write_cia(p("CIA_H2H2.dat"), "H2", "H2", ct, cw, al)
+        cia_files.append(p("CIA_H2H2.dat"))
+    keys = {
+        "atm": p("synth.atm"),
+        "molfile": p("molecules.dat"),
+        "csfile": ",".join(cia_files) if cia_files else None,
+        "opacityfile": p("opacity.dat") if len(opmol) else None,
+        "wnlow": repr(float(wn[0])), "wnhigh": repr(float(wn[-1])),
+        "wndelt": repr(float(wndelt)), "wnfct": "1.0", "wnosamp": 2160,
+        "solution": "eclipse",
+        "raygrid": list(raygrid),
+        "toomuch": toomuch,
+        "tlow": tlow, "thigh": thigh, "tempdelt": tempdelt,
+        "gsurf": gsurf, "refpress": refpress, "refradius": refradius,
+        "nwidth": 20, "verb": 0,
+    }
+    if extra_keys:
+        keys.update(extra_keys)
+    write_tcfg(p("transit.cfg"), keys)
+    return Case(dir=outdir, tcfg=p("transit.cfg"), atm=p("synth.atm"),
+                molfile=p("molecules.dat"), opacity=p("opacity.dat"), cia=cia_files,
+                species=species, opmol=opmol, press_bar=press, temp0=temp0,
+                abund0=np.array([[float("%1.4e" % a) for a in row] for row in ab]),
+                radius_km=rad, wn=wn, tgrid=tgrid, keys=keys)

@@ -1,0 +1,118 @@
+"""Drop-in replacement of BART's SWIG module ``transit_module``.
+
+Same eight names and call shapes as the module the reference worker imports
+(reference code/BARTfunc.py:28-30; call sites :230-234, :351-363, :406), backed
+by ``libbartrt.so`` (HIP kernels, ``include/bartrt.h``) through ctypes:
+
+    import transit_module as trm
+    trm.transit_init(3, ["transit", "-c", cfg])
+    nwave  = trm.get_no_samples()
+    specwn = trm.get_waveno_arr(nwave)
+    spectrum = trm.run_transit(profiles.flatten(), nwave)
+    trm.free_memory()
+
+There is no CPU path: without the built library or without a GPU every compute
+call raises.  Batched and device-resident variants live in ``bart_amd.engine``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libbartrt.so")
+_lib = None
+
+
+class TransitError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libbartrt.so (never builds it: ``__graft_entry__.build()`` or
+    ``python -m bart_amd.build`` does)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise TransitError(
+                "libbartrt.so is missing: build it with `python -m bart_amd.build` "
+                "(the engine has no CPU fallback)")
+        L = C.CDLL(_LIBPATH)
+        d, i, p = C.c_double, C.c_int, C.c_void_p
+        L.bartrt_last_error.restype = C.c_char_p
+        L.bartrt_init.argtypes = [i, C.POINTER(C.c_char_p)]
+        L.bartrt_get_waveno_arr.argtypes = [p, i]
+        L.bartrt_set_radius.argtypes = [d]
+        L.bartrt_set_cloudtop.argtypes = [d]
+        L.bartrt_set_scattering.argtypes = [i, d]
+        L.bartrt_run_transit.argtypes = [p, i, p, i]
+        L.bartrt_run_transit_batch.argtypes = [p, i, i, p, i, p]
+        L.bartrt_run_transit_batch_dev.argtypes = [p, i, p, p, p]
+        L.bartrt_step_setup.argtypes = [p, i, i, d, d, p, i, p, i, p, p, p, p, d, i]
+        L.bartrt_step_set_ebalance.argtypes = [i, d, d]
+        L.bartrt_step_batch.argtypes = [p, i, i, p, p]
+        L.bartrt_step_batch_dev.argtypes = [p, i, i, p, p, p, p]
+        L.bartrt_step_profiles_dev.argtypes = [p, i, i, p, p, p]
+        L.bartrt_step_bandflux_dev.argtypes = [p, i, p, p, p]
+        L.bartrt_get_local_range.argtypes = [C.POINTER(i), C.POINTER(i)]
+        L.bartrt_get_species.argtypes = [C.c_char_p, i]
+        L.bartrt_get_pressure.argtypes = [p, i]
+        L.bartrt_get_tau.argtypes = [p, p, i, i]
+        L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
+        L.bartrt_algorithmic_bytes.argtypes = [i]
+        L.bartrt_algorithmic_bytes.restype = d
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise TransitError(lib().bartrt_last_error().decode() or f"bartrt error {rc}")
+    return rc
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- the eight reference entry points ----------------------------------
+def transit_init(argc, argv):
+    args = [str(a).encode() for a in argv][:argc]
+    arr = (C.c_char_p * len(args))(*args)
+    check(lib().bartrt_init(len(args), arr))
+
+
+def get_no_samples():
+    return check(lib().bartrt_get_no_samples())
+
+
+def get_waveno_arr(n):
+    out = np.zeros(int(n), np.double)
+    check(lib().bartrt_get_waveno_arr(_ptr(out), int(n)))
+    return out
+
+
+def set_radius(refradius):
+    check(lib().bartrt_set_radius(float(refradius)))
+
+
+def set_cloudtop(cloudtop):
+    check(lib().bartrt_set_cloudtop(float(cloudtop)))
+
+
+def set_scattering(flag, value):
+    check(lib().bartrt_set_scattering(int(flag), float(value)))
+
+
+def run_transit(profiles, nwave):
+    """profiles: flat (nspecies+1)*nlayers doubles -> new ndarray[nwave]."""
+    prof = np.ascontiguousarray(profiles, np.double).ravel()
+    spec = np.zeros(int(nwave), np.double)
+    check(lib().bartrt_run_transit(_ptr(prof), prof.size, _ptr(spec), int(nwave)))
+    return spec
+
+
+def free_memory():
+    check(lib().bartrt_free_memory())

@@ -1,0 +1,143 @@
+/*
+ * bartrt.h -- C ABI of libbartrt.so, the MI355X-native forward
+ * radiative-transfer engine that replaces BART's `transit_module`.
+ *
+ * Every entry point below stands in for one call BART's per-step callable
+ * makes on the SWIG module (reference code/BARTfunc.py, line cited per
+ * function).  Plain pointers and sizes only; host pointers unless the name
+ * ends in `_dev`.  All functions return 0 on success and a negative code on
+ * error (message via bartrt_last_error()) unless documented otherwise.  The
+ * library computes ONLY on the GPU: with no HIP device every compute entry
+ * point fails with BARTRT_ENODEV -- there is no CPU fallback.
+ *
+ * Engine state is a process-global singleton, like the reference module's
+ * (created by transit_init, destroyed by free_memory; BARTfunc.py:230,406).
+ */
+#ifndef BARTRT_H
+#define BARTRT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BARTRT_OK        0
+#define BARTRT_EINVAL   -1   /* bad argument / not initialised */
+#define BARTRT_EIO      -2   /* input file missing or malformed */
+#define BARTRT_ENODEV   -3   /* no HIP device / HIP runtime error */
+#define BARTRT_ENOTSUP  -4   /* configuration not supported by this build */
+
+/* ---- the eight reference entry points -------------------------------- */
+
+/* trm.transit_init(argc, argv)  [BARTfunc.py:229-230]
+ * argv = {"transit", "-c", <transit cfg>}.  Extra flags accepted after the
+ * cfg: "--shard <rank> <nranks>" keeps only that contiguous block of the
+ * wavenumber grid on this process's GPU; "--device <n>". */
+int bartrt_init(int argc, const char **argv);
+
+/* trm.get_no_samples()  [BARTfunc.py:233].  Full-grid sample count (>=0),
+ * or a negative error code. */
+int bartrt_get_no_samples(void);
+
+/* trm.get_waveno_arr(n)  [BARTfunc.py:234].  out[n] = wavenumbers, cm-1. */
+int bartrt_get_waveno_arr(double *out, int n);
+
+/* trm.set_radius(r)  [BARTfunc.py:351].  Reference radius in km. */
+int bartrt_set_radius(double refradius_km);
+
+/* trm.set_cloudtop(p)  [BARTfunc.py:354].  log10(cloud-top pressure / bar). */
+int bartrt_set_cloudtop(double log10_pbar);
+
+/* trm.set_scattering(flag, value)  [BARTfunc.py:358,360]. */
+int bartrt_set_scattering(int flag, double value);
+
+/* trm.run_transit(profiles.flatten(), nwave)  [BARTfunc.py:363].
+ * prof[nprof] with nprof = (nspecies+1)*nlayers: row 0 temperature (K), rows
+ * 1..S mole mixing ratios in atm-file species order, layers in atm-file order
+ * (BARTfunc.py:213-222).  spec[nwave] = emergent flux, erg s-1 cm-2 cm.
+ * On a sharded engine nwave may be the full count (only the shard's block is
+ * written) or the shard's count. */
+int bartrt_run_transit(const double *prof, int nprof, double *spec, int nwave);
+
+/* trm.free_memory()  [BARTfunc.py:406]. */
+int bartrt_free_memory(void);
+
+/* ---- batched / device-resident variants (same arithmetic) ------------- */
+
+/* nwalkers profiles -> nwalkers spectra; ok[w] = 0 marks a profile the
+ * engine cannot evaluate (non-finite or non-positive temperature).  ok may
+ * be NULL.  spec is [nwalkers][nwave_local]. */
+int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
+                             double *spec, int nwave, unsigned char *ok);
+
+/* Same with HBM-resident buffers, asynchronous on `stream` (a hipStream_t;
+ * NULL = the engine's own stream).  d_spec is [nwalkers][local samples]. */
+int bartrt_run_transit_batch_dev(const double *d_prof, int nwalkers,
+                                 double *d_spec, unsigned char *d_ok,
+                                 void *stream);
+
+/* ---- per-step callable on the device (BARTfunc.py:309-399) ------------- */
+
+/* One-time setup of the input/output converters around the engine:
+ * PT model "line" (code/PT.py:589-701) with PTargs = {R_star[m], T_star[K],
+ * T_int[K], sma[m], g[cm s-2]} (BARTfunc.py:204-208), the base abundances
+ * abund[L][S] (atm order), indices of the fitted molecules, and the
+ * per-filter windows/weights produced by wine.resample
+ * (code/wine.py:127-174): for filter f, idx0[f] = first spectrum index,
+ * npts[f] = number of samples, weights/starflux concatenated in that order.
+ * pttype: 0 "line", 1 "iso".  tint_thorngren: T_int from Thorngren et al.
+ * 2019 (PT.py:680-685) instead of ptargs5[2].
+ * rprs = Rp/Rs.  solution: 0 eclipse (divide by stellar flux, times rprs^2),
+ * 1 transit / 2 direct (no star division) (BARTfunc.py:386-396). */
+int bartrt_step_setup(const double *ptargs5, int tint_thorngren, int pttype,
+                      double tmin, double tmax,
+                      const double *abund, int nmolfit, const int *imol,
+                      int nfilters, const int *idx0, const int *npts,
+                      const double *nifilter, const double *istarfl,
+                      double rprs, int solution);
+
+/* Energy-balance rejection (BARTfunc.py:366-383): reject a walker when
+ * trapz(spectrum, wn) * e_fac > e_in  (e_fac = 4 (Rp*100)^2). */
+int bartrt_step_set_ebalance(int on, double e_in, double e_fac);
+
+/* params[nwalkers][npars] (npars = nPT + nmolfit; nPT = 5 for "line", 1 for
+ * "iso") -> bandflux[nwalkers][nfilters]; rejected walkers get -1 in every
+ * band (BARTfunc.py:327-330,339-344,378-383).  status[w]: 0 ok, 1 bad
+ * temperature, 2 bad abundance, 3 energy balance.  status may be NULL. */
+int bartrt_step_batch(const double *params, int nwalkers, int npars,
+                      double *bandflux, int *status);
+/* Device-resident form; d_status and d_spec ([nwalkers][nwave]) may be NULL. */
+int bartrt_step_batch_dev(const double *d_params, int nwalkers, int npars,
+                          double *d_bandflux, int *d_status, double *d_spec,
+                          void *stream);
+/* The two converters on their own, for engines sharded by wavenumber block:
+ * profiles -> bartrt_run_transit_batch_dev on each shard -> all-gather of the
+ * spectra (caller, RCCL) -> bandflux on the reassembled [nwalkers][nwave]. */
+int bartrt_step_profiles_dev(const double *d_params, int nwalkers, int npars,
+                             double *d_prof, int *d_status, void *stream);
+int bartrt_step_bandflux_dev(const double *d_spec_full, int nwalkers,
+                             int *d_status, double *d_bandflux, void *stream);
+
+/* ---- introspection ----------------------------------------------------- */
+const char *bartrt_last_error(void);
+int bartrt_get_nlayers(void);
+int bartrt_get_nspecies(void);
+int bartrt_get_nprof(void);                 /* (S+1)*L */
+int bartrt_get_local_range(int *lo, int *hi); /* shard's [lo,hi) of the grid */
+int bartrt_get_species(char *buf, int buflen); /* space-separated names */
+int bartrt_get_pressure(double *out, int n);   /* barye, atm order */
+/* optical depth of the last single-walker run: tau[nwave_local][L], layer
+ * index 0 = top (the tau.dat convention read by code/cf.py:68-94). */
+int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers);
+
+/* HIP-event timing of the RT kernel launches (bench.py's roofline leg).
+ * begin resets; end returns accumulated device ms and launch count. */
+int bartrt_timing_begin(void);
+int bartrt_timing_end(double *kernel_ms, int *nlaunch);
+/* algorithmic bytes one launch of the RT kernel moves for `nwalkers`
+ * (2*L*W*M*8 + 2*L*W*8*ncia + (S+1)*L*8 + W*8 per spectrum) */
+double bartrt_algorithmic_bytes(int nwalkers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,308 @@
+/*
+ * rt_oracle.c -- scalar fp64 CPU restatement of the forward RT path.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see rt_oracle.h).
+ *
+ * Reference evidence followed, function by function:
+ *   - profile array layout ............ code/BARTfunc.py:213-222,363
+ *   - hydrostatic radii ............... code/makeatm.py:183-263
+ *   - mean molecular mass ............. code/makeatm.py:503-506
+ *   - Planck function & constants ..... code/cf.py:108-109, code/constants.py:13-16
+ *   - tau indexing (0 = top) .......... code/cf.py:68-94,123-131
+ *   - opacity grid (tlow/thigh/tempdelt, same layers and wn as the run)
+ *                                       examples/demo/BART_eclipse.cfg:142-145,
+ *                                       doc/BART_user_manual/BART_user_manual.tex:771-775
+ *   - raygrid / toomuch ............... examples/demo/BART_eclipse.cfg:135-136
+ *   - output units (erg s-1 cm-2 cm) .. code/BARTfunc.py:375-377, code/wine.py:121-122
+ * Everything else (table interpolation rule, CIA scaling, integration rule,
+ * angle quadrature, bottom boundary) restates the published Transit
+ * algorithm (Cubillos et al. 2022, PSJ 3, 81; Blecic et al. 2022, PSJ 3, 82)
+ * and is unverified against source.
+ */
+#include "rt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+double orc_planck(double wn, double temp) {
+  /* cf.py:108-109:  2 h wn^3 c^2 / (exp(h wn c / (k T)) - 1) */
+  return (2.0 * ORC_H * wn * wn * wn * ORC_LS * ORC_LS) /
+         (exp((ORC_H * wn * ORC_LS) / (ORC_KB * temp)) - 1.0);
+}
+
+void orc_meanmass(int L, int S, const double *q, const double *mass, double *mu) {
+  for (int l = 0; l < L; l++) {
+    double m = 0.0;
+    for (int s = 0; s < S; s++) m += q[(size_t)s * L + l] * mass[s];
+    mu[l] = m;
+  }
+}
+
+/* makeatm.py:183-263, restated for layers ordered bottom->top (index 0 has
+ * the highest pressure; this is the orientation the reference flips to at
+ * makeatm.py:225-227) and cgs units: KB/AMU replaces Avogadro*k because mu
+ * is in amu here. */
+void orc_radpress(int n, const double *press, const double *temp,
+                  const double *mu, double p0, double r0, double g0,
+                  double *rad) {
+  double *g = (double *)malloc(sizeof(double) * n);
+  const double rgas = ORC_KB / ORC_AMU;
+  /* closest layer to p0 (np.argmin(|press - p0|), first minimum) */
+  int idx = 0;
+  double best = fabs(press[0] - p0);
+  for (int i = 1; i < n; i++) {
+    double d = fabs(press[i] - p0);
+    if (d < best) { best = d; idx = i; }
+  }
+  if (press[idx] != p0) {
+    /* temp and mu at p0 by linear interpolation in log10(p)
+     * (makeatm.py:214-220) */
+    double lp0 = log10(p0), t0 = temp[idx], m0 = mu[idx];
+    for (int i = 0; i + 1 < n; i++) {
+      double la = log10(press[i]), lb = log10(press[i + 1]);
+      if ((lp0 <= la && lp0 >= lb) || (lp0 >= la && lp0 <= lb)) {
+        double f = (lp0 - la) / (lb - la);
+        t0 = temp[i] + f * (temp[i + 1] - temp[i]);
+        m0 = mu[i] + f * (mu[i + 1] - mu[i]);
+        break;
+      }
+    }
+    /* makeatm.py:236-243; both branches are the same expression */
+    rad[idx] = r0 + 0.5 * (temp[idx] / mu[idx] + t0 / m0) *
+                        (rgas * log(p0 / press[idx]) / g0);
+    g[idx] = g0 * r0 * r0 / (rad[idx] * rad[idx]);
+  } else {
+    rad[idx] = r0;
+    g[idx] = g0;
+  }
+  /* below p0 (higher pressure): makeatm.py:250-253 */
+  for (int i = idx - 1; i >= 0; i--) {
+    rad[i] = rad[i + 1] - 0.5 * (temp[i] / mu[i] + temp[i + 1] / mu[i + 1]) *
+                              (rgas * log(press[i] / press[i + 1]) / g[i + 1]);
+    g[i] = g[i + 1] * rad[i + 1] * rad[i + 1] / (rad[i] * rad[i]);
+  }
+  /* above p0: makeatm.py:254-258 */
+  for (int i = idx + 1; i < n; i++) {
+    rad[i] = rad[i - 1] + 0.5 * (temp[i] / mu[i] + temp[i - 1] / mu[i - 1]) *
+                              (rgas * log(press[i - 1] / press[i]) / g[i - 1]);
+    g[i] = g[i - 1] * rad[i - 1] * rad[i - 1] / (rad[i] * rad[i]);
+  }
+  free(g);
+}
+
+/* bracket T in grid: largest j with grid[j] <= T, clamped to [0, n-2] */
+static int bracket(const double *grid, int n, double t) {
+  int j = 0;
+  while (j < n - 2 && grid[j + 1] <= t) j++;
+  return j;
+}
+
+/* Rayleigh cross sections (cm2 per molecule).  Unverified conventions:
+ *  flag 1: 10^value * sigma0 * (wn*lambda0)^4 per H2 molecule with
+ *          sigma0 = 2.52e-28 cm2 at lambda0 = 750 nm (Lecavelier des Etangs
+ *          et al. 2008);
+ *  flag 2: (128 pi^5/3) alpha^2 wn^4 for H2 and He polarisabilities. */
+static const double RAY_SIGMA0 = 2.52e-28, RAY_LAMBDA0 = 7.5e-5;
+static const double POL_H2 = 0.8059e-24, POL_HE = 0.2051e-24;
+
+int orc_extinction(const rt_oracle_cfg *c, const double *prof, double *ext,
+                   double *rad_out) {
+  const int L = c->nlayers, S = c->nspecies, M = c->nmol, W = c->nwave,
+            Nt = c->ntemp;
+  const double *temp = prof;
+  const double *q = prof + L;
+  double *mu = (double *)malloc(sizeof(double) * L);
+  double *rad = (double *)malloc(sizeof(double) * L);
+  orc_meanmass(L, S, q, c->mass, mu);
+  orc_radpress(L, c->press, temp, mu, c->refpress, c->refradius, c->gsurf, rad);
+  if (rad_out) memcpy(rad_out, rad, sizeof(double) * L);
+
+  for (int l = 0; l < L; l++) {
+    const double T = temp[l];
+    const double nd = c->press[l] / (ORC_KB * T); /* molecules cm-3 */
+    double *e = ext + (size_t)l * W;
+    for (int i = 0; i < W; i++) e[i] = 0.0;
+    /* molecular extinction: linear-in-T between the two bracketing planes
+     * of the layer's own slab of the grid, times the molecule's mass density */
+    if (M > 0) {
+      int j = bracket(c->tgrid, Nt, T);
+      double f = (T - c->tgrid[j]) / (c->tgrid[j + 1] - c->tgrid[j]);
+      for (int m = 0; m < M; m++) {
+        int s = c->opmol[m];
+        double rho = q[(size_t)s * L + l] * c->mass[s] * ORC_AMU * nd;
+        const double *klo = c->kappa + (((size_t)l * Nt + j) * M + m) * W;
+        const double *khi = c->kappa + (((size_t)l * Nt + j + 1) * M + m) * W;
+        double wlo = rho * (1.0 - f), whi = rho * f;
+        for (int i = 0; i < W; i++) e[i] += wlo * klo[i] + whi * khi[i];
+      }
+    }
+    /* CIA: alpha(T, wn) * n1/amagat * n2/amagat; T clamped to the file range */
+    size_t toff = 0, aoff = 0;
+    for (int k = 0; k < c->ncia; k++) {
+      int nt = c->cia_nt[k];
+      const double *tg = c->cia_temp + toff;
+      const double *al = c->cia_alpha + aoff;
+      double Tc = T < tg[0] ? tg[0] : (T > tg[nt - 1] ? tg[nt - 1] : T);
+      double n1 = q[(size_t)c->cia_s1[k] * L + l] * nd / ORC_AMAGAT;
+      double n2 = q[(size_t)c->cia_s2[k] * L + l] * nd / ORC_AMAGAT;
+      if (nt == 1) {
+        double w = n1 * n2;
+        for (int i = 0; i < W; i++) e[i] += w * al[i];
+      } else {
+        int j = bracket(tg, nt, Tc);
+        double f = (Tc - tg[j]) / (tg[j + 1] - tg[j]);
+        double wlo = n1 * n2 * (1.0 - f), whi = n1 * n2 * f;
+        const double *alo = al + (size_t)j * W, *ahi = al + (size_t)(j + 1) * W;
+        for (int i = 0; i < W; i++) e[i] += wlo * alo[i] + whi * ahi[i];
+      }
+      toff += nt;
+      aoff += (size_t)nt * W;
+    }
+    /* Rayleigh */
+    if (c->scat_flag == 1 && c->scat_iH2 >= 0) {
+      double nh2 = q[(size_t)c->scat_iH2 * L + l] * nd;
+      double a = pow(10.0, c->scat_value) * RAY_SIGMA0 * nh2;
+      for (int i = 0; i < W; i++) {
+        double x = c->wn[i] * RAY_LAMBDA0;
+        e[i] += a * (x * x) * (x * x);
+      }
+    } else if (c->scat_flag == 2) {
+      double k0 = 128.0 * pow(ORC_PI, 5) / 3.0, a = 0.0;
+      if (c->scat_iH2 >= 0) a += POL_H2 * POL_H2 * q[(size_t)c->scat_iH2 * L + l] * nd;
+      if (c->scat_iHe >= 0) a += POL_HE * POL_HE * q[(size_t)c->scat_iHe * L + l] * nd;
+      a *= k0;
+      for (int i = 0; i < W; i++) {
+        double x = c->wn[i];
+        e[i] += a * (x * x) * (x * x);
+      }
+    }
+  }
+  free(mu);
+  free(rad);
+  return 0;
+}
+
+/* Simpson's rule on a non-uniform grid x[0..n-1] (n points).  With an odd
+ * number of intervals the first interval is taken by trapezoid and Simpson
+ * panels cover the rest. */
+static double simpson_nu(const double *x, const double *y, int n) {
+  if (n < 2) return 0.0;
+  double res = 0.0;
+  int start = 0;
+  if (((n - 1) & 1) == 1) {
+    res += 0.5 * (x[1] - x[0]) * (y[0] + y[1]);
+    start = 1;
+  }
+  for (int j = start; j + 2 <= n - 1; j += 2) {
+    double h0 = x[j + 1] - x[j], h1 = x[j + 2] - x[j + 1];
+    if (h0 == 0.0 || h1 == 0.0) { /* degenerate panel: fall back to trapezoid */
+      res += 0.5 * h0 * (y[j] + y[j + 1]) + 0.5 * h1 * (y[j + 1] + y[j + 2]);
+      continue;
+    }
+    double hs = h0 + h1;
+    res += hs / 6.0 * (y[j] * (2.0 - h1 / h0) + y[j + 1] * hs * hs / (h0 * h1) +
+                       y[j + 2] * (2.0 - h0 / h1));
+  }
+  return res;
+}
+
+/* Per-wavenumber column solve.  e_col[k], r_col[k], t_col[k] are indexed
+ * from the TOP layer (k = 0) downwards.  Returns intensities per angle and
+ * tau[k]; *last_out = index of the deepest layer included. */
+static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
+                           const double *e_col, const double *r_col,
+                           const double *t_col, int kcloud, double *tau,
+                           double *intens, int *last_out) {
+  const int A = c->nangles;
+  int last = L - 1;
+  double *path = (double *)malloc(sizeof(double) * L);
+  for (int k = 0; k < L; k++) path[k] = r_col[0] - r_col[k]; /* depth from top */
+  tau[0] = 0.0;
+  int kend = (kcloud >= 0) ? kcloud : L - 1;
+  for (int k = 1; k <= kend; k++) {
+    if (c->integ == ORC_INTEG_SIMPSON)
+      tau[k] = simpson_nu(path, e_col, k + 1);
+    else
+      tau[k] = tau[k - 1] + 0.5 * (e_col[k - 1] + e_col[k]) * (path[k] - path[k - 1]);
+    if (tau[k] > c->toomuch) { last = k; break; }
+    last = k;
+  }
+  if (kend == 0) last = 0;
+  for (int k = last + 1; k < L; k++) tau[k] = tau[last]; /* not computed deeper */
+  double *f = (double *)malloc(sizeof(double) * L);
+  for (int a = 0; a < A; a++) {
+    double mu = cos(c->angles_deg[a] * ORC_PI / 180.0);
+    for (int k = 0; k <= last; k++)
+      f[k] = orc_planck(wn, t_col[k]) * exp(-tau[k] / mu);
+    double I;
+    if (c->integ == ORC_INTEG_SIMPSON) {
+      I = simpson_nu(tau, f, last + 1);
+    } else {
+      I = 0.0;
+      for (int k = 1; k <= last; k++) I += 0.5 * (f[k - 1] + f[k]) * (tau[k] - tau[k - 1]);
+    }
+    I /= mu;
+    /* opaque cloud deck reached before toomuch: it emits as a surface */
+    if (kcloud >= 0 && last == kcloud && !(tau[last] > c->toomuch)) I += f[last];
+    intens[a] = I;
+  }
+  free(f);
+  free(path);
+  *last_out = last;
+}
+
+static int solve(const rt_oracle_cfg *c, const double *prof, double *spec,
+                 double *tau_out, int *last_out, double *intens_out) {
+  const int L = c->nlayers, W = c->nwave, A = c->nangles;
+  double *ext = (double *)malloc(sizeof(double) * (size_t)L * W);
+  double *rad = (double *)malloc(sizeof(double) * L);
+  orc_extinction(c, prof, ext, rad);
+  double *e_col = (double *)malloc(sizeof(double) * L);
+  double *r_col = (double *)malloc(sizeof(double) * L);
+  double *t_col = (double *)malloc(sizeof(double) * L);
+  double *tau = (double *)malloc(sizeof(double) * L);
+  double *intens = (double *)malloc(sizeof(double) * A);
+  double *wgt = (double *)malloc(sizeof(double) * A);
+  /* angle quadrature: pi * sum_a I_a (sin^2 hi - sin^2 lo), bin edges midway
+   * between raygrid angles, 0 and 90 deg at the ends */
+  for (int a = 0; a < A; a++) {
+    double lo = (a == 0) ? 0.0 : 0.5 * (c->angles_deg[a - 1] + c->angles_deg[a]);
+    double hi = (a == A - 1) ? 90.0 : 0.5 * (c->angles_deg[a] + c->angles_deg[a + 1]);
+    double sl = sin(lo * ORC_PI / 180.0), sh = sin(hi * ORC_PI / 180.0);
+    wgt[a] = ORC_PI * (sh * sh - sl * sl);
+  }
+  int kcloud = -1;
+  for (int k = 0; k < L; k++) {
+    r_col[k] = rad[L - 1 - k];
+    t_col[k] = prof[L - 1 - k];
+    if (c->has_cloud && kcloud < 0 && c->press[L - 1 - k] >= c->cloudtop) kcloud = k;
+  }
+  for (int i = 0; i < W; i++) {
+    for (int k = 0; k < L; k++) e_col[k] = ext[(size_t)(L - 1 - k) * W + i];
+    int last;
+    column_eclipse(c, c->wn[i], L, e_col, r_col, t_col, kcloud, tau, intens, &last);
+    if (spec) {
+      double F = 0.0;
+      for (int a = 0; a < A; a++) F += wgt[a] * intens[a];
+      spec[i] = F;
+    }
+    if (intens_out)
+      for (int a = 0; a < A; a++) intens_out[(size_t)a * W + i] = intens[a];
+    if (tau_out) memcpy(tau_out + (size_t)i * L, tau, sizeof(double) * L);
+    if (last_out) last_out[i] = last;
+  }
+  free(ext); free(rad); free(e_col); free(r_col); free(t_col);
+  free(tau); free(intens); free(wgt);
+  return 0;
+}
+
+int orc_run_transit(const rt_oracle_cfg *c, const double *prof, double *spec,
+                    double *tau_out, int *last_out) {
+  if (c->solution != ORC_SOL_ECLIPSE) return -1;
+  return solve(c, prof, spec, tau_out, last_out, NULL);
+}
+
+int orc_intensity(const rt_oracle_cfg *c, const double *prof, double *intens) {
+  if (c->solution != ORC_SOL_ECLIPSE) return -1;
+  return solve(c, prof, NULL, NULL, NULL, intens);
+}

@@ -1,0 +1,268 @@
+"""ctypes front end of the CPU oracle + independent (numpy) input readers.
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see rt_oracle.h).  Only tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this.
+The readers here are deliberately separate from the product's C++ readers in
+``bart_amd/csrc`` so that a parsing bug on either side shows up as a parity
+failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+H, LS, KB = 6.6260755e-27, 2.99792458e10, 1.380658e-16   # code/constants.py:14-16
+AMU, AMAGAT = 1.66053886e-24, 2.68679e19
+
+
+class _Cfg(C.Structure):
+    _fields_ = [
+        ("nlayers", C.c_int), ("nspecies", C.c_int), ("nmol", C.c_int),
+        ("ntemp", C.c_int), ("nwave", C.c_int), ("nangles", C.c_int),
+        ("ncia", C.c_int), ("integ", C.c_int), ("solution", C.c_int),
+        ("scat_flag", C.c_int), ("has_cloud", C.c_int), ("reserved", C.c_int),
+        ("press", C.c_void_p), ("mass", C.c_void_p), ("opmol", C.c_void_p),
+        ("tgrid", C.c_void_p), ("kappa", C.c_void_p), ("wn", C.c_void_p),
+        ("cia_s1", C.c_void_p), ("cia_s2", C.c_void_p), ("cia_nt", C.c_void_p),
+        ("cia_temp", C.c_void_p), ("cia_alpha", C.c_void_p),
+        ("angles_deg", C.c_void_p),
+        ("toomuch", C.c_double), ("gsurf", C.c_double), ("refpress", C.c_double),
+        ("refradius", C.c_double), ("cloudtop", C.c_double),
+        ("scat_value", C.c_double), ("scat_iH2", C.c_int), ("scat_iHe", C.c_int),
+        ("starrad", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "librt_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("rt_oracle.c", "rt_oracle.h")]
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "librt_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_planck.restype = C.c_double
+        _LIB.orc_planck.argtypes = [C.c_double, C.c_double]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- readers
+def read_tcfg(path: str) -> dict:
+    """transit ``key value`` file (examples/demo/transit_demo.cfg:1-66)."""
+    out = {}
+    for line in open(path):
+        line = line.strip()
+        if not line or line[0] in "#;":
+            continue
+        parts = line.split(None, 1)
+        out[parts[0]] = parts[1].strip() if len(parts) > 1 else ""
+    return out
+
+
+def read_atm(path: str):
+    """Atmosphere file (format written by code/makeatm.py:551-603,841-896)."""
+    lines = open(path).read().split("\n")
+    units = {"ur": 1e5, "up": 1e6, "ut": 1.0}
+    species, data, i = None, [], 0
+    while i < len(lines):
+        s = lines[i].strip()
+        tok = s.split()
+        if tok and tok[0] in units and len(tok) == 2:
+            units[tok[0]] = float(tok[1])
+        elif s == "#SPECIES":
+            species = lines[i + 1].split()
+            i += 1
+        elif s == "#TEADATA":
+            i += 2  # column header
+            while i < len(lines) and lines[i].strip():
+                data.append([float(x) for x in lines[i].split()])
+                i += 1
+            break
+        i += 1
+    d = np.array(data)
+    return dict(species=species, radius=d[:, 0] * units["ur"], press=d[:, 1] * units["up"],
+                temp=d[:, 2] * units["ut"], abund=d[:, 3:])
+
+
+def read_molfile(path: str):
+    ids, names, mass, diam = [], [], [], []
+    for line in open(path):
+        t = line.split("#")[0].split()
+        if len(t) >= 4:
+            ids.append(int(t[0])); names.append(t[1]); mass.append(float(t[2])); diam.append(float(t[3]))
+    return dict(id=ids, name=names, mass=mass, diam=diam)
+
+
+def read_opacity(path: str):
+    hdr = np.fromfile(path, np.int64, 4)
+    nm, nt, nl, nw = (int(x) for x in hdr)
+    off = 32
+    ids = np.fromfile(path, np.int32, nm, offset=off); off += 4 * nm
+    temps = np.fromfile(path, np.float64, nt, offset=off); off += 8 * nt
+    press = np.fromfile(path, np.float64, nl, offset=off); off += 8 * nl
+    wn = np.fromfile(path, np.float64, nw, offset=off); off += 8 * nw
+    k = np.memmap(path, np.float64, "r", offset=off, shape=(nl, nt, nm, nw))
+    return dict(ids=ids, temps=temps, press=press, wn=wn, kappa=k)
+
+
+def read_cia(path: str):
+    mode, sp, temps, rows = None, None, None, []
+    for line in open(path):
+        s = line.strip()
+        if not s or s[0] == "#":
+            continue
+        if s[0] == "@":
+            mode = s
+            continue
+        if mode == "@SPECIES" and sp is None:
+            sp = s.split()
+        elif mode == "@TEMPERATURES" and temps is None:
+            temps = np.array([float(x) for x in s.split()])
+        elif mode == "@DATA":
+            rows.append([float(x) for x in s.split()])
+    d = np.array(rows)
+    return dict(species=sp, temps=temps, wn=d[:, 0], alpha=d[:, 1:].T.copy())
+
+
+# ---------------------------------------------------------------- engine
+class OracleEngine:
+    """Oracle counterpart of the product engine: built from a transit cfg."""
+
+    def __init__(self, tcfg: str, wn_lo: int | None = None, wn_hi: int | None = None,
+                 integ: int = 0):
+        k = read_tcfg(tcfg)
+        self.keys = k
+        atm = read_atm(k["atm"])
+        mol = read_molfile(k["molfile"])
+        self.species = atm["species"]
+        S = len(self.species)
+        self.L = len(atm["press"])
+        self.press = np.ascontiguousarray(atm["press"])
+        self.mass = np.array([mol["mass"][mol["name"].index(s)] for s in self.species])
+        if k.get("opacityfile"):
+            op = read_opacity(k["opacityfile"])
+            wn = np.array(op["wn"])
+            self.tgrid = np.array(op["temps"])
+            self.opmol = np.array([self.species.index(mol["name"][mol["id"].index(int(i))])
+                                   for i in op["ids"]], np.int32)
+            kap = op["kappa"]
+        else:
+            if "wnlow" in k:
+                lo, hi = float(k["wnlow"]), float(k["wnhigh"])
+            else:
+                f = float(k.get("wlfct", 1e-4))
+                lo, hi = 1.0 / (float(k["wlhigh"]) * f), 1.0 / (float(k["wllow"]) * f)
+            d = float(k.get("wndelt", 1.0))
+            wn = lo + d * np.arange(int(np.floor((hi - lo) / d + 1e-9)) + 1)
+            self.tgrid = np.array([0.0, 1.0])
+            self.opmol = np.zeros(0, np.int32)
+            kap = np.zeros((self.L, 2, 0, len(wn)))
+        sl = slice(wn_lo or 0, wn_hi if wn_hi is not None else len(wn))
+        self.wn = np.ascontiguousarray(wn[sl])
+        self.kappa = np.ascontiguousarray(kap[:, :, :, sl]) if kap.shape[2] else np.zeros(1)
+        W = len(self.wn)
+        s1, s2, cnt, ct, ca = [], [], [], [], []
+        for f in [x for x in k.get("csfile", "").split(",") if x]:
+            c = read_cia(f)
+            s1.append(self.species.index(c["species"][0]))
+            s2.append(self.species.index(c["species"][1]))
+            cnt.append(len(c["temps"]))
+            ct.append(c["temps"])
+            # resample on the spectrum grid: linear in wn, zero outside the file
+            ca.append(np.stack([np.interp(self.wn, c["wn"], a, left=0.0, right=0.0)
+                                for a in c["alpha"]]))
+        self.cia_s1 = np.array(s1, np.int32); self.cia_s2 = np.array(s2, np.int32)
+        self.cia_nt = np.array(cnt, np.int32)
+        self.cia_temp = np.concatenate(ct) if ct else np.zeros(1)
+        self.cia_alpha = np.ascontiguousarray(np.concatenate(ca)) if ca else np.zeros(1)
+        self.angles = np.array([float(x) for x in k.get("raygrid", "0 20 40 60 80").split()])
+        c = _Cfg()
+        c.nlayers, c.nspecies, c.nmol = self.L, S, len(self.opmol)
+        c.ntemp, c.nwave, c.nangles = len(self.tgrid), W, len(self.angles)
+        c.ncia, c.integ = len(s1), integ
+        c.solution = 0 if k.get("solution", "eclipse") == "eclipse" else 1
+        c.press, c.mass, c.opmol = _p(self.press), _p(self.mass), _p(self.opmol)
+        c.tgrid, c.kappa, c.wn = _p(self.tgrid), _p(self.kappa), _p(self.wn)
+        c.cia_s1, c.cia_s2, c.cia_nt = _p(self.cia_s1), _p(self.cia_s2), _p(self.cia_nt)
+        c.cia_temp, c.cia_alpha = _p(self.cia_temp), _p(self.cia_alpha)
+        c.angles_deg = _p(self.angles)
+        c.toomuch = float(k.get("toomuch", 20.0))
+        c.gsurf = float(k["gsurf"])
+        c.refpress = float(k["refpress"]) * 1e6
+        c.refradius = float(k["refradius"]) * 1e5
+        c.scat_iH2 = self.species.index("H2") if "H2" in self.species else -1
+        c.scat_iHe = self.species.index("He") if "He" in self.species else -1
+        if "cloudtop" in k:
+            c.has_cloud, c.cloudtop = 1, 10.0 ** float(k["cloudtop"]) * 1e6
+        self.c = c
+        self.nprof = (S + 1) * self.L
+
+    # setters mirror the reference module's (code/BARTfunc.py:350-360)
+    def set_radius(self, r_km):
+        self.c.refradius = float(r_km) * 1e5
+
+    def set_cloudtop(self, logp_bar):
+        self.c.has_cloud, self.c.cloudtop = 1, 10.0 ** float(logp_bar) * 1e6
+
+    def set_scattering(self, flag, value):
+        self.c.scat_flag, self.c.scat_value = int(flag), float(value)
+
+    def run(self, prof, want_tau=False):
+        prof = np.ascontiguousarray(prof, np.float64).ravel()
+        assert prof.size == self.nprof
+        W = self.c.nwave
+        spec = np.zeros(W)
+        tau = np.zeros((W, self.L)) if want_tau else None
+        last = np.zeros(W, np.int32) if want_tau else None
+        rc = lib().orc_run_transit(C.byref(self.c), _p(prof), _p(spec),
+                                   _p(tau) if want_tau else None,
+                                   _p(last) if want_tau else None)
+        assert rc == 0
+        return (spec, tau, last) if want_tau else spec
+
+    def intensity(self, prof):
+        prof = np.ascontiguousarray(prof, np.float64).ravel()
+        out = np.zeros((self.c.nangles, self.c.nwave))
+        assert lib().orc_intensity(C.byref(self.c), _p(prof), _p(out)) == 0
+        return out
+
+    def extinction(self, prof):
+        prof = np.ascontiguousarray(prof, np.float64).ravel()
+        ext = np.zeros((self.L, self.c.nwave)); rad = np.zeros(self.L)
+        lib().orc_extinction(C.byref(self.c), _p(prof), _p(ext), _p(rad))
+        return ext, rad
+
+    def run_batch(self, profs, threads=1):
+        profs = np.ascontiguousarray(profs, np.float64).reshape(-1, self.nprof)
+        if threads <= 1:
+            return np.stack([self.run(p) for p in profs])
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            return np.stack(list(ex.map(self.run, profs)))
+
+
+def planck(wn, temp):
+    return lib().orc_planck(float(wn), float(temp))
+
+
+def radpress(press, temp, mu, p0, r0, g0):
+    press, temp, mu = (np.ascontiguousarray(x, np.float64) for x in (press, temp, mu))
+    rad = np.zeros(len(press))
+    lib().orc_radpress(C.c_int(len(press)), _p(press), _p(temp), _p(mu),
+                       C.c_double(p0), C.c_double(r0), C.c_double(g0), _p(rad))
+    return rad

@@ -200,10 +200,20 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
               tlow=400.0, thigh=3000.0, tempdelt=100.0, seed=20260101,
               cia=True, raygrid=(0, 20, 40, 60, 80), toomuch=10.0,
               refpress=0.1, tep_rp_rjup=1.35, tep_mp_mjup=0.66,
-              ptop=1e-5, pbottom=100.0, extra_keys=None) -> Case:
+              ptop=1e-5, pbottom=100.0, extra_keys=None, write=True, reuse=False) -> Case:
     """Write a full seeded input set: SURVEY.md section 8(d) headline shape by
     default (L=100, W=1e4, M=4, Nt=27, H2-H2 CIA, 5 angles)."""
-    os.makedirs(outdir, exist_ok=True)
+    if write and reuse:
+        # a finished earlier write of the same shape (transit.cfg is written last)
+        want = 32 + 4 * len(opmol) + 8 * (int(round((thigh - tlow) / tempdelt)) + 1) \
+            + 8 * nlayers + 8 * nwave \
+            + 8 * nlayers * (int(round((thigh - tlow) / tempdelt)) + 1) * len(opmol) * nwave
+        op = os.path.join(outdir, "opacity.dat")
+        if os.path.exists(os.path.join(outdir, "transit.cfg")) and \
+                (not len(opmol) or (os.path.exists(op) and os.path.getsize(op) == want)):
+            write = False
+    if write:
+        os.makedirs(outdir, exist_ok=True)
     species = list(species)
     opmol = list(opmol)
     L, W = nlayers, nwave
@@ -224,10 +234,11 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
     tgrid = np.arange(tlow, thigh + 0.5 * tempdelt, tempdelt)
 
     p = lambda n: os.path.join(outdir, n)
-    write_molfile(p("molecules.dat"))
-    write_atm(p("synth.atm"), species, press, temp0, ab, rad)
+    if write:
+        write_molfile(p("molecules.dat"))
+        write_atm(p("synth.atm"), species, press, temp0, ab, rad)
     ids = [MOLECULES[m][0] for m in opmol]
-    if len(opmol):
+    if len(opmol) and write:
         write_opacity(p("opacity.dat"), ids, tgrid, press * 1e6, wn,
                       plane_fn=lambda l: kappa_layer(seed, l, L, tgrid, len(opmol), wn, press[l]))
     cia_files = []
@@ -238,7 +249,8 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
         base = 1e-7 * np.exp(-((cw - 0.4 * (wn[0] + wn[-1])) / (0.6 * (wn[-1] - wn[0]))) ** 2)
         al = base[None, :] * (1.0 + 0.3 * (ct[:, None] - 400.0) / 2600.0) \
             * np.exp(0.2 * rng.normal(size=(1, len(cw))))
-        write_cia(p("CIA_H2H2.dat"), "H2", "H2", ct, cw, al)
+        if write:
+            write_cia(p("CIA_H2H2.dat"), "H2", "H2", ct, cw, al)
         cia_files.append(p("CIA_H2H2.dat"))
     keys = {
         "atm": p("synth.atm"),
@@ -256,7 +268,8 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
     }
     if extra_keys:
         keys.update(extra_keys)
-    write_tcfg(p("transit.cfg"), keys)
+    if write:
+        write_tcfg(p("transit.cfg"), keys)
     return Case(dir=outdir, tcfg=p("transit.cfg"), atm=p("synth.atm"),
                 molfile=p("molecules.dat"), opacity=p("opacity.dat"), cia=cia_files,
                 species=species, opmol=opmol, press_bar=press, temp0=temp0,

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Forward spectra/sec of the MI355X radiative-transfer engine.
+
+    python bench.py --gpus N --steps K --warmup W [--walkers B]
+
+A "step" is one pass of the hot path (profile prep + RT kernel; for N > 1 also
+the RCCL all-gather that reassembles each spectrum) over one batch of B*N
+synthetic walkers on the headline grid: 100 layers x 1e4 wavenumbers, 4 opacity
+molecules (H2O, CO, CO2, CH4), 27 table temperatures, H2-H2 CIA, ray angles
+0/20/40/60/80 deg, toomuch = 10.  Profiles and spectra stay
+resident in HBM inside the timed region.  N > 1 shards the wavenumber axis by
+block across the ranks (one process per GPU, launched by torch.distributed.run).
+
+Prints ONE JSON line on rank 0 (contract: see the task statement; `roofline`
+and `cpu_baseline` objects included).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_profiles(case, n, seed):
+    """Walker profiles as the per-step callable builds them: PT_line-like T(p)
+    inside [Tmin, Tmax] and abundance log-factors U(-2, 1)."""
+    rng = np.random.default_rng(seed)
+    L = len(case.press_bar)
+    lp = np.log10(case.press_bar)
+    out = np.empty((n, (len(case.species) + 1) * L))
+    for w in range(n):
+        t_top = rng.uniform(700, 1500)
+        t_bot = rng.uniform(1500, 2600)
+        x = 1.0 / (1.0 + np.exp(-(lp - rng.uniform(-2.0, 0.5)) / rng.uniform(0.4, 1.0)))
+        t = np.clip(t_top + (t_bot - t_top) * x, 410.0, 2990.0)
+        ab = case.abund0.copy()
+        for s in range(2, ab.shape[1]):
+            ab[:, s] *= 10 ** rng.uniform(-2, 1)
+        q = 1 - ab[:, 2:].sum(1)
+        r = ab[:, 1] / ab[:, 0]
+        ab[:, 1] = r * q / (1 + r)
+        ab[:, 0] = q / (1 + r)
+        out[w] = case.profiles(t, ab).ravel()
+    return out
+
+
+def cpu_baseline(case, profs, seconds_target=12.0):
+    """The CPU oracle (a restatement, NOT reference transit: its source is an
+    empty submodule) timed on this host's cores, one walker per thread."""
+    from oracle import rt_oracle as orc
+    cores = os.cpu_count() or 1
+    eng = orc.OracleEngine(case.tcfg)
+    t0 = time.perf_counter()
+    eng.run(profs[0])
+    one = time.perf_counter() - t0
+    n = int(min(len(profs), max(cores, seconds_target / max(one, 1e-3))))
+    n = max(cores, (n // cores) * cores)
+    n = min(n, len(profs))
+    t0 = time.perf_counter()
+    eng.run_batch(profs[:n], threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
+            "sample": f"{n} spectra of the same workload (100x1e4, 4 molecules), "
+                      f"one walker per thread, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--walkers", type=int, default=256, help="walkers per GPU per step")
+    ap.add_argument("--nwave", type=int, default=10000)
+    ap.add_argument("--nlayers", type=int, default=100)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--workdir", default=None)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run "
+                     "(one rank per GPU)")
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bart_amd import engine, synth
+
+    # ---- synthetic inputs (rank 0 of the node writes, everyone reads)
+    wd = a.workdir or os.path.join(tempfile.gettempdir(),
+                                   "bartrt_bench_%s" % os.environ.get("MASTER_PORT", "single"))
+    case = synth.make_case(wd, nlayers=a.nlayers, nwave=a.nwave, write=(local_rank == 0),
+                           reuse=True)
+    if world > 1:
+        dist.barrier()
+    engine.init(case.tcfg, shard=(rank, world) if world > 1 else None, device=local_rank)
+
+    nwalk = a.walkers * world            # weak scaling: per-GPU work is fixed
+    profs_h = make_profiles(case, nwalk, seed=20260103)
+    d_prof = torch.from_numpy(profs_h).to(dev)
+    lo, hi = engine.local_range()
+    d_local = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
+
+    def step():
+        engine.run_batch_dev(d_prof, d_local)
+        if world > 1:
+            return engine.allgather_blocks(d_local)
+        return d_local
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    engine.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms, nlaunch = engine.timing_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        assert out.shape == (nwalk, a.nwave) and bool(torch.isfinite(out).all())
+        value = nwalk * a.steps / dt
+        alg = engine.algorithmic_bytes(nwalk)          # bytes per RT launch on this GPU
+        per_launch_s = kern_ms / 1e3 / max(nlaunch, 1)
+        achieved = alg / per_launch_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "forward spectra/sec (100 layers x 1e4 wavenumbers)",
+            "value": value, "unit": "spectra/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "H2O+CO+CO2+CH4 eclipse, %d layers x %d wavenumbers, %d walkers "
+                            "batched per GPU per step, opacity-table path, 27 T planes, "
+                            "H2-H2 CIA, 5 ray angles" % (a.nlayers, a.nwave, a.walkers),
+                "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave,
+                "parallelism": "wavenumber-block shard x%d + all-gather" % world if world > 1
+                               else "single GPU",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "kernel": "rt_eclipse", "launches": nlaunch,
+                         "avg_launch_ms": per_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if world == 1 and not a.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(case, profs_h)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    from bart_amd import transit_module as trm
+    trm.free_memory()
+
+
+if __name__ == "__main__":
+    main()

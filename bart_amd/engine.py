@@ -130,8 +130,9 @@ def allgather_blocks(local, group=None):
     if local.shape[1] != wmax:
         send = torch.zeros((n, wmax), dtype=local.dtype, device=local.device)
         send[:, :local.shape[1]] = local
-    out = torch.empty((world, n, wmax), dtype=local.dtype, device=local.device)
+    out = torch.empty((world * n, wmax), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    out = out.view(world, n, wmax)
     return torch.cat([out[r, :, :sizes[r]] for r in range(world)], dim=1)
 
 

@@ -275,3 +275,51 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
                 species=species, opmol=opmol, press_bar=press, temp0=temp0,
                 abund0=np.array([[float("%1.4e" % a) for a in row] for row in ab]),
                 radius_km=rad, wn=wn, tgrid=tgrid, keys=keys)
+
+
+def write_kurucz(path: str, temps, loggs, wl_nm, inten_cgs, nainten_cgs=None) -> None:
+    """Kurucz ``.pck``-shaped grid (fixed 10-character fields, the layout parsed
+    by reference code/kurucz_inten.py:260-305): preamble ending in ``END``,
+    wavelength block in nm, then per model a ``TEFF`` header (T in columns 5:12,
+    log g in 22:29) and two equal blocks of Eddington fluxes."""
+    wl_nm = np.asarray(wl_nm, float)
+    inten_cgs = np.asarray(inten_cgs, float)
+    if nainten_cgs is None:
+        nainten_cgs = inten_cgs
+    per = 8
+
+    def block(v):
+        return ["".join("%10.4E" % x for x in v[i:i + per]) for i in range(0, len(v), per)]
+
+    def block_nm(v):
+        return ["".join("%10.2f" % x for x in v[i:i + per]) for i in range(0, len(v), per)]
+
+    lines = ["synthetic stellar grid (bart_amd.synth), Kurucz .pck layout", "preamble END"]
+    lines += block_nm(wl_nm)
+    k = 0
+    for t in temps:
+        for g in loggs:
+            h = "TEFF %7.0f  GRAVITY %7.5f  [0.0] SYNTH" % (t, g)
+            lines.append(h)
+            lines += block(inten_cgs[k]) + block(nainten_cgs[k])
+            k += 1
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def blackbody_kurucz(path: str, temps=(5500.0, 5750.0, 6000.0, 6250.0), loggs=(4.0, 4.5, 5.0),
+                     wl_nm=None) -> None:
+    """A blackbody stand-in for inputs/kurucz/*.pck (absent from the reference
+    checkout: .MISSING_LARGE_BLOBS).  Eddington flux H_nu = B_nu / 4, cgs."""
+    if wl_nm is None:
+        wl_nm = np.unique(np.round(np.concatenate([
+            np.linspace(300, 2000, 120), np.linspace(2000, 12000, 400),
+            np.linspace(12000, 40000, 100)]), 2))
+    h, c, k = 6.62607015e-27, 2.99792458e10, 1.380649e-16
+    nu = c / (wl_nm * 1e-7)
+    models = []
+    for t in temps:
+        b = 2 * h * nu ** 3 / c ** 2 / np.expm1(h * nu / (k * t))
+        for gi, _ in enumerate(loggs):
+            models.append(b / 4.0 * (1.0 + 0.01 * gi))
+    write_kurucz(path, temps, loggs, wl_nm, np.array(models))

@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library loads, exports every symbol include/bartrt.h declares,
+refuses to compute without a GPU (no CPU fallback) and reports input errors.
+No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bart_amd import build, transit_module as trm
+    build.build()
+    return trm.lib()
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "bartrt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bartrt_\w+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 25 and "bartrt_run_transit" in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_reference_module_names_present():
+    from bart_amd import transit_module as trm
+    for n in ("transit_init", "get_no_samples", "get_waveno_arr", "set_radius", "set_cloudtop",
+              "set_scattering", "run_transit", "free_memory"):      # BARTfunc.py:230-234,351-363,406
+        assert callable(getattr(trm, n))
+
+
+def test_calls_before_init_fail_loudly(lib):
+    from bart_amd import transit_module as trm
+    trm.free_memory()
+    assert lib.bartrt_get_no_samples() < 0
+    assert b"not initialised" in lib.bartrt_last_error()
+    with pytest.raises(trm.TransitError):
+        trm.run_transit([1.0, 2.0], 2)
+    with pytest.raises(trm.TransitError):
+        trm.set_radius(1.0)
+
+
+def test_missing_and_malformed_inputs(lib, tmp_path):
+    from bart_amd import synth, transit_module as trm
+    with pytest.raises(trm.TransitError, match="cannot open"):
+        trm.transit_init(3, ["transit", "-c", str(tmp_path / "nope.cfg")])
+    with pytest.raises(trm.TransitError, match="no '-c"):
+        trm.transit_init(1, ["transit"])
+    case = synth.make_case(str(tmp_path / "c"), nwave=16, nlayers=10)
+    bad = dict(case.keys)
+    bad["solution"] = "transit"
+    synth.write_tcfg(str(tmp_path / "t.cfg"), bad)
+    with pytest.raises(trm.TransitError, match="not built yet"):
+        trm.transit_init(3, ["transit", "-c", str(tmp_path / "t.cfg")])
+    bad = dict(case.keys)
+    del bad["gsurf"]
+    synth.write_tcfg(str(tmp_path / "g.cfg"), bad)
+    with pytest.raises(trm.TransitError, match="gsurf"):
+        trm.transit_init(3, ["transit", "-c", str(tmp_path / "g.cfg")])
+    with open(case.opacity, "r+b") as f:
+        f.truncate(4000)
+    with pytest.raises(trm.TransitError, match="truncated"):
+        trm.transit_init(3, ["transit", "-c", case.tcfg])
+
+
+def test_no_gpu_means_error_not_fallback(lib, tmp_path):
+    """On a box without a GPU a valid configuration must fail with ENODEV."""
+    import torch
+    from bart_amd import synth, transit_module as trm
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    case = synth.make_case(str(tmp_path), nwave=16, nlayers=10)
+    with pytest.raises(trm.TransitError, match="GPU only"):
+        trm.transit_init(3, ["transit", "-c", case.tcfg])
+    assert lib.bartrt_get_no_samples() < 0
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "bart_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("PT oracle", ""), os.path.join(dirpath, f)

@@ -1,0 +1,63 @@
+"""Copies the rocprofv3 summaries bench.py's numbers come from out of the
+scratch gpurun_out/ tree into profiles/ (tracked).  Usage:
+    python tools/collect_profiles.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir> <calib_dir>]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ours(name):
+    return "bartrt::" in name
+
+
+def kernel_stats(d, out):
+    f = glob.glob(os.path.join(d, "*", "*_kernel_stats.csv"))[0]
+    rows = list(csv.reader(open(f)))
+    with open(out, "w", newline="") as g:
+        w = csv.writer(g)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if ours(r[0]) or "copyBuffer" in r[0]:
+                w.writerow(r)
+
+
+def pmc_mean(d, kernel, counter):
+    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    v, t = [], []
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            v.append(float(r["Counter_Value"]))
+            t.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return sum(v) / len(v), sum(t) / len(t) / 1e3, len(v)
+
+
+if __name__ == "__main__":
+    tag, stats = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    kernel_stats(stats, os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
+    if len(sys.argv) >= 6:
+        fetch, write, calib = sys.argv[3:6]
+        expected = float(sys.argv[6]) if len(sys.argv) > 6 else 80.0e6
+        cal_kb, _, _ = pmc_mean(calib, "rt_eclipse", "FETCH_SIZE")
+        factor = expected / (cal_kb * 1024.0)
+        f_kb, f_us, n = pmc_mean(fetch, "rt_eclipse", "FETCH_SIZE")
+        w_kb, w_us, _ = pmc_mean(write, "rt_eclipse", "WRITE_SIZE")
+        res = {
+            "kernel": "bartrt::rt_eclipse<5,4,1>",
+            "launches_averaged": n,
+            "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB_raw": w_kb,
+            "fetch_calibration": {
+                "known_bytes": expected, "FETCH_SIZE_KB_reported": cal_kb, "factor": factor,
+                "method": "tools/pmc_calib.py: 1 walker, toomuch=1e30, every table byte read "
+                          "once with the kernel's own 8 B/lane coalesced loads"},
+            "traffic_bytes_per_launch": f_kb * 1024.0 * factor + w_kb * 1024.0,
+            "avg_launch_us_in_pmc_pass": f_us,
+        }
+        json.dump(res, open(os.path.join(ROOT, "profiles", tag + "_pmc.json"), "w"), indent=1)
+        json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+        print(json.dumps(res, indent=1))

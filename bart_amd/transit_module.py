@@ -30,6 +30,23 @@ class TransitError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so under torch/lib with the same SONAME as /opt/rocm's; whichever
+    is mapped first serves both torch and libbartrt.so.  When torch is installed
+    its copy is mapped here (without importing torch) so that a later
+    ``import torch`` in the same process finds the runtime it was built for."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Loads libbartrt.so (never builds it: ``__graft_entry__.build()`` or
     ``python -m bart_amd.build`` does)."""
@@ -39,6 +56,7 @@ def lib():
             raise TransitError(
                 "libbartrt.so is missing: build it with `python -m bart_amd.build` "
                 "(the engine has no CPU fallback)")
+        _preload_hip_runtime()
         L = C.CDLL(_LIBPATH)
         d, i, p = C.c_double, C.c_int, C.c_void_p
         L.bartrt_last_error.restype = C.c_char_p

@@ -1,0 +1,248 @@
+"""The per-MCMC-step callable on the MI355X engine.
+
+Mirror of the reference worker ``code/BARTfunc.py``: same configuration keys
+(its ``[MCMC]`` section, BARTfunc.py:47-123), same wire protocol with the MC3
+master (BARTfunc.py:129-132, 309-316, 399, 405: broadcast of (npars, niter),
+per step a scatter of ``params[npars]`` and a gather of ``bandflux[nfilters]``,
+``params[0] == inf`` ends the loop), same rejection semantics (``-1`` in every
+band for a non-physical T(p), a negative H2/He remainder or a violated energy
+balance: BARTfunc.py:327-330, 339-344, 378-383).
+
+What differs is where the work runs: T(p), abundance scaling, the RT engine and
+the band integration are device kernels of libbartrt.so; ``Worker.step`` takes a
+whole batch of walkers.  ``main(comm)`` keeps the reference's one-walker-per-
+process shape so MC3 can drive it unchanged; the communicator only needs the
+mpi4py methods ``Get_rank, Barrier, Bcast, Scatter, Gather, Disconnect``.
+"""
+from __future__ import annotations
+
+import argparse
+import configparser
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import engine, hostio
+from . import transit_module as trm
+
+PT_NPARS = {"line": 5, "iso": 1}
+PT_CODE = {"line": 0, "iso": 1}
+SOLUTION_CODE = {"eclipse": 0, "transit": 1, "direct": 2}
+
+
+def parray(s):
+    """MC3's ``parray``: whitespace/newline separated list; numbers if they all
+    parse, strings otherwise."""
+    if isinstance(s, (list, tuple, np.ndarray)):
+        return list(s)
+    tok = str(s).split()
+    try:
+        return [float(t) for t in tok]
+    except ValueError:
+        return tok
+
+
+@dataclass
+class WorkerConfig:
+    atmfile: str = None
+    tconfig: str = None
+    tep_name: str = None
+    kurucz: str = None
+    filters: list = field(default_factory=list)
+    params: list = field(default_factory=list)
+    molfit: list = field(default_factory=list)
+    PTtype: str = "line"
+    tint: float = 100.0
+    tint_type: str = "const"
+    Tmin: float = 400.0
+    Tmax: float = 3000.0
+    cloudtop: float = None
+    scattering: str = None
+    solution: str = "eclipse"
+    ebalance: bool = False
+
+    @classmethod
+    def from_cfg(cls, path: str, section: str = "MCMC") -> "WorkerConfig":
+        cp = configparser.ConfigParser()
+        cp.optionxform = str
+        if not cp.read([path]):
+            raise FileNotFoundError(path)
+        d = dict(cp.items(section))
+        base = os.path.dirname(os.path.abspath(path))
+        rel = lambda p: p if os.path.isabs(p) else os.path.normpath(os.path.join(base, p))
+        c = cls()
+        for k in ("atmfile", "tconfig", "tep_name", "kurucz"):
+            if d.get(k):
+                setattr(c, k, rel(d[k]))
+        c.filters = [rel(f) for f in parray(d.get("filters", ""))]
+        c.params = parray(d.get("params", ""))
+        c.molfit = [str(m) for m in parray(d.get("molfit", ""))]
+        c.PTtype = d.get("PTtype", c.PTtype)
+        c.tint = float(d.get("tint", c.tint))
+        c.tint_type = d.get("tint_type", c.tint_type)
+        c.Tmin = float(d.get("Tmin", c.Tmin))
+        c.Tmax = float(d.get("Tmax", c.Tmax))
+        if d.get("cloudtop") not in (None, "", "None"):
+            c.cloudtop = float(d["cloudtop"])
+        if d.get("scattering") not in (None, "", "None"):
+            c.scattering = d["scattering"]
+        c.solution = d.get("solution", c.solution)
+        c.ebalance = str(d.get("ebalance", "False")).strip() in ("True", "1", "true")
+        return c
+
+
+class Worker:
+    """Initialisation of BARTfunc.py:134-299 plus a batched ``step``."""
+
+    def __init__(self, cfg: WorkerConfig, shard=None, device=None):
+        self.cfg = cfg
+        if cfg.PTtype not in PT_NPARS:
+            raise NotImplementedError(
+                "PTtype %r: only %s run on the device so far" % (cfg.PTtype, sorted(PT_NPARS)))
+        if cfg.solution == "transit":
+            raise NotImplementedError("solution 'transit' (modulation spectrum) is not built yet")
+        tep = hostio.TepFile(cfg.tep_name)
+        self.tstar = float(tep.getvalue("Ts")[0])
+        self.rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+        self.sma = float(tep.getvalue("a")[0]) * hostio.AU
+        self.rplanet = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+        self.mplanet = float(tep.getvalue("Mp")[0]) * hostio.Mjup
+        self.gstar = float(tep.getvalue("loggstar")[0])
+        self.rprs = self.rplanet / self.rstar
+        nfree = len(cfg.params)
+        self.nmolfit = len(cfg.molfit)
+        self.ncloud = int(cfg.cloudtop is not None)
+        self.nray = int(cfg.scattering is not None)
+        self.nradfit = int(cfg.solution == "transit")
+        self.nPT = nfree - self.nmolfit - self.ncloud - self.nray - self.nradfit
+        if self.nPT != PT_NPARS[cfg.PTtype]:
+            raise ValueError("PTtype %r takes %d parameters, the configuration leaves %d"
+                             % (cfg.PTtype, PT_NPARS[cfg.PTtype], self.nPT))
+        self.species, press, _, self.abundances = hostio.readatm(cfg.atmfile)
+        self.nlayers, self.nspecies = self.abundances.shape
+        self.imol = [self.species.index(m) for m in cfg.molfit]
+        gplanet = 100.0 * hostio.G_NEWTON * self.mplanet / self.rplanet ** 2
+        ptargs = [self.rstar, self.tstar, cfg.tint, self.sma, gplanet]
+        # engine (BARTfunc.py:226-234)
+        engine.init(cfg.tconfig, shard=shard, device=device)
+        self.nwave = trm.get_no_samples()
+        self.specwn = trm.get_waveno_arr(self.nwave)
+        if engine.species() != self.species or engine.nlayers() != self.nlayers:
+            raise ValueError("atmfile of the MCMC configuration and 'atm' of the transit "
+                             "configuration describe different atmospheres")
+        # filters and star on the spectrum grid (BARTfunc.py:244-292)
+        self.nfilters = len(cfg.filters)
+        starwn = starfl = None
+        if cfg.solution in ("eclipse", "transit"):
+            starfl, starwn, _, _ = hostio.readkurucz(cfg.kurucz, self.tstar, self.gstar)
+        idx0, npts, nif, ist = [], [], [], []
+        for i, f in enumerate(cfg.filters):
+            fwn, ftr = hostio.readfilter(f)
+            if fwn[0] < self.specwn[0] or fwn[-1] > self.specwn[-1]:
+                raise ValueError(
+                    "Wavenumber array ({:.2f} - {:.2f} cm-1) does not cover the filter[{:d}] "
+                    "wavenumber range ({:.2f} - {:.2f} cm-1).".format(
+                        self.specwn[0], self.specwn[-1], i, fwn[0], fwn[-1]))
+            if starwn is not None:
+                a, b, ind = hostio.resample(self.specwn, fwn, ftr, starwn, starfl)
+            else:
+                a, b, ind = hostio.resample(self.specwn, fwn, ftr, fwn, ftr)
+            ind = ind[0]
+            idx0.append(int(ind[0])); npts.append(len(ind)); nif.append(a); ist.append(b)
+        self.windows = (np.array(idx0, np.int32), np.array(npts, np.int32),
+                        np.concatenate(nif) if nif else np.zeros(0),
+                        np.concatenate(ist) if ist else np.zeros(0))
+        engine.step_setup(ptargs, cfg.Tmin, cfg.Tmax, self.abundances, self.imol, *self.windows,
+                          self.rprs, solution=SOLUTION_CODE[cfg.solution],
+                          pttype=PT_CODE[cfg.PTtype],
+                          tint_thorngren=(cfg.tint_type == "thorngren"))
+        if cfg.ebalance:
+            # BARTfunc.py:375-377
+            e_in = (hostio.sig * self.tstar ** 4 * self.rstar ** 2 * np.pi * self.rplanet ** 2
+                    / self.sma ** 2 * 1e7)
+            engine.step_set_ebalance(True, e_in, 4 * (self.rplanet * 100) ** 2)
+        self.nbad = {1: 0, 2: 0, 3: 0}
+
+    def step(self, params: np.ndarray) -> np.ndarray:
+        """params [nwalkers, npars] (or [npars]) -> bandflux [nwalkers, nfilters];
+        rejected walkers carry -1 in every band."""
+        p = np.atleast_2d(np.asarray(params, np.double))
+        off = self.nPT + self.nradfit
+        if self.ncloud or self.nray:
+            # engine-global setters, as in the reference (one walker per call)
+            if p.shape[0] != 1:
+                raise NotImplementedError("cloud/scattering parameters are per-call settings: "
+                                          "batch size must be 1")
+            if self.ncloud:
+                trm.set_cloudtop(p[0, off])
+            if self.nray:
+                if "polar" in self.cfg.scattering:
+                    trm.set_scattering(2, 0.0)
+                else:
+                    trm.set_scattering(1, p[0, off + self.ncloud])
+        core = np.concatenate([p[:, :self.nPT], p[:, off + self.ncloud + self.nray:]], axis=1)
+        band, status = engine.step_batch(core, self.nfilters)
+        for s in status[status > 0]:
+            self.nbad[int(s)] += 1
+        return band
+
+    def close(self):
+        trm.free_memory()
+
+
+# ---- MC3 communicator helpers (same call order as MCcubed.utils on the worker) ----
+def comm_bcast(comm, array):
+    comm.Barrier()
+    comm.Bcast(array, root=0)
+
+
+def comm_scatter(comm, array):
+    comm.Barrier()
+    comm.Scatter(None, array, root=0)
+
+
+def comm_gather(comm, array):
+    comm.Barrier()
+    comm.Gather(array, None, root=0)
+
+
+def comm_disconnect(comm):
+    comm.Barrier()
+    comm.Disconnect()
+
+
+def main(comm, argv=None):
+    """The reference's ``main(comm)`` (BARTfunc.py:33-412) on the GPU engine."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("-c", "--config_file", required=True)
+    args, _ = ap.parse_known_args(argv)
+    cfg = WorkerConfig.from_cfg(args.config_file)
+    verb = comm.Get_rank() == 0
+    array1 = np.zeros(2, int)
+    comm_bcast(comm, array1)
+    npars, niter = int(array1[0]), int(array1[1])
+    w = Worker(cfg)
+    if verb:
+        print("There are {:d} layers and {:d} species.".format(w.nlayers, w.nspecies))
+    params = np.zeros(npars, np.double)
+    while niter >= 0:
+        niter -= 1
+        comm_scatter(comm, params)
+        if params[0] == np.inf:
+            break
+        comm_gather(comm, np.ascontiguousarray(w.step(params)[0]))
+    comm_disconnect(comm)
+    w.close()
+    if verb:
+        print("Bad iterations of chain 0 due to:")
+        print("  Temperature: {}".format(w.nbad[1]))
+        print("  Abundance:   {}".format(w.nbad[2]))
+        if cfg.ebalance:
+            print("  Energy:      {}".format(w.nbad[3]))
+    return w.nbad
+
+
+if __name__ == "__main__":
+    from mpi4py import MPI  # only needed when launched by MC3
+    main(MPI.Comm.Get_parent())

@@ -1,0 +1,108 @@
+"""The BARTfunc-compatible worker: configuration parsing (CPU) and the MC3 wire
+protocol driven by an in-process fake communicator (GPU)."""
+import numpy as np
+import pytest
+
+
+class FakeIntercomm:
+    """Master side of MC3's protocol for one worker (reference
+    code/BARTfunc.py:129-132,309-316,399,405): Bcast (npars, niter), then per
+    step Scatter(params) / Gather(bandflux); an all-inf vector ends the run."""
+
+    def __init__(self, param_sets):
+        self.queue = [np.asarray(p, float) for p in param_sets]
+        self.npars = len(self.queue[0])
+        self.received = []
+        self.log = []
+        self.disconnected = False
+
+    def Get_rank(self):
+        return 0
+
+    def Barrier(self):
+        self.log.append("barrier")
+
+    def Bcast(self, array, root=0):
+        array[:] = [self.npars, len(self.queue) + 5]     # niter larger than the run: inf ends it
+        self.log.append("bcast")
+
+    def Scatter(self, send, recv, root=0):
+        recv[:] = self.queue.pop(0) if self.queue else np.inf
+        self.log.append("scatter")
+
+    def Gather(self, send, recv, root=0):
+        self.received.append(np.array(send, float))
+        self.log.append("gather")
+
+    def Disconnect(self):
+        self.disconnected = True
+
+
+def test_worker_config_parsing(tmp_path):
+    from bart_amd import synthcfg
+    from bart_amd.BARTfunc import WorkerConfig, parray
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=64, nlayers=12)
+    c = WorkerConfig.from_cfg(cfg)
+    assert c.tconfig == case.tcfg and c.atmfile == case.atm
+    assert len(c.filters) == 10 and c.molfit == ["CH4"] and len(c.params) == 6
+    assert c.PTtype == "line" and c.solution == "eclipse" and c.ebalance is False
+    assert (c.Tmin, c.Tmax) == (400.0, 3000.0)
+    assert parray("a b\n c") == ["a", "b", "c"] and parray("1 2.5") == [1.0, 2.5]
+
+
+@pytest.mark.gpu
+def test_worker_protocol_and_results(tmp_path):
+    from bart_amd import BARTfunc, hostio, synthcfg
+    from oracle import pyhalf, rt_oracle as orc
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=2501)
+    good = [-2.0, 0.0, 1.0, 0.0, 0.98, -0.5]
+    good2 = [-2.2, -0.3, 0.5, 0.4, 0.9, 0.3]
+    hot = [-1.0, -2.0, -2.0, 0.0, 1.2, -0.5]
+    rich = [-2.0, 0.0, 1.0, 0.0, 0.98, 4.1]
+    comm = FakeIntercomm([good, hot, good2, rich])
+    nbad = BARTfunc.main(comm, ["-c", cfg])
+    assert comm.disconnected and nbad[1] == 1 and nbad[2] == 1
+    assert [x for x in comm.log if x != "barrier"] == \
+        ["bcast"] + ["scatter", "gather"] * 4 + ["scatter"]
+    out = comm.received
+    assert len(out) == 4 and all(o.shape == (10,) for o in out)
+    assert np.all(out[1] == -1.0) and np.all(out[3] == -1.0)
+    # independent chain: reference-pinned host readers -> oracle RT -> numpy band integration
+    wc = BARTfunc.WorkerConfig.from_cfg(cfg)
+    tep = hostio.TepFile(wc.tep_name)
+    rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+    rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+    mp = float(tep.getvalue("Mp")[0]) * hostio.Mjup
+    ptargs = [rstar, float(tep.getvalue("Ts")[0]), 100.0, float(tep.getvalue("a")[0]) * hostio.AU,
+              100.0 * hostio.G_NEWTON * mp / rp ** 2]
+    species, press, _, abund = hostio.readatm(wc.atmfile)
+    o = orc.OracleEngine(wc.tconfig)
+    starfl, starwn, _, _ = hostio.readkurucz(wc.kurucz, ptargs[1], float(tep.getvalue("loggstar")[0]))
+    idx0, npts, nif, ist = [], [], [], []
+    for f in wc.filters:
+        a, b, ind = hostio.resample(o.wn, *hostio.readfilter(f), starwn, starfl)
+        idx0.append(ind[0][0]); npts.append(len(ind[0])); nif.append(a); ist.append(b)
+    for par, got in ((good, out[0]), (good2, out[2])):
+        prof, st = pyhalf.step_profiles(np.array(par), press, abund, species, ["CH4"], ptargs,
+                                        400.0, 3000.0)
+        assert st == 0
+        ref = pyhalf.bandflux(o.run(prof), o.wn, idx0, npts, np.concatenate(nif),
+                              np.concatenate(ist), rp / rstar)
+        np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_worker_batched_step_and_ebalance(tmp_path):
+    from bart_amd import BARTfunc, synthcfg
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=1200, ebalance=True)
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        rng = np.random.default_rng(2)
+        p = np.array([-2.0, 0.0, 1.0, 0.0, 0.98, -0.5]) + 0.05 * rng.normal(size=(33, 6))
+        band = w.step(p)
+        assert band.shape == (33, 10)
+        one = np.array([w.step(q)[0] for q in p[:4]])
+        assert np.array_equal(one, band[:4])          # batch == one-at-a-time, bit for bit
+        assert np.all(band[band[:, 0] >= 0] > 0)
+    finally:
+        w.close()

@@ -13,6 +13,9 @@
 // read back as wave-uniform broadcasts.  HBM-bound: no MFMA anywhere.
 #include "kernels.hpp"
 
+#include <cstdlib>
+#include <string>
+
 namespace bartrt {
 
 // ---------------------------------------------------------------------------
@@ -43,34 +46,44 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   }
   __syncthreads();
   const bool bad = sBad != 0;
-  if (threadIdx.x == 0 && !bad) {
-    // Hydrostatic radii: sequential recurrence with g ~ 1/r^2
-    // (makeatm.py:229-258), layers bottom -> top.
+  // Hydrostatic radii, makeatm.py:229-258 (layers bottom -> top).  The
+  // reference steps r_i = r_{i+-1} -+ H_i / g and rescales g by (r_old/r_new)^2,
+  // i.e. g r^2 stays g0 R0^2: the step is r -+ (H_i / (g0 R0^2)) r^2.  The
+  // layer terms H_i are formed in parallel; only that two-flop recurrence is
+  // serial (lane 0 walks down from the reference layer, lane 64 walks up).
+  double *sH = sm + 3 * L;
+  {
     const double rgas = kKB / kAMU;
+    const double invG = 1.0 / (p.gsurf * p.refradius * p.refradius);
+    for (int i = threadIdx.x; i + 1 < L; i += blockDim.x)
+      sH[i] = 0.5 * (sT[i] / sMu[i] + sT[i + 1] / sMu[i + 1]) * (rgas * p.dlnp[i]) * invG;
+    if (threadIdx.x == 0 && !bad) {
+      const int ix = p.ref_idx;
+      const double r0 = p.refradius, g0 = p.gsurf;
+      if (!p.ref_exact) {
+        const int b = p.ref_ib;
+        double t0 = sT[b] + p.ref_f * (sT[b + 1] - sT[b]);
+        double m0 = sMu[b] + p.ref_f * (sMu[b + 1] - sMu[b]);
+        sR[ix] = r0 + 0.5 * (sT[ix] / sMu[ix] + t0 / m0) * (rgas * p.ref_lnp / g0);
+      } else {
+        sR[ix] = r0;
+      }
+    }
+  }
+  __syncthreads();
+  if (!bad && (threadIdx.x == 0 || threadIdx.x == 64)) {
     const int ix = p.ref_idx;
-    const double r0 = p.refradius, g0 = p.gsurf;
-    double g;
-    if (!p.ref_exact) {
-      const int b = p.ref_ib;
-      double t0 = sT[b] + p.ref_f * (sT[b + 1] - sT[b]);
-      double m0 = sMu[b] + p.ref_f * (sMu[b + 1] - sMu[b]);
-      sR[ix] = r0 + 0.5 * (sT[ix] / sMu[ix] + t0 / m0) * (rgas * p.ref_lnp / g0);
-      g = g0 * r0 * r0 / (sR[ix] * sR[ix]);
+    double r = sR[ix];
+    if (threadIdx.x == 0) {
+      for (int i = ix - 1; i >= 0; i--) {
+        r = fma(-sH[i], r * r, r);
+        sR[i] = r;
+      }
     } else {
-      sR[ix] = r0;
-      g = g0;
-    }
-    double gi = g;
-    for (int i = ix - 1; i >= 0; i--) {
-      sR[i] = sR[i + 1] - 0.5 * (sT[i] / sMu[i] + sT[i + 1] / sMu[i + 1]) *
-                              (rgas * p.dlnp[i] / gi);
-      gi = gi * sR[i + 1] * sR[i + 1] / (sR[i] * sR[i]);
-    }
-    gi = g;
-    for (int i = ix + 1; i < L; i++) {
-      sR[i] = sR[i - 1] + 0.5 * (sT[i] / sMu[i] + sT[i - 1] / sMu[i - 1]) *
-                              (rgas * p.dlnp[i - 1] / gi);
-      gi = gi * sR[i - 1] * sR[i - 1] / (sR[i] * sR[i]);
+      for (int i = ix + 1; i < L; i++) {
+        r = fma(sH[i - 1], r * r, r);
+        sR[i] = r;
+      }
     }
   }
   __syncthreads();
@@ -247,9 +260,144 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// exp(x) for finite x <= ~700 without the special-case selects of the library
+// routine: Cody-Waite reduction by ln2, degree-11 interpolant on
+// [-ln2/2, ln2/2] (Chebyshev nodes, max relative error 1.7e-17 before
+// rounding), scaling by ldexp (underflows to 0 for very negative x).
+__device__ __forceinline__ double exp_core(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 2.5110037605963777e-08;
+  p = fma(p, r, 2.763263963904103e-07);
+  p = fma(p, r, 2.755724091857897e-06);
+  p = fma(p, r, 2.4801485482328494e-05);
+  p = fma(p, r, 0.00019841269890047113);
+  p = fma(p, r, 0.0013888888952314775);
+  p = fma(p, r, 0.008333333333319601);
+  p = fma(p, r, 0.0416666666664881);
+  p = fma(p, r, 0.1666666666666668);
+  p = fma(p, r, 0.5000000000000019);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// 1/d for normal, positive d: hardware estimate + two Newton steps.
+__device__ __forceinline__ double rcp_core(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+
+// Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
+// bases (SGPR) + one 32-bit lane offset for every load, and the next layer's
+// 2M+2C loads issued before the current layer's arithmetic so that a lone wave
+// on a SIMD keeps HBM requests in flight while it computes.
+template <int AT, int MT, int CT>
+__global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  const int L = p.L, W = p.W, Nt = p.Nt;
+  int tile, w;
+  block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  int *sI = reinterpret_cast<int *>(smem + (size_t)L * NC);
+  {
+    const double *gC = p.coef + (size_t)w * L * NC;
+    const int *gI = p.idx + (size_t)w * L * NI;
+    for (int t = threadIdx.x; t < L * NC; t += blockDim.x) sC[t] = gC[t];
+    for (int t = threadIdx.x; t < L * NI; t += blockDim.x) sI[t] = gI[t];
+  }
+  __syncthreads();
+
+  const int i = tile * blockDim.x + threadIdx.x;
+  const bool valid = i < W;
+  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
+  const unsigned off = ii * 8u;  // byte offset of this lane inside a table row
+  const double nu = p.wn[ii];
+  const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+  const double nu4 = (nu * nu) * (nu * nu);
+  const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
+
+  auto load_layer = [&](int k, double (&r)[NLD > 0 ? NLD : 1]) {
+    const int *ix = sI + k * NI;
+    const int l = L - 1 - k;
+    if (M > 0) {
+      const int t0 = __builtin_amdgcn_readfirstlane(ix[0]);
+      const char *row = reinterpret_cast<const char *>(p.kappa) + ((size_t)l * Nt + t0) * planeB;
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        r[2 * m] = *reinterpret_cast<const double *>(row + m * rowB + off);
+        r[2 * m + 1] = *reinterpret_cast<const double *>(row + planeB + m * rowB + off);
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const int j = __builtin_amdgcn_readfirstlane(ix[1 + cc]);
+      const char *row = reinterpret_cast<const char *>(p.cia) + (size_t)j * rowB;
+      r[2 * M + 2 * cc] = *reinterpret_cast<const double *>(row + off);
+      r[2 * M + 2 * cc + 1] = *reinterpret_cast<const double *>(row + rowB + off);
+    }
+  };
+
+  double I[A], fprev[A];
+#pragma unroll
+  for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 0.0; }
+  double cur[NLD > 0 ? NLD : 1], nxt[NLD > 0 ? NLD : 1];
+  double tau = 0.0, eprev = 0.0;
+  bool active = true;
+  int last = 0;
+  const int kend = p.kstop[w];
+  load_layer(0, cur);
+  for (int k = 0; k <= kend; ++k) {
+    if (k < kend) load_layer(k + 1, nxt);
+    const double *c = sC + k * NC;
+    double e = c[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+    for (int j = 0; j < NLD; j++) e = fma(c[2 + j], cur[j], e);
+    const double dtau = active ? 0.5 * (eprev + e) * c[0] : 0.0;
+    tau += dtau;
+    const double B = bnum * rcp_core(exp_core(fmin(c[1] * nu, 700.0)) - 1.0);
+    const double hd = 0.5 * dtau;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+      const double f = B * exp_core(fmax(-tau * p.invmu[a], -745.0));
+      I[a] = fma(fprev[a] + f, hd, I[a]);
+      fprev[a] = f;
+    }
+    eprev = e;
+    if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tau;
+    if (active) {
+      last = k;
+      if (tau > p.toomuch) active = false;
+    }
+    if (!__any(active)) break;
+#pragma unroll
+    for (int j = 0; j < NLD; j++) cur[j] = nxt[j];
+  }
+  double F = 0.0;
+  const bool surf = p.cloud_on && active;
+#pragma unroll
+  for (int a = 0; a < A; a++) F += p.wgt[a] * (I[a] * p.invmu[a] + (surf ? fprev[a] : 0.0));
+  if (valid) {
+    p.spec[(size_t)w * W + i] = F;
+    if (p.tau_out) {
+      for (int k = last + 1; k < L; k++) p.tau_out[(size_t)i * L + k] = tau;
+      p.last_out[i] = last;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
-  size_t sh = sizeof(double) * 3 * a.L;
+  size_t sh = sizeof(double) * 4 * a.L;
   hipLaunchKernelGGL(prep_profiles, dim3(a.nwalkers), dim3(128), sh, st, a);
   return hipGetLastError();
 }
@@ -267,8 +415,23 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * (size_t)a.L * coef_stride(a.M, a.C) +
                     sizeof(int) * (size_t)a.L * idx_stride(a.C);
-  if (a.A == 5 && a.M == 4 && a.C == 1) return launch_rt_t<5, 4, 1>(a, block, nblocks, sh, st);
-  if (a.A == 5 && a.M == 1 && a.C == 1) return launch_rt_t<5, 1, 1>(a, block, nblocks, sh, st);
+  static const bool generic_only = [] {
+    const char *e = std::getenv("BARTRT_KERNEL");  // "generic" forces the fallback (A/B runs)
+    return e && std::string(e) == "generic";
+  }();
+  if (!generic_only && a.A == 5) {
+#define BARTRT_FAST(MM, CC)                                                        \
+  if (a.M == MM && a.C == CC) {                                                    \
+    hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC>), dim3(nblocks), dim3(block), sh, st, a); \
+    return hipGetLastError();                                                      \
+  }
+    BARTRT_FAST(1, 0) BARTRT_FAST(1, 1) BARTRT_FAST(1, 2)
+    BARTRT_FAST(2, 0) BARTRT_FAST(2, 1) BARTRT_FAST(2, 2)
+    BARTRT_FAST(3, 0) BARTRT_FAST(3, 1) BARTRT_FAST(3, 2)
+    BARTRT_FAST(4, 0) BARTRT_FAST(4, 1) BARTRT_FAST(4, 2)
+    BARTRT_FAST(5, 1) BARTRT_FAST(6, 1)
+#undef BARTRT_FAST
+  }
   if (a.A == 5) return launch_rt_t<5, -1, -1>(a, block, nblocks, sh, st);
   return launch_rt_t<0, -1, -1>(a, block, nblocks, sh, st);
 }

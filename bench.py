@@ -59,6 +59,8 @@ def cpu_baseline(case, profs, seconds_target=12.0):
     empty submodule) timed on this host's cores, one walker per thread."""
     from oracle import rt_oracle as orc
     cores = os.cpu_count() or 1
+    if len(profs) < 4 * cores:
+        profs = make_profiles(case, 4 * cores, seed=20260104)
     eng = orc.OracleEngine(case.tcfg)
     t0 = time.perf_counter()
     eng.run(profs[0])
@@ -77,11 +79,16 @@ def cpu_baseline(case, profs, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--walkers", type=int, default=256, help="walkers per GPU per step")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--walkers", type=int, default=10,
+                    help="walkers per GPU per step (BASELINE.json config 3: 10)")
     ap.add_argument("--nwave", type=int, default=10000)
     ap.add_argument("--nlayers", type=int, default=100)
+    ap.add_argument("--nsets", type=int, default=16,
+                    help="distinct walker batches cycled through the steps")
+    ap.add_argument("--sweep", default="64,256,1024",
+                    help="extra batch sizes reported under batch_sweep (N=1 only; '' = none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
@@ -115,49 +122,68 @@ def main():
     if world > 1:
         dist.barrier()
     engine.init(case.tcfg, shard=(rank, world) if world > 1 else None, device=local_rank)
+    lo, hi = engine.local_range()
+
+    def timed(nwalk, steps, warmup, record):
+        """`steps` passes of the hot path over batches of nwalk walkers; the
+        batches cycle through a.nsets distinct seeded sets so that consecutive
+        steps do not re-read exactly the same table planes."""
+        nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
+        profs_h = make_profiles(case, nwalk * nsets, seed=20260103).reshape(nsets, nwalk, -1)
+        d_prof = torch.from_numpy(profs_h).to(dev)
+        d_local = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
+
+        def step(i):
+            engine.run_batch_dev(d_prof[i % nsets], d_local)
+            if world > 1:
+                return engine.allgather_blocks(d_local)
+            return d_local
+
+        for i in range(warmup):
+            out = step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if record:
+            engine.timing_begin()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kern_ms, nlaunch = engine.timing_end() if record else (0.0, 0)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ok = out.shape == (nwalk, a.nwave) and bool(torch.isfinite(out).all())
+        return dt, kern_ms, nlaunch, ok, profs_h[0]
 
     nwalk = a.walkers * world            # weak scaling: per-GPU work is fixed
-    profs_h = make_profiles(case, nwalk, seed=20260103)
-    d_prof = torch.from_numpy(profs_h).to(dev)
-    lo, hi = engine.local_range()
-    d_local = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
+    dt, kern_ms, nlaunch, ok, profs0 = timed(nwalk, a.steps, a.warmup, True)
 
-    def step():
-        engine.run_batch_dev(d_prof, d_local)
-        if world > 1:
-            return engine.allgather_blocks(d_local)
-        return d_local
-
-    for _ in range(a.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    engine.timing_begin()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern_ms, nlaunch = engine.timing_end()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    sweep = {}
+    if world == 1 and a.sweep:
+        for b in [int(x) for x in a.sweep.split(",") if x]:
+            k = max(5, min(50, 2000 // b))
+            sdt, skm, snl, sok, _ = timed(b, k, 2, True)
+            sweep[str(b)] = {"spectra_per_s": b * k / sdt, "ms_per_step": sdt / k * 1e3,
+                             "rt_kernel_ms": skm / max(snl, 1),
+                             "algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
 
     if rank == 0:
-        assert out.shape == (nwalk, a.nwave) and bool(torch.isfinite(out).all())
+        assert ok
         value = nwalk * a.steps / dt
         alg = engine.algorithmic_bytes(nwalk)          # bytes per RT launch on this GPU
         per_launch_s = kern_ms / 1e3 / max(nlaunch, 1)
         achieved = alg / per_launch_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1 and a.walkers == 10:
             try:
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
             except Exception:
@@ -182,8 +208,10 @@ def main():
                          "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg},
         }
+        if sweep:
+            res["batch_sweep"] = sweep
         if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(case, profs_h)
+            res["cpu_baseline"] = cpu_baseline(case, profs0)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

@@ -94,6 +94,51 @@ def test_demo_shape_one_molecule(demo_case):
         trm.free_memory()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(opmol=("H2O", "CO"), cia=False),                       # specialised kernel, no CIA
+    dict(opmol=("H2O", "CO", "CH4"), raygrid=(0, 30, 60)),      # generic kernel, 3 angles
+    dict(opmol=(), cia=True),                                   # CIA only, no opacity table
+    dict(opmol=("H2O",), raygrid=(0, 10, 20, 30, 40, 50, 60, 70, 80)),
+    dict(nlayers=37, nwave=100, toomuch=1e30),                  # ragged sizes, no early exit
+    dict(nlayers=150, nwave=65),
+])
+def test_kernel_variants_match_oracle(tmp_path, kw):
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    kw = dict(kw)
+    kw.setdefault("nwave", 333)
+    c = synth.make_case(str(tmp_path), **kw)
+    engine.init(c.tcfg)
+    try:
+        profs = walkers(c, 3, seed=4)
+        spec = engine.run_batch(profs)
+        ref = orc.OracleEngine(c.tcfg).run_batch(profs)
+        np.testing.assert_allclose(spec, ref, rtol=RTOL, atol=1e-300)
+    finally:
+        trm.free_memory()
+
+
+def test_generic_kernel_agrees_with_specialised(small_case, monkeypatch):
+    """BARTRT_KERNEL=generic is read once per process: run it in a child."""
+    import subprocess, sys, os
+    from bart_amd import engine, transit_module as trm
+    c = small_case
+    profs = walkers(c, 2, seed=8)
+    np.save(os.path.join(c.dir, "p.npy"), profs)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bart_amd import engine, transit_module as trm\n"
+            "engine.init(%r); s = engine.run_batch(np.load(%r)); np.save(%r, s); trm.free_memory()\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), c.tcfg,
+               os.path.join(c.dir, "p.npy"), os.path.join(c.dir, "s_generic.npy")))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_KERNEL="generic"))
+    engine.init(c.tcfg)
+    try:
+        fast = engine.run_batch(profs)
+    finally:
+        trm.free_memory()
+    np.testing.assert_allclose(fast, np.load(os.path.join(c.dir, "s_generic.npy")), rtol=1e-12)
+
+
 def test_shards_reassemble_full_spectrum(small_case):
     """Wavenumber-block sharding: the blocks of every rank, concatenated, are the
     unsharded spectrum bit for bit (no halo)."""

@@ -26,8 +26,9 @@ import numpy as np
 from . import engine, hostio
 from . import transit_module as trm
 
-PT_NPARS = {"line": 5, "iso": 1}
-PT_CODE = {"line": 0, "iso": 1}
+# the reference's PTfunc table (BARTfunc.py:150-155) -> device model codes
+PT_NPARS = {"line": 5, "iso": 1, "madhu_noinv": 5, "madhu_inv": 6, "adiabatic": 3, "piette": 8}
+PT_CODE = {"line": 0, "iso": 1, "madhu_noinv": 2, "madhu_inv": 3, "adiabatic": 4, "piette": 5}
 SOLUTION_CODE = {"eclipse": 0, "transit": 1, "direct": 2}
 
 
@@ -98,8 +99,7 @@ class Worker:
     def __init__(self, cfg: WorkerConfig, shard=None, device=None):
         self.cfg = cfg
         if cfg.PTtype not in PT_NPARS:
-            raise NotImplementedError(
-                "PTtype %r: only %s run on the device so far" % (cfg.PTtype, sorted(PT_NPARS)))
+            raise ValueError("unknown PTtype %r (known: %s)" % (cfg.PTtype, sorted(PT_NPARS)))
         if cfg.solution == "transit":
             raise NotImplementedError("solution 'transit' (modulation spectrum) is not built yet")
         tep = hostio.TepFile(cfg.tep_name)

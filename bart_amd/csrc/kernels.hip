@@ -19,9 +19,14 @@
 namespace bartrt {
 
 // ---------------------------------------------------------------------------
+// Largest j with g[j] <= t, clamped to [0, n-2].  Starts from the uniform-grid
+// guess (tlow/thigh/tempdelt grids are uniform) and walks to the exact bracket.
 __device__ inline int bracket_dev(const double *g, int n, double t) {
-  int j = 0;
+  if (n <= 2) return 0;
+  double x = (t - g[0]) / (g[1] - g[0]);
+  int j = x > 0.0 ? (x < (double)(n - 2) ? (int)x : n - 2) : 0;
   while (j < n - 2 && g[j + 1] <= t) j++;
+  while (j > 0 && g[j] > t) j--;
   return j;
 }
 
@@ -74,16 +79,27 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   if (!bad && (threadIdx.x == 0 || threadIdx.x == 64)) {
     const int ix = p.ref_idx;
     double r = sR[ix];
+    // blocks of 8 terms are fetched from LDS ahead of the dependent chain
     if (threadIdx.x == 0) {
-      for (int i = ix - 1; i >= 0; i--) {
-        r = fma(-sH[i], r * r, r);
-        sR[i] = r;
+      int i = ix - 1;
+      for (; i >= 7; i -= 8) {
+        double h[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[j] = sH[i - j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { r = fma(-h[j], r * r, r); sR[i - j] = r; }
       }
+      for (; i >= 0; i--) { r = fma(-sH[i], r * r, r); sR[i] = r; }
     } else {
-      for (int i = ix + 1; i < L; i++) {
-        r = fma(sH[i - 1], r * r, r);
-        sR[i] = r;
+      int i = ix + 1;
+      for (; i + 7 < L; i += 8) {
+        double h[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[j] = sH[i + j - 1];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { r = fma(h[j], r * r, r); sR[i + j] = r; }
       }
+      for (; i < L; i++) { r = fma(sH[i - 1], r * r, r); sR[i] = r; }
     }
   }
   __syncthreads();

@@ -70,20 +70,95 @@ struct StepDev {
   const double *abund, *ratio, *pbar;
   const int *imol;
   const unsigned char *metal;
+  // smoothing of the Madhusudhan and Piette profiles (scipy gaussian_filter1d,
+  // mode 'nearest'): weights gw[0..2*grad], radius grad
+  const double *gw;
+  int grad;
+  double ptop, pbot;      // min / max pressure of the grid, bar
+  int pnode[8];           // piette: layers closest to top, 0.01, 0.1, 1, 3.2, 10, 32 bar, bottom
 };
+
+// Raw (unsmoothed) temperature of one layer; sets *bad for parameter sets the
+// reference rejects with ValueError (PT.py:332-335, 546-548).
+__device__ inline double pt_raw(const StepDev &a, const double *par, double p, int l, int *bad,
+                                double kappa, double g1, double g2, double alpha, double Tirr,
+                                double Tint) {
+  switch (a.pttype) {
+    case PT_LINE: {  // PT.py:687-699
+      const double tau = kappa * (p * 1e6) / a.grav;
+      const double x1 = xi_line(g1, tau), x2 = xi_line(g2, tau);
+      const double ti4 = Tint * Tint * Tint * Tint, tr4 = Tirr * Tirr * Tirr * Tirr;
+      return pow(0.75 * (ti4 * (2.0 / 3.0 + tau) + tr4 * (1 - alpha) * x1 + tr4 * alpha * x2), 0.25);
+    }
+    case PT_ISO:  // PT.py:719
+      return par[0];
+    case PT_MADHU_NOINV: {  // PT.py:539-576
+      const double a1 = par[0], a2 = par[1], p1 = par[2], p3 = par[3], T3 = par[4], p0 = a.ptop;
+      const double d31 = log(p3 / p1) / a2, d10 = log(p1 / p0) / a1;
+      const double T1 = T3 - d31 * d31, T0 = T1 - d10 * d10;
+      if (T0 < 0 || T1 < 0 || T3 < 0) *bad = 1;
+      // the reference assigns the three regions in turn: the last match wins
+      if (p >= p3 && p <= a.pbot) return T3;
+      if (p >= p1 && p < p3) { const double d = log(p / p1) / a2; return d * d + T1; }
+      if (p >= p0 && p < p1) { const double d = log(p / p0) / a1; return d * d + T0; }
+      return 0.0;
+    }
+    case PT_MADHU_INV: {  // PT.py:316-370
+      const double a1 = par[0], a2 = par[1], p1 = par[2], p2 = par[3], p3 = par[4], T3 = par[5];
+      const double p0 = a.ptop;
+      const double d32 = log(p3 / p2) / a2, d12 = log(p1 / p2) / -a2, d10 = log(p1 / p0) / a1;
+      const double T2 = T3 - d32 * d32;
+      const double T0 = T2 + d12 * d12 - d10 * d10;
+      const double T1 = T0 + d10 * d10;
+      if (T0 < 0 || T1 < 0 || T2 < 0 || T3 < 0) *bad = 1;
+      // four regions assigned in turn (PT.py:367-370): the last match wins,
+      // which matters when p3 < p2
+      if (p >= p3 && p <= a.pbot) return T3;
+      if (p >= p2 && p < p3) { const double d = log(p / p2) / a2; return d * d + T2; }
+      if (p >= p1 && p < p2) { const double d = log(p / p2) / -a2; return d * d + T2; }
+      if (p >= p0 && p < p1) { const double d = log(p / p0) / a1; return d * d + T0; }
+      return 0.0;
+    }
+    case PT_ADIABATIC: {  // PT.py:747-749
+      const double T0 = par[0], gam = par[1], p0 = pow(10.0, par[2]);
+      return T0 / (1 + (gam - 1) / gam * log(p0 / p));
+    }
+    case PT_PIETTE: {  // PT.py:786-809: node temperatures, then linear in log10 p
+      // nodes ordered top -> bottom: top, 0.01, 0.1, 1, 3.2, 10, 32 bar, bottom
+      double tn[8];
+      tn[4] = par[0];
+      tn[5] = par[0] + par[3];
+      tn[6] = tn[5] + par[2];
+      tn[7] = tn[6] + par[1];
+      tn[3] = par[0] - par[4];
+      tn[2] = tn[3] - par[5];
+      tn[1] = tn[2] - par[6];
+      tn[0] = tn[1] - par[7];
+      const double x = log10(p);
+      int s = 0;  // segment [s, s+1] with x between the nodes' log10 p
+      for (int j = 1; j < 7; j++)
+        if (x >= log10(a.pbar[a.pnode[j]])) s = j;
+      const double x0 = log10(a.pbar[a.pnode[s]]), x1 = log10(a.pbar[a.pnode[s + 1]]);
+      if (l == a.pnode[s]) return tn[s];
+      if (l == a.pnode[s + 1]) return tn[s + 1];
+      return ((x1 - x) * tn[s] + (x - x0) * tn[s + 1]) / (x1 - x0);
+    }
+  }
+  return 0.0;
+}
 
 // One workgroup per walker; lanes over layers.
 __global__ __launch_bounds__(128) void step_profiles(StepDev a, const double *params,
                                                      double *prof, int *status) {
+  extern __shared__ double sTraw[];
   const int w = blockIdx.x, L = a.L, S = a.S;
   const double *par = params + (size_t)w * a.npars;
   double *pr = prof + (size_t)w * (S + 1) * L;
   __shared__ int sBadT, sBadQ;
   if (threadIdx.x == 0) { sBadT = 0; sBadQ = 0; }
   __syncthreads();
-  // PT.py:675-699 ("line"), PT.py:704-719 ("iso")
   double kappa = 0, g1 = 0, g2 = 0, alpha = 0, Tirr = 0, Tint = a.tint;
-  if (a.pttype == PT_LINE) {
+  if (a.pttype == PT_LINE) {  // PT.py:675-688
     kappa = pow(10.0, par[0]);
     g1 = pow(10.0, par[1]);
     g2 = pow(10.0, par[2]);
@@ -97,15 +172,24 @@ __global__ __launch_bounds__(128) void step_profiles(StepDev a, const double *pa
     }
     Tirr = par[4] * teq;
   }
+  const bool smooth = a.grad > 0;
   for (int l = threadIdx.x; l < L; l += blockDim.x) {
-    double T;
-    if (a.pttype == PT_LINE) {
-      const double tau = kappa * (a.pbar[l] * 1e6) / a.grav;
-      const double x1 = xi_line(g1, tau), x2 = xi_line(g2, tau);
-      const double ti4 = Tint * Tint * Tint * Tint, tr4 = Tirr * Tirr * Tirr * Tirr;
-      T = pow(0.75 * (ti4 * (2.0 / 3.0 + tau) + tr4 * (1 - alpha) * x1 + tr4 * alpha * x2), 0.25);
-    } else {
-      T = par[0];
+    int bad = 0;
+    const double T = pt_raw(a, par, a.pbar[l], l, &bad, kappa, g1, g2, alpha, Tirr, Tint);
+    if (bad) sBadT = 1;   // the reference raises ValueError: rejected here
+    sTraw[l] = T;
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    double T = sTraw[l];
+    if (smooth) {
+      // scipy.ndimage correlate1d, symmetric kernel, edge values repeated
+      const int r = a.grad;
+      T = sTraw[l] * a.gw[r];
+      for (int j = r; j >= 1; j--) {
+        const int lo = l - j < 0 ? 0 : l - j, hi = l + j > L - 1 ? L - 1 : l + j;
+        T += (sTraw[lo] + sTraw[hi]) * a.gw[r - j];
+      }
     }
     pr[l] = T;
     // BARTfunc.py:327 (NaN compares false on both sides, as in numpy)
@@ -175,7 +259,7 @@ __global__ __launch_bounds__(64) void step_bandflux(int F, int Wfull, int soluti
 StepArgs::~StepArgs() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_abund); fr(d_ratio); fr(d_pbar); fr(d_imol); fr(d_metal); fr(d_idx0);
-  fr(d_npts); fr(d_woff); fr(d_nifilter); fr(d_istarfl); fr(d_params);
+  fr(d_npts); fr(d_woff); fr(d_gw); fr(d_nifilter); fr(d_istarfl); fr(d_params);
   fr(d_prof); fr(d_spec); fr(d_band); fr(d_status);
 }
 
@@ -191,15 +275,15 @@ void step_setup(Engine &e, const double *ptargs5, int tint_thorngren, int pttype
                 double tmin, double tmax, const double *abund, int nmolfit,
                 const int *imol, int nfilters, const int *idx0, const int *npts,
                 const double *nifilter, const double *istarfl, double rprs, int solution) {
-  if (pttype != PT_LINE && pttype != PT_ISO)
-    throw IoError{"step_setup: PT model not built yet (line and iso are)"};
+  static const int npt_of[] = {5, 1, 5, 6, 3, 8};
+  if (pttype < 0 || pttype > PT_PIETTE) throw IoError{"step_setup: unknown PT model"};
   if (!abund || nmolfit < 0 || nfilters < 0) throw IoError{"step_setup: bad arguments"};
   delete e.step;
   e.step = nullptr;
   StepArgs *s = new StepArgs();
   e.step = s;
   s->pttype = pttype;
-  s->nPT = pttype == PT_LINE ? 5 : 1;
+  s->nPT = npt_of[pttype];
   if (ptargs5) std::memcpy(s->ptargs, ptargs5, sizeof(double) * 5);
   s->tint_thorngren = tint_thorngren;
   s->tmin = tmin; s->tmax = tmax;
@@ -217,6 +301,40 @@ void step_setup(Engine &e, const double *ptargs5, int tint_thorngren, int pttype
   for (int l = 0; l < L; l++) {
     pbar[l] = e.atm.press[l] / 1e6;
     if (e.iH2 >= 0 && e.iHe >= 0) ratio[l] = abund[(size_t)l * S + e.iH2] / abund[(size_t)l * S + e.iHe];
+  }
+  // Gaussian smoothing weights exactly as scipy.ndimage.gaussian_filter1d
+  // builds them: radius int(4 sigma + 0.5), exp(-x^2 / (2 sigma^2)) / sum
+  double sigma = 0.0;
+  if (pttype == PT_MADHU_NOINV || pttype == PT_MADHU_INV) sigma = 4.0;                 // PT.py:377,583
+  if (pttype == PT_PIETTE && L > 1)                                                    // PT.py:811
+    sigma = 0.3 / std::fabs(std::log10(pbar[L - 1]) - std::log10(pbar[L - 2]));
+  std::vector<double> gw(1, 1.0);
+  s->grad = 0;
+  if (sigma > 0) {
+    const int r = (int)(4.0 * sigma + 0.5);
+    gw.assign(2 * r + 1, 0.0);
+    double sum = 0.0;
+    for (int x = -r; x <= r; x++) { gw[x + r] = std::exp(-0.5 / (sigma * sigma) * x * x); sum += gw[x + r]; }
+    for (auto &g : gw) g /= sum;
+    s->grad = r;
+  }
+  s->d_gw = up(gw.data(), gw.size());
+  s->ptop = pbar[L - 1]; s->pbot = pbar[0];
+  for (int l = 0; l < L; l++) { s->ptop = std::min(s->ptop, pbar[l]); s->pbot = std::max(s->pbot, pbar[l]); }
+  {
+    // np.argmin(|p - v|) on the top -> bottom array the reference works on
+    const double targets[6] = {0.01, 0.1, 1.0, 3.2, 10.0, 32.0};
+    auto nearest = [&](double v) {
+      int best = L - 1;
+      for (int l = L - 1; l >= 0; l--)
+        if (std::fabs(pbar[l] - v) < std::fabs(pbar[best] - v)) best = l;
+      return best;
+    };
+    int itop = L - 1, ibot = 0;
+    for (int l = L - 1; l >= 0; l--) { if (pbar[l] < pbar[itop]) itop = l; }
+    for (int l = L - 1; l >= 0; l--) { if (pbar[l] > pbar[ibot]) ibot = l; }
+    s->pnode[0] = itop; s->pnode[7] = ibot;
+    for (int j = 0; j < 6; j++) s->pnode[1 + j] = nearest(targets[j]);
   }
   s->d_abund = up(abund, (size_t)L * S);
   s->d_ratio = up(ratio.data(), L);
@@ -279,7 +397,10 @@ void step_profiles_dev(Engine &e, const double *d_params, int n, int npars, doub
   a.tmin = s->tmin; a.tmax = s->tmax;
   a.abund = s->d_abund; a.ratio = s->d_ratio; a.pbar = s->d_pbar;
   a.imol = s->d_imol; a.metal = s->d_metal;
-  hipLaunchKernelGGL(step_profiles, dim3(n), dim3(128), 0, st, a, d_params, d_prof, d_status);
+  a.gw = s->d_gw; a.grad = s->grad; a.ptop = s->ptop; a.pbot = s->pbot;
+  for (int j = 0; j < 8; j++) a.pnode[j] = s->pnode[j];
+  hipLaunchKernelGGL(step_profiles, dim3(n), dim3(128), sizeof(double) * e.L, st, a, d_params,
+                     d_prof, d_status);
   HIPCHK(hipGetLastError());
 }
 

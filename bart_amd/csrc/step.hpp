@@ -5,7 +5,7 @@
 
 namespace bartrt {
 
-enum { PT_LINE = 0, PT_ISO = 1 };
+enum { PT_LINE = 0, PT_ISO = 1, PT_MADHU_NOINV = 2, PT_MADHU_INV = 3, PT_ADIABATIC = 4, PT_PIETTE = 5 };
 
 struct StepArgs {
   int pttype = PT_LINE, nPT = 5;
@@ -18,6 +18,10 @@ struct StepArgs {
   double e_in = 0, e_fac = 0;  // reject when trapz(spec) * e_fac > e_in
   int iH2 = -1, iHe = -1;
   int nwin = 0;                // total filter samples
+  int grad = 0;                // smoothing radius (0 = none)
+  double ptop = 0, pbot = 0;
+  int pnode[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double *d_gw = nullptr;
   // device
   double *d_abund = nullptr;   // [L][S] base abundances
   double *d_ratio = nullptr;   // [L] H2/He of the base abundances

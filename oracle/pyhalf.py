@@ -130,12 +130,20 @@ def step_profiles(params, press_bar_atm, abund, species, molfit, ptargs, tmin, t
     imol = [int(np.where(species == m)[0][0]) for m in molfit]
     npt = len(params) - len(molfit)
     p = np.asarray(press_bar_atm)[::-1]
-    if pttype == "line":
-        t = pt_line(p, *params[:npt], *ptargs, t_int_type)[::-1]
-    else:
-        t = pt_iso(p, params[0])[::-1]
     L, S = abund.shape
     prof = np.zeros((S + 1, L))
+    prof[1:] = abund.T
+    try:
+        if pttype == "line":
+            t = pt_line(p, *params[:npt], *ptargs, t_int_type)[::-1]
+        else:
+            fn = {"iso": pt_iso, "madhu_noinv": pt_noinversion, "madhu_inv": pt_inversion,
+                  "adiabatic": pt_adiabatic, "piette": pt_piette}[pttype]
+            t = fn(p, *params[:npt])[::-1]
+    except ValueError:
+        # the reference logs and carries on with the previous step's profile
+        # (BARTfunc.py:322-324); a batch has no "previous", so it is rejected
+        return prof, 1
     prof[0] = t
     prof[1:] = abund.T
     if np.any(t < tmin) or np.any(t > tmax):

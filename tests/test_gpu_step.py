@@ -60,6 +60,47 @@ def test_pt_line_and_abundances_on_device(demo_case, wg, ptg):
         trm.free_memory()
 
 
+@pytest.mark.parametrize("pttype,code,key", [
+    ("iso", 1, "iso"), ("madhu_noinv", 2, "noinv"), ("madhu_inv", 3, "inv"),
+    ("adiabatic", 4, "adiab"), ("piette", 5, "piette")])
+def test_other_pt_models_on_device(demo_case, wg, ptg, pttype, code, key):
+    """Parameter draws of the golden file (the reference's own T(p) for them is
+    pinned on CPU in tests/test_golden.py); device vs the pinned restatement on
+    this case's pressure grid, including the draws the reference rejects."""
+    import torch
+    import ctypes as C
+    from bart_amd import engine, transit_module as trm
+    from oracle import pyhalf
+    c = demo_case
+    engine.init(c.tcfg)
+    try:
+        engine.step_setup(None, 0.0, 1e9, c.abund0, [], wg["demo_idx0"], wg["demo_npts"],
+                          wg["demo_nifilter"], wg["demo_istarfl"], float(wg["rprs"]), pttype=code)
+        params = np.ascontiguousarray(ptg[key + "_params"])
+        n = len(params)
+        d_par = torch.from_numpy(params).cuda()
+        d_prof = torch.empty((n, engine.nprof()), dtype=torch.float64, device="cuda")
+        d_st = torch.empty(n, dtype=torch.int32, device="cuda")
+        trm.check(trm.lib().bartrt_step_profiles_dev(
+            C.c_void_p(d_par.data_ptr()), n, params.shape[1], C.c_void_p(d_prof.data_ptr()),
+            C.c_void_p(d_st.data_ptr()), None))
+        torch.cuda.synchronize()
+        T = d_prof.cpu().numpy().reshape(n, len(c.species) + 1, -1)[:, 0]
+        st = d_st.cpu().numpy()
+        nbad = 0
+        for w in range(n):
+            ref, rst = pyhalf.step_profiles(params[w], c.press_bar, c.abund0, c.species, [], None,
+                                            0.0, 1e9, pttype=pttype)
+            assert st[w] == rst
+            if rst == 0:
+                np.testing.assert_allclose(T[w], ref[0], rtol=1e-12)
+            nbad += rst != 0
+        if key in ("noinv", "inv"):
+            assert 0 < nbad < n          # both accepted and rejected draws are covered
+    finally:
+        trm.free_memory()
+
+
 def test_bandflux_matches_reference_golden(demo_case, wg, ptg):
     """Band integration of the reference's own spectra with the reference's own
     filter weights: expected values come straight from wine.bandintegrate."""

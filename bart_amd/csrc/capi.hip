@@ -4,6 +4,7 @@
 
 #include "../../include/bartrt.h"
 #include "engine.hpp"
+#include "lbl.hpp"
 #include "step.hpp"
 
 using namespace bartrt;
@@ -182,6 +183,22 @@ int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(tau, e->d_tau, sizeof(double) * (size_t)nwave * nlayers, hipMemcpyDeviceToHost));
     if (last) HIPCHK(hipMemcpy(last, e->d_last, sizeof(int) * (size_t)nwave, hipMemcpyDeviceToHost));
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext, int nlayers, int nwave) {
+  NEED_ENGINE();
+  Engine *e = g_eng;
+  if (!e->lbl) return fail(BARTRT_EINVAL, "get_lbl_extinction: the engine was not set up with a line list");
+  if (!prof || !ext || nprof != (e->S + 1) * e->L || nlayers != e->L || nwave != e->W())
+    return fail(BARTRT_EINVAL, "get_lbl_extinction: bad shapes");
+  return guarded([&] {
+    e->ensure_walkers(1);
+    HIPCHK(hipMemcpy(e->d_prof, prof, sizeof(double) * nprof, hipMemcpyHostToDevice));
+    lbl_extinction(*e, e->d_prof, 1, e->stream);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(ext, e->lbl->d_ext, sizeof(double) * (size_t)nlayers * nwave, hipMemcpyDeviceToHost));
     return BARTRT_OK;
   });
 }

@@ -1,6 +1,7 @@
 // Host-side engine: reads the transit inputs, places the tables in HBM and
 // drives the kernels.  One engine per process (one process per GPU).
 #include "engine.hpp"
+#include "lbl.hpp"
 #include "step.hpp"
 
 #include <algorithm>
@@ -36,9 +37,10 @@ static std::vector<std::string> split_commas(const std::string &s) {
 
 Engine::~Engine() {
   delete step;
+  delete lbl;
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_dlnp); fr(d_mass);
-  fr(d_tgrid); fr(d_cia_temp); fr(d_opmol); fr(d_prof); fr(d_coef); fr(d_spec);
+  fr(d_tgrid); fr(d_cia_temp); fr(d_diam); fr(d_opmol); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_ok); fr(d_tau); fr(d_last);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
@@ -58,7 +60,39 @@ void Engine::init(int argc, const char **argv) {
   if (cfile.empty()) throw IoError{"transit_init: no '-c <configuration file>' in argv"};
   if (shard_n < 1 || shard_rank < 0 || shard_rank >= shard_n)
     throw IoError{"transit_init: bad --shard rank/nranks"};
-  cfg = read_tcfg(cfile);
+  setup(read_tcfg(cfile), shard_rank, shard_n);
+}
+
+static bool file_exists(const std::string &p) {
+  FILE *f = std::fopen(p.c_str(), "rb");
+  if (f) std::fclose(f);
+  return f != nullptr;
+}
+
+void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
+  cfg = cfg_in;
+  // An opacity file that does not exist yet is generated from the line list
+  // first (what `transit --justOpacity` does, BART.py:561-565), by a
+  // temporary line-by-line engine on the same configuration.
+  if (cfg_has(cfg, "opacityfile") && !file_exists(cfg["opacityfile"])) {
+    if (!cfg_has(cfg, "linedb"))
+      throw IoError{"cannot open opacity file '" + cfg["opacityfile"] + "' (and no 'linedb' to build it from)"};
+    if (shard_rank == 0) {
+      TCfg gcfg = cfg;
+      gcfg.erase("opacityfile");
+      Engine gen;
+      gen.device = device;
+      gen.setup(gcfg, 0, 1);
+      std::vector<double> tg;
+      const double tlow = cfg_num(cfg, "tlow", 500.0), thigh = cfg_num(cfg, "thigh", 3000.0),
+                   dt = cfg_num(cfg, "tempdelt", 100.0);
+      if (!(dt > 0) || !(thigh > tlow)) throw IoError{"transit cfg: bad tlow/thigh/tempdelt"};
+      for (int k = 0; tlow + k * dt <= thigh + 1e-9 * dt; k++) tg.push_back(tlow + k * dt);
+      lbl_write_opacity(gen, cfg["opacityfile"], tg);
+    } else {
+      throw IoError{"opacity file missing: generate it on an unsharded engine first"};
+    }
+  }
   if (!cfg_has(cfg, "atm")) throw IoError{"transit cfg: missing 'atm'"};
   if (!cfg_has(cfg, "molfile")) throw IoError{"transit cfg: missing 'molfile'"};
   std::string sol = cfg_has(cfg, "solution") ? cfg["solution"] : "eclipse";
@@ -104,8 +138,6 @@ void Engine::init(int argc, const char **argv) {
       opmol[m] = (int)(it - atm.species.begin());
     }
   } else {
-    if (cfg_has(cfg, "linedb"))
-      throw IoError{"line-by-line (TLI) extinction is not built yet: give an 'opacityfile'"};
     double lo_wn, hi_wn;
     double wnfct = cfg_num(cfg, "wnfct", 1.0), wlfct = cfg_num(cfg, "wlfct", 1e-4);
     if (cfg_has(cfg, "wnlow") && cfg_has(cfg, "wnhigh")) {
@@ -221,6 +253,11 @@ void Engine::init(int argc, const char **argv) {
   d_press = dev_upload(atm.press);
   d_dlnp = dev_upload(dlnp);
   d_mass = dev_upload(mass);
+  {
+    std::vector<double> diam(S);
+    for (int s = 0; s < S; s++) diam[s] = mol.diam[mol.find_name(atm.species[s])] * 1e-8;
+    d_diam = dev_upload(diam);
+  }
   d_tgrid = dev_upload(tgrid);
   d_opmol = dev_upload(opmol);
 
@@ -263,6 +300,7 @@ void Engine::init(int argc, const char **argv) {
     r.wgt[a] = kPI * (sh * sh - sl * sl);
     r.invmu[a] = 1.0 / std::cos(angles[a] * kPI / 180.0);
   }
+  if (!have_table && cfg_has(cfg, "linedb")) lbl_init(*this, cfg["linedb"]);
   HIPCHK(hipMalloc(&d_tau, sizeof(double) * (size_t)Wl * L));
   HIPCHK(hipMalloc(&d_last, sizeof(int) * (size_t)Wl));
   ensure_walkers(16);
@@ -297,12 +335,27 @@ void Engine::ensure_pin(size_t bytes) {
 void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
                      unsigned char *d_okp, hipStream_t st, bool want_tau) {
   if (n <= 0) return;
+  if (lbl) {
+    // line-by-line extinction needs [walkers][L][W] doubles: bounded chunks
+    const size_t per = (size_t)L * W() * sizeof(double);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)2 << 30) / per));
+    const int nprof = (S + 1) * L;
+    for (int off = 0; off < n; off += chunk) {
+      const int m = std::min(chunk, n - off);
+      lbl_extinction(*this, d_prof_in + (size_t)off * nprof, m, st);
+      run_chunk(d_prof_in + (size_t)off * nprof, m, d_spec_out + (size_t)off * W(),
+                d_okp ? d_okp + off : d_ok + (off < cap_walkers ? off : 0), st, want_tau, lbl->d_ext);
+    }
+    return;
+  }
+  run_chunk(d_prof_in, n, d_spec_out, d_okp, st, want_tau, nullptr);
+}
+
+void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
+                       unsigned char *d_okp, hipStream_t st, bool want_tau, const double *d_ext) {
   // coefficient workspaces are sized by cap_walkers; the caller's profile and
   // spectrum buffers are used in place
-  if (n > cap_walkers) {
-    // grow coef/idx only (d_prof/d_spec of the caller are separate buffers)
-    ensure_walkers(n);
-  }
+  if (n > cap_walkers) ensure_walkers(n);
   PrepArgs pa = prep;
   pa.nwalkers = n;
   pa.prof = d_prof_in;
@@ -316,6 +369,7 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
   RtArgs r = rt;
   r.nwalkers = n;
   r.coef = d_coef; r.idx = d_idx; r.kstop = d_kstop;
+  r.ext = d_ext;
   r.cloud_on = has_cloud;
   r.toomuch = toomuch;
   r.spec = d_spec_out;

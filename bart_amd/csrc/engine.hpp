@@ -14,6 +14,7 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st);
 
 struct StepArgs;  // converters around the engine (step.hip)
+struct Lbl;       // line-by-line extinction (lbl.hip)
 
 struct Engine {
   // configuration
@@ -32,7 +33,7 @@ struct Engine {
   // device-resident inputs
   double *d_kappa = nullptr, *d_cia = nullptr, *d_wn = nullptr, *d_wn_full = nullptr;
   double *d_press = nullptr, *d_dlnp = nullptr, *d_mass = nullptr, *d_tgrid = nullptr;
-  double *d_cia_temp = nullptr;
+  double *d_cia_temp = nullptr, *d_diam = nullptr;
   int *d_opmol = nullptr;
   PrepArgs prep{};  // static part filled at init
   RtArgs rt{};
@@ -53,14 +54,18 @@ struct Engine {
   int ev_used = 0;
   // per-step converters
   StepArgs *step = nullptr;
+  Lbl *lbl = nullptr;
 
   ~Engine();
   void init(int argc, const char **argv);
+  void setup(const TCfg &cfg_in, int shard_rank, int shard_n);
   void ensure_walkers(int n);
   void ensure_pin(size_t bytes);
   // d_prof_in -> d_spec_out ([n][W]); records events when timing
   void run_dev(const double *d_prof_in, int n, double *d_spec_out, unsigned char *d_okp,
                hipStream_t st, bool want_tau);
+  void run_chunk(const double *d_prof_in, int n, double *d_spec_out, unsigned char *d_okp,
+                 hipStream_t st, bool want_tau, const double *d_ext);
 };
 
 struct HipError {

@@ -220,4 +220,77 @@ Cia read_cia(const std::string &path) {
   return c;
 }
 
+namespace {
+struct BinReader {
+  FILE *fp;
+  const std::string &path;
+  template <class T>
+  T get() {
+    T v;
+    if (std::fread(&v, sizeof(T), 1, fp) != 1) throw IoError{"TLI file '" + path + "' is truncated"};
+    return v;
+  }
+  std::string str() {
+    unsigned short n = get<unsigned short>();
+    std::string s(n, '\0');
+    if (n && std::fread(&s[0], 1, n, fp) != n) throw IoError{"TLI file '" + path + "' is truncated"};
+    return s;
+  }
+  template <class T>
+  void arr(std::vector<T> &v, size_t n) {
+    v.resize(n);
+    if (n && std::fread(v.data(), sizeof(T), n, fp) != n)
+      throw IoError{"TLI file '" + path + "' is truncated"};
+  }
+};
+}  // namespace
+
+Tli read_tli(const std::string &path) {
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) throw IoError{"cannot open TLI file '" + path + "'"};
+  Tli t;
+  try {
+    BinReader r{fp, path};
+    if (r.get<int>() != 0x494C54FF) throw IoError{"'" + path + "' is not a TLI file (bad magic)"};
+    r.get<unsigned short>(); r.get<unsigned short>(); r.get<unsigned short>();
+    t.wn_lo = r.get<double>();
+    t.wn_hi = r.get<double>();
+    unsigned short ndb = r.get<unsigned short>();
+    t.db.resize(ndb);
+    for (auto &d : t.db) {
+      d.name = r.str();
+      d.molecule = r.str();
+      unsigned short nt = r.get<unsigned short>(), ni = r.get<unsigned short>();
+      if (nt < 1 || ni < 1) throw IoError{"TLI file '" + path + "': empty database header"};
+      r.arr(d.temp, nt);
+      d.iso.resize(ni);
+      for (auto &i : d.iso) {
+        i.name = r.str();
+        i.mass = r.get<double>();
+        i.ratio = r.get<double>();
+        r.arr(i.Z, nt);
+      }
+    }
+    for (auto &d : t.db) {
+      long long n = r.get<long long>();
+      if (n < 0 || n > (1LL << 33)) throw IoError{"TLI file '" + path + "': bad transition count"};
+      r.arr(d.wn, (size_t)n);
+      r.arr(d.isoid, (size_t)n);
+      r.arr(d.elow, (size_t)n);
+      r.arr(d.gf, (size_t)n);
+      for (size_t k = 0; k < (size_t)n; k++) {
+        if (d.isoid[k] < 0 || (size_t)d.isoid[k] >= d.iso.size())
+          throw IoError{"TLI file '" + path + "': isotope index out of range"};
+        if (k && d.wn[k] < d.wn[k - 1])
+          throw IoError{"TLI file '" + path + "': transitions are not sorted by wavenumber"};
+      }
+    }
+  } catch (...) {
+    std::fclose(fp);
+    throw;
+  }
+  std::fclose(fp);
+  return t;
+}
+
 }  // namespace bartrt

@@ -59,4 +59,25 @@ struct Cia {
 };
 Cia read_cia(const std::string &path);
 
+// Transit-line-information (TLI) file: per database (= one molecule) its
+// isotopes with tabulated partition functions, then the transitions sorted by
+// wavenumber (per-line fields of doc/BART_user_manual.tex:449-455).
+struct TliIso {
+  std::string name;
+  double mass = 0, ratio = 1;
+  std::vector<double> Z;  // [ntemp]
+};
+struct TliDb {
+  std::string name, molecule;
+  std::vector<double> temp;
+  std::vector<TliIso> iso;
+  std::vector<double> wn, elow, gf;  // [nlines], wn ascending
+  std::vector<short> isoid;          // index into iso
+};
+struct Tli {
+  double wn_lo = 0, wn_hi = 0;
+  std::vector<TliDb> db;
+};
+Tli read_tli(const std::string &path);
+
 }  // namespace bartrt

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     const int *ix = sI + k * NI;
     const int l = L - 1 - k;
     double e = c[2 + 2 * M + 2 * C] * nu4;
+    if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
     const double *kb = p.kappa + ((size_t)l * Nt + ix[0]) * MW + ii;
 #pragma unroll
     for (int m = 0; m < (MT >= 0 ? MT : kMaxMol); m++) {
@@ -435,7 +436,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const char *e = std::getenv("BARTRT_KERNEL");  // "generic" forces the fallback (A/B runs)
     return e && std::string(e) == "generic";
   }();
-  if (!generic_only && a.A == 5) {
+  if (!generic_only && a.A == 5 && !a.ext) {
 #define BARTRT_FAST(MM, CC)                                                        \
   if (a.M == MM && a.C == CC) {                                                    \
     hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC>), dim3(nblocks), dim3(block), sh, st, a); \

@@ -61,6 +61,7 @@ struct RtArgs {
   int L, M, Nt, C, A, W, nwalkers, ntiles;
   const double *kappa;     // [L][Nt][M][W]
   const double *cia;       // [planes][W]
+  const double *ext;       // optional line-by-line extinction [nw][L][W] (atm layer order)
   const double *wn;        // [W]
   const double *coef;
   const int *idx;

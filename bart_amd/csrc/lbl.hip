@@ -1,0 +1,392 @@
+// Line-by-line Voigt extinction on the GPU (gather form: one lane per output
+// wavenumber, the tile's window of the sorted line list staged through LDS in
+// chunks; no atomics, fixed summation order).
+//
+// Per line j of isotope i at a layer state (T, p, composition):
+//   S_j   = SIGCTE gf_j scale_i exp(-EXPCTE E_j / T) (1 - exp(-EXPCTE nu_j / T))
+//   aD    = nu_j sqrt(2 ln2 k T / m_i) / c        (Doppler HWHM, scripts/broadening.py:143)
+//   aL    = sqrt(2) / (c sqrt(pi k T)) p sum_{c in H2,He} q_c ((d+d_c)/2)^2 sqrt(1/m_i + 1/m_c)
+//                                                 (Lorentz HWHM, scripts/broadening.py:121-127)
+//   e(nu) += S_j sqrt(ln2/pi)/aD  K(sqrt(ln2)|nu-nu_j|/aD, sqrt(ln2) aL/aD)
+// for |nu - nu_j| <= nwidth max(aD, aL) and S_j >= ethresh max_j S_j (per state
+// and database).  scale_i = n_i / Z_i(T) for extinction (cm-1) or
+// ratio_i / (Z_i(T) m_mol AMU) for opacity per gram of the molecule (cm2/g).
+#include "lbl.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "engine.hpp"
+#include "voigt_coef.hpp"
+
+namespace bartrt {
+
+constexpr double kSIGCTE = 8.852821681767784e-13;  // pi e^2 / (m_e c^2), cm
+constexpr double kEXPCTE = kH * kLS / kKB;          // h c / k_B, cm K
+constexpr double kSqrtLn2 = 0.8325546111576977;
+constexpr double kInvSqrtPi = 0.5641895835477563;
+
+// Re w(x + i y), x >= 0, y > 0.
+__device__ inline double voigt_k(double x, double y) {
+  const double r2 = x * x + y * y;
+  if (r2 >= 64.0) {
+    // Laplace continued fraction, 4 (|z| >= 15) or 8 levels
+    const int K = r2 >= 225.0 ? 4 : 8;
+    double fr = x, fi = y;
+    for (int k = K; k >= 1; k--) {
+      const double s = (0.5 * k) / (fr * fr + fi * fi);
+      const double nr = x - s * fr, ni = y + s * fi;
+      fr = nr; fi = ni;
+    }
+    return kInvSqrtPi * fi / (fr * fr + fi * fi);
+  }
+  // Weideman N = 40: Z = ((L - y) + i x) / ((L + y) - i x)
+  const double ar = kWeidL - y, br = kWeidL + y;
+  const double den = 1.0 / (br * br + x * x);
+  const double Zr = (ar * br - x * x) * den, Zi = (x * br + ar * x) * den;
+  double pr = kWeidA[0], pi = 0.0;
+#pragma unroll 8
+  for (int k = 1; k < kWeidN; k++) {
+    const double t = fma(pr, Zr, -pi * Zi) + kWeidA[k];
+    pi = fma(pr, Zi, pi * Zr);
+    pr = t;
+  }
+  // 1/(L - iz) = (br + i x) den ; its square
+  const double qr = br * den, qi = x * den;
+  const double q2r = qr * qr - qi * qi, q2i = 2.0 * qr * qi;
+  return 2.0 * (pr * q2r - pi * q2i) + kInvSqrtPi * qr;
+}
+
+struct StateArgs {
+  int L, S, nstate, table_mode, iH2, iHe, Nt, layer0;
+  const double *prof;    // extinction mode: [nw][(S+1)][L]
+  const double *abund0;  // table mode: base abundances [L][S]
+  const double *press;   // [L] barye
+  const double *mass;    // [S] amu
+  const double *diam;    // [S] cm
+  const double *tgrid;   // table mode temperatures
+  double *state;         // [nstate][2 + 3*niso]: T, unused, then (dopfac, alphaL, scale) per isotope
+};
+
+// One workgroup per state, lanes over isotopes.
+__global__ void lbl_states(StateArgs a, LblDev d) {
+  const int st = blockIdx.x, L = a.L, S = a.S;
+  double T, p;
+  const double *q;  // mixing ratios with stride qs
+  size_t qs;
+  int l;
+  if (a.table_mode) {
+    l = a.layer0 + st / a.Nt;
+    T = a.tgrid[st % a.Nt];
+    q = a.abund0 + (size_t)l * S; qs = 1;
+  } else {
+    const int w = st / L;
+    l = st % L;
+    const double *pr = a.prof + (size_t)w * (S + 1) * L;
+    T = pr[l];
+    q = pr + L + l; qs = L;
+  }
+  p = a.press[l];
+  double *out = a.state + (size_t)st * (2 + 3 * d.niso);
+  if (threadIdx.x == 0) { out[0] = T; out[1] = p; }
+  const int i = threadIdx.x;
+  if (i >= d.niso) return;
+  const int g = d.iso_group[i];
+  const double mi = d.iso_mass[i] * kAMU;
+  const double dop = sqrt(2.0 * 0.6931471805599453 * kKB * T / mi) / kLS;
+  double sum = 0.0;
+  const double dm = d.gdiam[g];
+  if (a.iH2 >= 0) {
+    const double dd = 0.5 * (dm + a.diam[a.iH2]);
+    sum += q[(size_t)a.iH2 * qs] * dd * dd * sqrt(1.0 / mi + 1.0 / (a.mass[a.iH2] * kAMU));
+  }
+  if (a.iHe >= 0) {
+    const double dd = 0.5 * (dm + a.diam[a.iHe]);
+    sum += q[(size_t)a.iHe * qs] * dd * dd * sqrt(1.0 / mi + 1.0 / (a.mass[a.iHe] * kAMU));
+  }
+  const double aL = sqrt(2.0) / (kLS * sqrt(kPI * kKB * T)) * p * sum;
+  // partition function: linear in T on the database grid, clamped
+  const double *zt = d.ztemp + d.iso_toff[i], *zz = d.ztab + d.iso_zoff[i];
+  const int nt = d.iso_nt[i];
+  double Z;
+  if (nt == 1 || T <= zt[0]) Z = zz[0];
+  else if (T >= zt[nt - 1]) Z = zz[nt - 1];
+  else {
+    int j = 0;
+    while (j < nt - 2 && zt[j + 1] <= T) j++;
+    const double f = (T - zt[j]) / (zt[j + 1] - zt[j]);
+    Z = zz[j] * (1.0 - f) + zz[j + 1] * f;
+  }
+  double scale;
+  if (a.table_mode) {
+    const int sp = d.gspecies[g];
+    scale = d.iso_ratio[i] / (Z * a.mass[sp] * kAMU);
+  } else {
+    const double nd = p / (kKB * T);
+    scale = d.iso_ratio[i] * q[(size_t)d.gspecies[g] * qs] * nd / Z;
+  }
+  out[2 + 3 * i] = dop;
+  out[3 + 3 * i] = aL;
+  out[4 + 3 * i] = kSIGCTE * scale;
+}
+
+__device__ inline double line_strength(double gf, double elow, double nu0, double scale, double T) {
+  return gf * scale * exp(-kEXPCTE * elow / T) * (1.0 - exp(-kEXPCTE * nu0 / T));
+}
+
+// max line strength per (state, group); positive doubles order like their bits
+__global__ __launch_bounds__(256) void lbl_smax(LblDev d, const double *state, double *smax,
+                                                int nstate) {
+  const int st = blockIdx.y, g = blockIdx.z;
+  const double *sv = state + (size_t)st * (2 + 3 * d.niso);
+  const double T = sv[0];
+  double m = 0.0;
+  for (long j = d.gstart[g] + blockIdx.x * blockDim.x + threadIdx.x; j < d.gend[g];
+       j += (long)gridDim.x * blockDim.x) {
+    const int i = d.liso[j];
+    m = fmax(m, line_strength(d.gf[j], d.elow[j], d.nu0[j], sv[4 + 3 * i], T));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.0)
+    atomicMax(reinterpret_cast<unsigned long long *>(smax + (size_t)st * d.ngroup + g),
+              (unsigned long long)__double_as_longlong(m));
+}
+
+struct AccArgs {
+  int W, nstate, per_group;   // per_group: out[state][g][W] else out[state][W] summed over groups
+  const double *wn;
+  const double *state, *smax;
+  double *out;
+};
+
+__global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
+  __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
+  __shared__ long s_j0, s_j1;
+  const int st = blockIdx.y;
+  const int tile0 = blockIdx.x * 256;
+  const int i = tile0 + threadIdx.x;
+  const bool valid = i < a.W;
+  const double nu = a.wn[valid ? i : a.W - 1];
+  const double nu_a = a.wn[tile0], nu_b = a.wn[min(tile0 + 255, a.W - 1)];
+  const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
+  const double T = sv[0];
+  const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
+  double acc = 0.0;
+  for (int g = g_lo; g < g_hi; g++) {
+    if (threadIdx.x == 0) {
+      double cmax = 0.0;
+      for (int k = 0; k < d.niso; k++)
+        if (d.iso_group[k] == g)
+          cmax = fmax(cmax, d.nwidth * fmax(sv[3 + 3 * k], (nu_b + 1.0) * sv[2 + 3 * k] * 1.001));
+      // window of the sorted list: nu0 in [nu_a - cmax', nu_b + cmax'] (cmax' a little
+      // generous: the exact per-line cut is applied below)
+      const double lo = nu_a - cmax * 1.01, hi = nu_b + cmax * 1.01;
+      long a0 = d.gstart[g], a1 = d.gend[g];
+      while (a0 < a1) { long m = (a0 + a1) >> 1; if (d.nu0[m] < lo) a0 = m + 1; else a1 = m; }
+      s_j0 = a0;
+      a1 = d.gend[g];
+      while (a0 < a1) { long m = (a0 + a1) >> 1; if (d.nu0[m] <= hi) a0 = m + 1; else a1 = m; }
+      s_j1 = a0;
+    }
+    __syncthreads();
+    const long j0 = s_j0, j1 = s_j1;
+    const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
+    for (long base = j0; base < j1; base += 256) {
+      const long j = base + threadIdx.x;
+      double cut = -1.0, n0 = 0.0, amp = 0.0, xs = 0.0, yy = 1.0;
+      if (j < j1) {
+        const int k = d.liso[j];
+        n0 = d.nu0[j];
+        const double S = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * k], T);
+        if (S >= thresh && S > 0.0) {
+          const double aD = n0 * sv[2 + 3 * k], aL = sv[3 + 3 * k];
+          cut = d.nwidth * fmax(aD, aL);
+          xs = kSqrtLn2 / aD;
+          amp = S * kSqrtLn2 * kInvSqrtPi / aD;
+          yy = aL * xs;
+        }
+      }
+      s_nu0[threadIdx.x] = n0; s_amp[threadIdx.x] = amp; s_xs[threadIdx.x] = xs;
+      s_y[threadIdx.x] = yy; s_cut[threadIdx.x] = cut;
+      __syncthreads();
+      const int cnt = (int)min((long)256, j1 - base);
+      for (int t = 0; t < cnt; t++) {
+        const double dv = fabs(nu - s_nu0[t]);
+        if (dv <= s_cut[t]) acc += s_amp[t] * voigt_k(dv * s_xs[t], s_y[t]);
+      }
+      __syncthreads();
+    }
+  }
+  if (valid) {
+    if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + i] = acc;
+    else a.out[(size_t)st * a.W + i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+Lbl::~Lbl() {
+  auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  fr(d_nu0); fr(d_elow); fr(d_gf); fr(d_ztab); fr(d_ztemp); fr(d_liso);
+  fr(d_state); fr(d_smax); fr(d_ext);
+}
+
+template <class T>
+static T *upv(const std::vector<T> &v) {
+  T *d = nullptr;
+  HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+void lbl_init(Engine &e, const std::string &path) {
+  Lbl *b = new Lbl();
+  delete e.lbl;
+  e.lbl = b;
+  b->tli = read_tli(path);
+  Tli &t = b->tli;
+  if (t.db.empty()) throw IoError{"TLI file '" + path + "' holds no database"};
+  if ((int)t.db.size() > kMaxGroup) throw IoError{"TLI file: too many databases"};
+  LblDev &d = b->dev;
+  std::vector<double> nu0, elow, gf, ztab, ztemp;
+  std::vector<int> liso;
+  d.ngroup = (int)t.db.size();
+  d.niso = 0;
+  for (int g = 0; g < d.ngroup; g++) {
+    TliDb &db = t.db[g];
+    auto it = std::find(e.atm.species.begin(), e.atm.species.end(), db.molecule);
+    if (it == e.atm.species.end())
+      throw IoError{"TLI database molecule '" + db.molecule + "' is not in the atmosphere file"};
+    d.gspecies[g] = (int)(it - e.atm.species.begin());
+    int mj = e.mol.find_name(db.molecule);
+    d.gdiam[g] = e.mol.diam[mj] * 1e-8;
+    const int toff = (int)ztemp.size();
+    ztemp.insert(ztemp.end(), db.temp.begin(), db.temp.end());
+    const int iso0 = d.niso;
+    for (auto &iso : db.iso) {
+      if (d.niso >= kMaxIso) throw IoError{"TLI file: too many isotopes"};
+      const int k = d.niso++;
+      d.iso_group[k] = g;
+      d.iso_mass[k] = iso.mass;
+      d.iso_ratio[k] = iso.ratio;
+      d.iso_toff[k] = toff;
+      d.iso_nt[k] = (int)db.temp.size();
+      d.iso_zoff[k] = (int)ztab.size();
+      ztab.insert(ztab.end(), iso.Z.begin(), iso.Z.end());
+    }
+    d.gstart[g] = (long)nu0.size();
+    // keep only transitions that can reach the spectral range (generous margin)
+    const double lo = e.wn_full.front() - 500.0, hi = e.wn_full.back() + 500.0;
+    for (size_t k = 0; k < db.wn.size(); k++) {
+      if (db.wn[k] < lo || db.wn[k] > hi) continue;
+      nu0.push_back(db.wn[k]); elow.push_back(db.elow[k]); gf.push_back(db.gf[k]);
+      liso.push_back(iso0 + db.isoid[k]);
+    }
+    d.gend[g] = (long)nu0.size();
+  }
+  b->nlines = (long)nu0.size();
+  b->d_nu0 = upv(nu0); b->d_elow = upv(elow); b->d_gf = upv(gf); b->d_liso = upv(liso);
+  b->d_ztab = upv(ztab); b->d_ztemp = upv(ztemp);
+  d.nu0 = b->d_nu0; d.elow = b->d_elow; d.gf = b->d_gf; d.liso = b->d_liso;
+  d.ztab = b->d_ztab; d.ztemp = b->d_ztemp;
+  d.nwidth = cfg_num(e.cfg, "nwidth", 20.0);
+  d.ethresh = cfg_num(e.cfg, "ethresh", 1e-6);
+  // free the host copy of the big arrays
+  for (auto &db : t.db) { db.wn.clear(); db.wn.shrink_to_fit(); db.elow.clear(); db.elow.shrink_to_fit();
+                          db.gf.clear(); db.gf.shrink_to_fit(); db.isoid.clear(); db.isoid.shrink_to_fit(); }
+}
+
+static void ensure_states(Engine &e, long nstate, bool need_ext) {
+  Lbl *b = e.lbl;
+  if (nstate <= b->cap_state && (!need_ext || b->d_ext)) return;
+  HIPCHK(hipDeviceSynchronize());
+  auto re = [&](double *&p, size_t n) {
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double)));
+  };
+  long cap = std::max(nstate, b->cap_state);
+  re(b->d_state, (size_t)cap * (2 + 3 * b->dev.niso));
+  re(b->d_smax, (size_t)cap * b->dev.ngroup);
+  if (need_ext) re(b->d_ext, (size_t)cap * e.W());
+  b->cap_state = cap;
+}
+
+static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
+  Lbl *b = e.lbl;
+  const LblDev &d = b->dev;
+  sa.L = e.L; sa.S = e.S; sa.iH2 = e.iH2; sa.iHe = e.iHe;
+  sa.press = e.d_press; sa.mass = e.d_mass; sa.diam = e.d_diam;
+  sa.state = b->d_state;
+  hipLaunchKernelGGL(lbl_states, dim3(sa.nstate), dim3(64), 0, st, sa, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(b->d_smax, 0, sizeof(double) * (size_t)sa.nstate * d.ngroup, st));
+  const int nb = (int)std::max<long>(1, std::min<long>(64, b->nlines / 4096 + 1));
+  hipLaunchKernelGGL(lbl_smax, dim3(nb, sa.nstate, d.ngroup), dim3(256), 0, st, d, b->d_state,
+                     b->d_smax, sa.nstate);
+  HIPCHK(hipGetLastError());
+  aa.W = e.W(); aa.nstate = sa.nstate; aa.wn = e.d_wn; aa.state = b->d_state; aa.smax = b->d_smax;
+  const int ntile = (aa.W + 255) / 256;
+  hipLaunchKernelGGL(lbl_accumulate, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
+                     0, st, d, aa);
+  HIPCHK(hipGetLastError());
+}
+
+void lbl_extinction(Engine &e, const double *d_prof, int nwalkers, hipStream_t st) {
+  const long nstate = (long)nwalkers * e.L;
+  ensure_states(e, nstate, true);
+  StateArgs sa{};
+  sa.nstate = (int)nstate; sa.table_mode = 0; sa.prof = d_prof;
+  AccArgs aa{};
+  aa.per_group = 0; aa.out = e.lbl->d_ext;
+  run_states(e, sa, aa, st);
+}
+
+void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<double> &tgrid) {
+  Lbl *b = e.lbl;
+  const int Nt = (int)tgrid.size(), L = e.L, M = b->dev.ngroup, W = e.W();
+  if (e.lo != 0 || e.hi != e.Wfull) throw IoError{"the opacity grid is generated on an unsharded engine"};
+  double *d_tg = nullptr, *d_ab = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_tg, sizeof(double) * Nt));
+  HIPCHK(hipMemcpy(d_tg, tgrid.data(), sizeof(double) * Nt, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&d_ab, sizeof(double) * e.atm.abund.size()));
+  HIPCHK(hipMemcpy(d_ab, e.atm.abund.data(), sizeof(double) * e.atm.abund.size(), hipMemcpyHostToDevice));
+  FILE *fp = std::fopen(path.c_str(), "wb");
+  if (!fp) { (void)hipFree(d_tg); (void)hipFree(d_ab); throw IoError{"cannot create opacity file '" + path + "'"}; }
+  long dims[4] = {M, Nt, L, W};
+  std::fwrite(dims, sizeof(long), 4, fp);
+  std::vector<int> ids(M);
+  for (int g = 0; g < M; g++) ids[g] = e.mol.id[e.mol.find_name(b->tli.db[g].molecule)];
+  std::fwrite(ids.data(), sizeof(int), M, fp);
+  std::fwrite(tgrid.data(), sizeof(double), Nt, fp);
+  std::fwrite(e.atm.press.data(), sizeof(double), L, fp);
+  std::fwrite(e.wn_full.data(), sizeof(double), W, fp);
+  // layers in slabs so the device buffer stays bounded: [nl][Nt][M][W]
+  const int slab = std::max(1, std::min(L, (int)((size_t)256 * 1024 * 1024 / ((size_t)Nt * M * W * 8) + 1)));
+  std::vector<double> host((size_t)slab * Nt * M * W);
+  HIPCHK(hipMalloc(&d_out, host.size() * sizeof(double)));
+  ensure_states(e, (long)slab * Nt, false);
+  try {
+    for (int l0 = 0; l0 < L; l0 += slab) {
+      const int nl = std::min(slab, L - l0);
+      StateArgs sa{};
+      sa.nstate = nl * Nt; sa.table_mode = 1; sa.Nt = Nt; sa.tgrid = d_tg;
+      sa.abund0 = d_ab; sa.layer0 = l0;
+      AccArgs aa{};
+      aa.per_group = 1; aa.out = d_out;
+      run_states(e, sa, aa, e.stream);
+      HIPCHK(hipStreamSynchronize(e.stream));
+      HIPCHK(hipMemcpy(host.data(), d_out, sizeof(double) * (size_t)nl * Nt * M * W, hipMemcpyDeviceToHost));
+      std::fwrite(host.data(), sizeof(double), (size_t)nl * Nt * M * W, fp);
+    }
+  } catch (...) {
+    std::fclose(fp); std::remove(path.c_str());
+    (void)hipFree(d_tg); (void)hipFree(d_ab); (void)hipFree(d_out);
+    throw;
+  }
+  std::fclose(fp);
+  (void)hipFree(d_tg); (void)hipFree(d_ab); (void)hipFree(d_out);
+}
+
+}  // namespace bartrt

@@ -1,0 +1,57 @@
+// Line-by-line (Voigt) extinction from a TLI line list: the on-the-fly path
+// the reference takes when no opacity file is configured
+// (doc/BART_user_manual/BART_user_manual.tex:776-777) and the generator of the
+// opacity grid (`transit --justOpacity`, BART.py:561-565).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "io.hpp"
+
+namespace bartrt {
+
+struct Engine;
+
+constexpr int kMaxIso = 64;    // isotopes over all databases
+constexpr int kMaxGroup = 16;  // databases (molecules) in the TLI
+
+struct LblDev {
+  // line arrays, all groups concatenated, ascending wavenumber inside a group
+  const double *nu0, *elow, *gf;
+  const int *liso;               // global isotope index per line
+  int ngroup, niso;
+  long gstart[kMaxGroup], gend[kMaxGroup];
+  int gspecies[kMaxGroup];       // species index of the group's molecule
+  double gdiam[kMaxGroup];       // collision diameter of the molecule, cm
+  int iso_group[kMaxIso];
+  double iso_mass[kMaxIso], iso_ratio[kMaxIso];
+  int iso_zoff[kMaxIso], iso_nt[kMaxIso], iso_toff[kMaxIso];
+  const double *ztab, *ztemp;    // concatenated partition functions / their temperatures
+  double nwidth, ethresh;
+};
+
+struct Lbl {
+  Tli tli;
+  LblDev dev{};
+  long nlines = 0;
+  double *d_nu0 = nullptr, *d_elow = nullptr, *d_gf = nullptr, *d_ztab = nullptr, *d_ztemp = nullptr;
+  int *d_liso = nullptr;
+  // per-call workspaces
+  double *d_state = nullptr;     // [nstate][3*niso + 2]
+  double *d_smax = nullptr;      // [nstate][ngroup]
+  double *d_ext = nullptr;       // [nstate][W] (extinction mode)
+  long cap_state = 0;
+  ~Lbl();
+};
+
+// Reads the TLI named by the cfg's `linedb`, uploads the lines.
+void lbl_init(Engine &e, const std::string &path);
+// ext[w][l][W_local] (atm layer order) for nwalkers profiles, into e.lbl->d_ext.
+void lbl_extinction(Engine &e, const double *d_prof, int nwalkers, hipStream_t st);
+// Computes o[L][Nt][M][W] for the cfg's tlow/thigh/tempdelt and writes the
+// opacity file (molecule order = TLI database order).
+void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<double> &tgrid);
+
+}  // namespace bartrt

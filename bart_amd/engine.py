@@ -79,6 +79,16 @@ def get_tau():
     return tau, last
 
 
+def lbl_extinction(profile: np.ndarray) -> np.ndarray:
+    """Line-by-line extinction [L, W_local] (cm-1, atm layer order) of one profile."""
+    prof = np.ascontiguousarray(profile, np.double).ravel()
+    lo, hi = local_range()
+    ext = np.zeros((nlayers(), hi - lo))
+    _check(trm.lib().bartrt_get_lbl_extinction(_ptr(prof), prof.size, _ptr(ext), ext.shape[0],
+                                               ext.shape[1]))
+    return ext
+
+
 # ---- device-resident (torch tensors own the memory) ----------------------
 def _stream_ptr(stream=None):
     import torch

@@ -323,3 +323,62 @@ def blackbody_kurucz(path: str, temps=(5500.0, 5750.0, 6000.0, 6250.0), loggs=(4
         for gi, _ in enumerate(loggs):
             models.append(b / 4.0 * (1.0 + 0.01 * gi))
     write_kurucz(path, temps, loggs, wl_nm, np.array(models))
+
+
+# ---------------------------------------------------------------------------
+TLI_MAGIC = 0x494C54FF   # bytes FF 'T' 'L' 'I'
+
+
+def write_tli(path: str, databases, wn_lo: float, wn_hi: float) -> None:
+    """Transit-line-information file (layout of DESIGN.md C12; unverified against
+    pylineread).  ``databases`` = list of dicts {name, molecule, temps[nt],
+    isotopes: [{name, mass, ratio, Z[nt]}], wn[n], iso[n] (index within the
+    database), elow[n] (cm-1), gf[n]}; lines are stored sorted by wavenumber
+    within each database.  Binary, native endian:
+      int32 magic; uint16 x3 versions; f64 wn_lo, wn_hi; uint16 ndb;
+      per database: str name, str molecule, uint16 ntemp, uint16 niso,
+        f64 temp[ntemp], per isotope: str name, f64 mass, f64 ratio, f64 Z[ntemp];
+      per database: int64 nlines, f64 wn[n], int16 isoid[n], f64 elow[n], f64 gf[n]
+    (str = uint16 length + bytes)."""
+    def s(b):
+        b = b.encode()
+        return struct.pack("=H", len(b)) + b
+    with open(path, "wb") as f:
+        f.write(struct.pack("=i3H2dH", TLI_MAGIC, 6, 7, 0, wn_lo, wn_hi, len(databases)))
+        for db in databases:
+            t = np.asarray(db["temps"], np.float64)
+            f.write(s(db["name"]) + s(db["molecule"]))
+            f.write(struct.pack("=HH", len(t), len(db["isotopes"])))
+            f.write(t.tobytes())
+            for iso in db["isotopes"]:
+                f.write(s(iso["name"]) + struct.pack("=dd", iso["mass"], iso["ratio"]))
+                f.write(np.asarray(iso["Z"], np.float64).tobytes())
+        for db in databases:
+            o = np.argsort(db["wn"], kind="stable")
+            f.write(struct.pack("=q", len(o)))
+            f.write(np.asarray(db["wn"], np.float64)[o].tobytes())
+            f.write(np.asarray(db["iso"], np.int16)[o].tobytes())
+            f.write(np.asarray(db["elow"], np.float64)[o].tobytes())
+            f.write(np.asarray(db["gf"], np.float64)[o].tobytes())
+
+
+def synth_linelist(molecules, nlines, wn_lo, wn_hi, seed=20260104, niso=2):
+    """Seeded line lists: centres U(wn_lo, wn_hi),
+    log10 gf ~ N(-6, 2) clipped, E_low ~ U(0, 8000) cm-1, `niso` isotopologues
+    per molecule with partition functions ~ T^1.5."""
+    temps = np.arange(100.0, 3501.0, 100.0)
+    dbs = []
+    for k, mol in enumerate(molecules):
+        rng = np.random.default_rng([seed + 3, k])
+        mass = MOLECULES[mol][1]
+        isos = [{"name": "%s_%d" % (mol, i + 1), "mass": mass + i,
+                 "ratio": (0.98 if i == 0 else 0.02 / max(niso - 1, 1)) if niso > 1 else 1.0,
+                 "Z": 50.0 * (1 + 0.1 * i) * (temps / 296.0) ** 1.5} for i in range(niso)]
+        n = int(nlines)
+        dbs.append({"name": "synth_%s" % mol, "molecule": mol, "temps": temps, "isotopes": isos,
+                    "wn": rng.uniform(wn_lo, wn_hi, n),
+                    "iso": rng.choice(niso, n, p=[0.8] + [0.2 / max(niso - 1, 1)] * (niso - 1))
+                    if niso > 1 else np.zeros(n, int),
+                    "elow": rng.uniform(0.0, 8000.0, n),
+                    "gf": 10 ** np.clip(rng.normal(-6.0, 2.0, n), -12, -1)})
+    return dbs

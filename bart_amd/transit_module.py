@@ -78,6 +78,7 @@ def lib():
         L.bartrt_get_species.argtypes = [C.c_char_p, i]
         L.bartrt_get_pressure.argtypes = [p, i]
         L.bartrt_get_tau.argtypes = [p, p, i, i]
+        L.bartrt_get_lbl_extinction.argtypes = [p, i, p, i, i]
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
         L.bartrt_algorithmic_bytes.argtypes = [i]
         L.bartrt_algorithmic_bytes.restype = d

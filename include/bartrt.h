@@ -129,6 +129,11 @@ int bartrt_get_pressure(double *out, int n);   /* barye, atm order */
  * index 0 = top (the tau.dat convention read by code/cf.py:68-94). */
 int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers);
 
+/* Line-by-line engines only (cfg has `linedb`, no `opacityfile`): the Voigt
+ * extinction of one profile, ext[nlayers][nwave_local] in cm-1, atm layer order. */
+int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext,
+                              int nlayers, int nwave);
+
 /* HIP-event timing of the RT kernel launches (bench.py's roofline leg).
  * begin resets; end returns accumulated device ms and launch count. */
 int bartrt_timing_begin(void);

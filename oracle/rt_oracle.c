@@ -121,7 +121,7 @@ int orc_extinction(const rt_oracle_cfg *c, const double *prof, double *ext,
     const double T = temp[l];
     const double nd = c->press[l] / (ORC_KB * T); /* molecules cm-3 */
     double *e = ext + (size_t)l * W;
-    for (int i = 0; i < W; i++) e[i] = 0.0;
+    for (int i = 0; i < W; i++) e[i] = c->extra_ext ? c->extra_ext[(size_t)l * W + i] : 0.0;
     /* molecular extinction: linear-in-T between the two bracketing planes
      * of the layer's own slab of the grid, times the molecule's mass density */
     if (M > 0) {

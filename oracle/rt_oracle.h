@@ -76,6 +76,7 @@ typedef struct {
   int    scat_iH2;          /* species index of H2 (or -1) */
   int    scat_iHe;          /* species index of He (or -1) */
   double starrad;           /* cm (transit geometry only) */
+  const double *extra_ext;  /* optional [L][W] extinction added as is (line-by-line), or NULL */
 } rt_oracle_cfg;
 
 /* Hydrostatic radii.  Follows code/makeatm.py:183-263 (radpress), in cgs and

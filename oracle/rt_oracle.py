@@ -35,7 +35,7 @@ class _Cfg(C.Structure):
         ("toomuch", C.c_double), ("gsurf", C.c_double), ("refpress", C.c_double),
         ("refradius", C.c_double), ("cloudtop", C.c_double),
         ("scat_value", C.c_double), ("scat_iH2", C.c_int), ("scat_iHe", C.c_int),
-        ("starrad", C.c_double),
+        ("starrad", C.c_double), ("extra_ext", C.c_void_p),
     ]
 
 
@@ -221,6 +221,11 @@ class OracleEngine:
 
     def set_scattering(self, flag, value):
         self.c.scat_flag, self.c.scat_value = int(flag), float(value)
+
+    def set_extra_extinction(self, ext):
+        """ext [L][W] (atm layer order) added to the extinction, or None."""
+        self._extra = None if ext is None else np.ascontiguousarray(ext, np.float64)
+        self.c.extra_ext = None if ext is None else _p(self._extra)
 
     def run(self, prof, want_tau=False):
         prof = np.ascontiguousarray(prof, np.float64).ravel()

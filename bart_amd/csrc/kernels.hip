@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   constexpr int AMAX = AT > 0 ? AT : kMaxAngles;
   double I[AMAX], fprev[AMAX];
 #pragma unroll
-  for (int a = 0; a < AMAX; a++) { I[a] = 0.0; fprev[a] = 0.0; }
+  for (int a = 0; a < AMAX; a++) { I[a] = 0.0; fprev[a] = 1.0; }  // fprev: E_{a,k-1}
 
-  double tau = 0.0, eprev = 0.0;
+  double tau = 0.0, eprev = 0.0, Bprev = 0.0;
   bool active = true;
   int last = 0;
   const int kend = p.kstop[w];
@@ -244,14 +244,18 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     }
     const double dtau = active ? 0.5 * (eprev + e) * c[0] : 0.0;
     tau += dtau;
+    // I_a += (B_{k-1} + B_k)/2 * (E_{a,k-1} - E_{a,k}), E = exp(-tau/mu):
+    // trapezoid in the transmittance (exact for an isothermal column)
     const double B = bnum / (exp(c[1] * nu) - 1.0);
+    const double hb = active ? 0.5 * (Bprev + B) : 0.0;
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
       if (AT <= 0 && a >= A) break;
-      const double f = B * exp(-tau * p.invmu[a]);
-      I[a] += 0.5 * (fprev[a] + f) * dtau;
-      fprev[a] = f;
+      const double E = exp(-tau * p.invmu[a]);
+      I[a] += hb * (fprev[a] - E);
+      fprev[a] = E;
     }
+    Bprev = B;
     eprev = e;
     if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tau;
     if (active) {
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
 #pragma unroll
   for (int a = 0; a < AMAX; a++) {
     if (AT <= 0 && a >= A) break;
-    F += p.wgt[a] * (I[a] * p.invmu[a] + (surf ? fprev[a] : 0.0));
+    F += p.wgt[a] * (I[a] + (surf ? Bprev * fprev[a] : 0.0));
   }
   if (valid) {
     p.spec[(size_t)w * W + i] = F;
@@ -365,9 +369,9 @@ __global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
 
   double I[A], fprev[A];
 #pragma unroll
-  for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 0.0; }
+  for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }  // fprev: E_{a,k-1}
   double cur[NLD > 0 ? NLD : 1], nxt[NLD > 0 ? NLD : 1];
-  double tau = 0.0, eprev = 0.0;
+  double tau = 0.0, eprev = 0.0, Bprev = 0.0;
   bool active = true;
   int last = 0;
   const int kend = p.kstop[w];
@@ -381,13 +385,14 @@ __global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
     const double dtau = active ? 0.5 * (eprev + e) * c[0] : 0.0;
     tau += dtau;
     const double B = bnum * rcp_core(exp_core(fmin(c[1] * nu, 700.0)) - 1.0);
-    const double hd = 0.5 * dtau;
+    const double hb = active ? 0.5 * (Bprev + B) : 0.0;
 #pragma unroll
     for (int a = 0; a < A; a++) {
-      const double f = B * exp_core(fmax(-tau * p.invmu[a], -745.0));
-      I[a] = fma(fprev[a] + f, hd, I[a]);
-      fprev[a] = f;
+      const double E = exp_core(fmax(-tau * p.invmu[a], -745.0));
+      I[a] = fma(hb, fprev[a] - E, I[a]);
+      fprev[a] = E;
     }
+    Bprev = B;
     eprev = e;
     if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tau;
     if (active) {
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
   double F = 0.0;
   const bool surf = p.cloud_on && active;
 #pragma unroll
-  for (int a = 0; a < A; a++) F += p.wgt[a] * (I[a] * p.invmu[a] + (surf ? fprev[a] : 0.0));
+  for (int a = 0; a < A; a++) F += p.wgt[a] * (I[a] + (surf ? Bprev * fprev[a] : 0.0));
   if (valid) {
     p.spec[(size_t)w * W + i] = F;
     if (p.tau_out) {

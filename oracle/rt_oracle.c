@@ -236,12 +236,22 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
       f[k] = orc_planck(wn, t_col[k]) * exp(-tau[k] / mu);
     double I;
     if (c->integ == ORC_INTEG_SIMPSON) {
-      I = simpson_nu(tau, f, last + 1);
-    } else {
+      I = simpson_nu(tau, f, last + 1) / mu;
+    } else if (c->integ == ORC_INTEG_TRAPZ_TAU) {
       I = 0.0;
       for (int k = 1; k <= last; k++) I += 0.5 * (f[k - 1] + f[k]) * (tau[k] - tau[k - 1]);
+      I /= mu;
+    } else {
+      /* default: I = int B d(exp(-tau/mu)), trapezoid in the transmittance.
+       * Exact for an isothermal column, never exceeds the hottest layer's
+       * Planck function (a trapezoid in tau does when tau jumps by >> 1
+       * across one layer), and is the discretisation BART's own
+       * contribution functions use (code/cf.py:123-131). */
+      I = 0.0;
+      for (int k = 1; k <= last; k++)
+        I += 0.5 * (orc_planck(wn, t_col[k - 1]) + orc_planck(wn, t_col[k])) *
+             (exp(-tau[k - 1] / mu) - exp(-tau[k] / mu));
     }
-    I /= mu;
     /* opaque cloud deck reached before toomuch: it emits as a surface */
     if (kcloud >= 0 && last == kcloud && !(tau[last] > c->toomuch)) I += f[last];
     intens[a] = I;

@@ -34,7 +34,10 @@ extern "C" {
 #define ORC_AMAGAT 2.68679e19
 #define ORC_PI     3.141592653589793
 
-enum { ORC_INTEG_TRAPZ = 0, ORC_INTEG_SIMPSON = 1 };
+/* intensity integration rule: 0 (default) trapezoid in the transmittance
+ * exp(-tau/mu); 1 Simpson in tau (tau itself by Simpson in radius too);
+ * 2 trapezoid in tau of B exp(-tau/mu) */
+enum { ORC_INTEG_TRAPZ = 0, ORC_INTEG_SIMPSON = 1, ORC_INTEG_TRAPZ_TAU = 2 };
 enum { ORC_SOL_ECLIPSE = 0, ORC_SOL_TRANSIT = 1 };
 
 typedef struct {

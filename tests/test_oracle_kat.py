@@ -58,23 +58,37 @@ def test_table_interpolation_at_nodes_and_midpoints(tmp_path):
 
 
 def test_isothermal_closed_form(tmp_path):
-    """Isothermal column: B factors out, so I(mu) = B * trapz_tau(exp(-tau/mu))/mu
-    exactly, and the flux tends to pi*B once tau >> 1 (independent of opacity)."""
+    """Isothermal column, any opacity: I(mu) = B (1 - exp(-tau_last/mu))
+    exactly, so the flux tends to pi*B from below once tau >> 1."""
     case, e = _engine(tmp_path, nwave=40)
     T = 1500.0
     spec, tau, last = e.run(case.profiles(temp=np.full(100, T)), want_tau=True)
     wg = _wgt(e.angles)
     for i in range(0, 40, 7):
         B = orc.planck(e.wn[i], T)
-        F = 0.0
-        for a, w in zip(e.angles, wg):
-            mu = np.cos(np.radians(a))
-            t = tau[i, :last[i] + 1]
-            f = np.exp(-t / mu)
-            F += w * B * np.sum(0.5 * (f[1:] + f[:-1]) * np.diff(t)) / mu
+        F = sum(w * B * (1.0 - np.exp(-tau[i, last[i]] / np.cos(np.radians(a))))
+                for a, w in zip(e.angles, wg))
         assert abs(spec[i] / F - 1) < 1e-13
         assert tau[i, last[i]] > 10.0
-        assert abs(spec[i] / (np.pi * B) - 1) < 0.02     # discretisation only
+        assert 1 - 1e-4 < spec[i] / (np.pi * B) <= 1.0
+
+
+def test_intensity_never_exceeds_hottest_planck(tmp_path):
+    """A jump of tau by >> 1 across one layer (a line core) must not push the
+    intensity above the hottest layer's Planck function."""
+    case = synth.make_case(str(tmp_path), nwave=8, nlayers=30, opmol=("H2O",), cia=False)
+    op = orc.read_opacity(case.opacity)
+    kap = np.full(op["kappa"].shape, 1e-2)
+    kap[:12] = 1e7                      # layers are bottom -> top: an opaque floor at mid-column
+    synth.write_opacity(case.opacity, op["ids"], op["temps"], op["press"], op["wn"], kappa=kap)
+    e = orc.OracleEngine(case.tcfg)
+    prof = case.profiles()
+    spec, tau, last = e.run(prof, want_tau=True)
+    assert np.max(np.diff(tau[0][:last[0] + 1])) > 5.0
+    bmax = np.array([orc.planck(w, prof[0].max()) for w in e.wn])
+    assert np.all(spec <= np.pi * bmax * (1 + 1e-12)) and np.all(spec > 0)
+    old = orc.OracleEngine(case.tcfg, integ=2).run(prof)          # trapezoid in tau
+    assert np.any(old > np.pi * bmax)                              # the artefact it avoids
 
 
 def test_grey_atmosphere_tau_is_column_mass(tmp_path):

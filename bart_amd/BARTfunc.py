@@ -100,8 +100,6 @@ class Worker:
         self.cfg = cfg
         if cfg.PTtype not in PT_NPARS:
             raise ValueError("unknown PTtype %r (known: %s)" % (cfg.PTtype, sorted(PT_NPARS)))
-        if cfg.solution == "transit":
-            raise NotImplementedError("solution 'transit' (modulation spectrum) is not built yet")
         tep = hostio.TepFile(cfg.tep_name)
         self.tstar = float(tep.getvalue("Ts")[0])
         self.rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
@@ -169,11 +167,13 @@ class Worker:
         rejected walkers carry -1 in every band."""
         p = np.atleast_2d(np.asarray(params, np.double))
         off = self.nPT + self.nradfit
-        if self.ncloud or self.nray:
+        if self.ncloud or self.nray or self.nradfit:
             # engine-global setters, as in the reference (one walker per call)
             if p.shape[0] != 1:
-                raise NotImplementedError("cloud/scattering parameters are per-call settings: "
-                                          "batch size must be 1")
+                raise NotImplementedError("radius/cloud/scattering parameters are per-call "
+                                          "settings: batch size must be 1")
+            if self.nradfit:
+                trm.set_radius(p[0, self.nPT])          # BARTfunc.py:350-351, km
             if self.ncloud:
                 trm.set_cloudtop(p[0, off])
             if self.nray:

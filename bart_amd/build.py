@@ -8,7 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
-SOURCES = ["capi.hip", "engine.hip", "kernels.hip", "step.hip", "lbl.hip", "io.cpp"]
+SOURCES = ["capi.hip", "engine.hip", "kernels.hip", "step.hip", "lbl.hip", "transit_geom.hip",
+           "io.cpp"]
 HEADERS = ["engine.hpp", "kernels.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "io.hpp",
            "../../include/bartrt.h"]
 

@@ -41,7 +41,7 @@ Engine::~Engine() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_dlnp); fr(d_mass);
   fr(d_tgrid); fr(d_cia_temp); fr(d_diam); fr(d_opmol); fr(d_prof); fr(d_coef); fr(d_spec);
-  fr(d_idx); fr(d_kstop); fr(d_ok); fr(d_tau); fr(d_last);
+  fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_ok); fr(d_tau); fr(d_last);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
@@ -96,8 +96,15 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   if (!cfg_has(cfg, "atm")) throw IoError{"transit cfg: missing 'atm'"};
   if (!cfg_has(cfg, "molfile")) throw IoError{"transit cfg: missing 'molfile'"};
   std::string sol = cfg_has(cfg, "solution") ? cfg["solution"] : "eclipse";
-  if (sol != "eclipse")
-    throw IoError{"solution '" + sol + "' is not built yet: only 'eclipse' (SURVEY.md 8f-1)"};
+  if (sol == "transit") {
+    solution = 1;
+    if (!cfg_has(cfg, "starrad"))
+      throw IoError{"solution 'transit' needs 'starrad' (stellar radius in solar radii) in the transit cfg"};
+    starrad = cfg_num(cfg, "starrad", 0) * 6.96e10;  // Rsun of code/constants.py:11
+    if (!(starrad > 0)) throw IoError{"transit cfg: bad 'starrad'"};
+  } else if (sol != "eclipse") {
+    throw IoError{"unknown solution '" + sol + "' (eclipse or transit)"};
+  }
   atm = read_atm(cfg["atm"]);
   mol = read_molfile(cfg["molfile"]);
   L = (int)atm.press.size();
@@ -321,6 +328,10 @@ void Engine::ensure_walkers(int n) {
   re(d_kstop, (size_t)cap);
   re(d_ok, (size_t)cap);
   re(d_spec, (size_t)cap * W());
+  if (solution == 1) {
+    re(d_rtop, (size_t)cap * L);
+    re(d_ds, (size_t)cap * L * L);
+  }
   cap_walkers = cap;
 }
 
@@ -364,6 +375,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.has_cloud = has_cloud; pa.cloudtop = cloudtop;
   pa.coef = d_coef; pa.idx = d_idx; pa.kstop = d_kstop;
   pa.ok = d_okp ? d_okp : d_ok;
+  pa.rtop = solution == 1 ? d_rtop : nullptr;
+  pa.ds = solution == 1 ? d_ds : nullptr;
   HIPCHK(launch_prep(pa, st));
 
   RtArgs r = rt;
@@ -376,8 +389,10 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;
   r.last_out = (want_tau && n == 1) ? d_last : nullptr;
   int block = 256;
-  if ((long)((r.W + 255) / 256) * n < 512) block = 64;
+  if ((long)((r.W + 255) / 256) * n < 512 || solution == 1) block = 64;
   r.ntiles = (r.W + block - 1) / block;
+  r.rtop = d_rtop; r.ds = d_ds;
+  r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
   if (timing) {
     while ((int)ev.size() < ev_used + 2) {
       hipEvent_t e;
@@ -386,7 +401,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     }
     HIPCHK(hipEventRecord(ev[ev_used], st));
   }
-  HIPCHK(launch_rt(r, block, st));
+  if (solution == 1) HIPCHK(launch_transit(r, st));
+  else HIPCHK(launch_rt(r, block, st));
   if (timing) {
     HIPCHK(hipEventRecord(ev[ev_used + 1], st));
     ev_used += 2;

@@ -12,6 +12,7 @@ namespace bartrt {
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st);
+hipError_t launch_transit(const RtArgs &a, hipStream_t st);
 
 struct StepArgs;  // converters around the engine (step.hip)
 struct Lbl;       // line-by-line extinction (lbl.hip)
@@ -28,6 +29,8 @@ struct Engine {
   std::vector<int> opmol;
   double toomuch = 20.0, gsurf = 0, refpress = 0, refradius = 0;
   int scat_flag = 0, iH2 = -1, iHe = -1, has_cloud = 0;
+  int solution = 0;       // 0 eclipse (emergent flux), 1 transit (modulation)
+  double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;
   int device = 0;
   // device-resident inputs
@@ -41,6 +44,7 @@ struct Engine {
   int cap_walkers = 0;
   double *d_prof = nullptr, *d_coef = nullptr, *d_spec = nullptr;
   int *d_idx = nullptr, *d_kstop = nullptr;
+  double *d_rtop = nullptr, *d_ds = nullptr;  // transit geometry workspaces
   unsigned char *d_ok = nullptr;
   double *d_tau = nullptr;  // [W][L] of the last single-walker run
   int *d_last = nullptr;

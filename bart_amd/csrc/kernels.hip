@@ -162,6 +162,21 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
     }
     c[2 + 2 * M + 2 * C] = ray;
   }
+  if (p.rtop && !bad) {
+    double *rt = p.rtop + (size_t)w * L, *ds = p.ds + (size_t)w * L * L;
+    for (int k = threadIdx.x; k < L; k += blockDim.x) rt[k] = sR[L - 1 - k];
+    for (int t = threadIdx.x; t < L * L; t += blockDim.x) {
+      const int k = t / L, j = t % L;
+      double v = 0.0;
+      if (j >= 1 && j <= k) {
+        const double rk = sR[L - 1 - k], r0 = sR[L - j], r1 = sR[L - 1 - j];
+        const double s0 = sqrt((r0 - rk) * (r0 + rk));
+        const double s1 = (j == k) ? 0.0 : sqrt((r1 - rk) * (r1 + rk));
+        v = s0 - s1;
+      }
+      ds[t] = v;
+    }
+  }
   if (threadIdx.x == 0) {
     int ks = L - 1;
     if (p.has_cloud) {

@@ -55,6 +55,10 @@ struct PrepArgs {
   int *idx;                // [nw][L][idx_stride]
   int *kstop;              // [nw] deepest layer index k to integrate to
   unsigned char *ok;       // [nw]
+  // transit geometry only (null otherwise): radii top -> bottom and the chord
+  // segments ds[k][j] = s_{j-1} - s_j, s_j = sqrt(r_j^2 - r_k^2), j = 1..k
+  double *rtop;            // [nw][L]
+  double *ds;              // [nw][L][L]
 };
 
 struct RtArgs {
@@ -73,6 +77,9 @@ struct RtArgs {
   double *spec;            // [nw][W]
   double *tau_out;         // optional [W][L] (single walker), may be null
   int *last_out;           // optional [W]
+  // transit geometry
+  const double *rtop, *ds;
+  double inv_starrad2;
 };
 
 }  // namespace bartrt

@@ -261,6 +261,71 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
   *last_out = last;
 }
 
+/* Transit (transmission) geometry.  For the ray with impact parameter b = r_k
+ * (each layer radius in turn, from the top) the optical depth along the chord is
+ *   tau_k = 2 int_b^{r_top} e(r) ds,  s = sqrt(r^2 - b^2),
+ * by trapezoid in s over the layers above; the chord with tau > toomuch and
+ * everything below it is opaque.  Modulation (what BARTfunc compares with the
+ * transit depths, examples/demo/BART_transit.cfg:45-47):
+ *   M = (r_top^2 - 2 int_{r_last}^{r_top} exp(-tau(b)) b db) / R_star^2,
+ * trapezoid in b.  With no absorber M = (r_bottom / R_star)^2: the lowest layer
+ * is an opaque surface.  Published Transit algorithm; unverified vs source. */
+static void column_transit(const rt_oracle_cfg *c, int L, const double *e_col,
+                           const double *r_col, int kcloud, double *tau, double *mod,
+                           int *last_out) {
+  int kend = (kcloud >= 0) ? kcloud : L - 1;
+  int last = kend;
+  tau[0] = 0.0;
+  for (int k = 1; k <= kend; k++) {
+    double t = 0.0, sprev = sqrt((r_col[0] - r_col[k]) * (r_col[0] + r_col[k]));
+    for (int j = 1; j <= k; j++) {
+      double s = (j == k) ? 0.0 : sqrt((r_col[j] - r_col[k]) * (r_col[j] + r_col[k]));
+      t += (e_col[j - 1] + e_col[j]) * (sprev - s);
+      sprev = s;
+    }
+    tau[k] = t;
+    if (t > c->toomuch) { last = k; break; }
+  }
+  for (int k = last + 1; k < L; k++) tau[k] = tau[last];
+  double integ = 0.0, gprev = r_col[0];
+  for (int k = 1; k <= last; k++) {
+    double g = exp(-tau[k]) * r_col[k];
+    integ += 0.5 * (gprev + g) * (r_col[k - 1] - r_col[k]);
+    gprev = g;
+  }
+  /* below r_last the planet is opaque: subtract the transmitted light of the
+   * annulus between r_last and the top only */
+  double rl = r_col[last];
+  double area = rl * rl + 2.0 * (0.5 * (r_col[0] * r_col[0] - rl * rl) - integ);
+  *mod = area / (c->starrad * c->starrad);
+  *last_out = last;
+}
+
+static int solve_transit(const rt_oracle_cfg *c, const double *prof, double *spec,
+                         double *tau_out, int *last_out) {
+  const int L = c->nlayers, W = c->nwave;
+  double *ext = (double *)malloc(sizeof(double) * (size_t)L * W);
+  double *rad = (double *)malloc(sizeof(double) * L);
+  orc_extinction(c, prof, ext, rad);
+  double *e_col = (double *)malloc(sizeof(double) * L);
+  double *r_col = (double *)malloc(sizeof(double) * L);
+  double *tau = (double *)malloc(sizeof(double) * L);
+  int kcloud = -1;
+  for (int k = 0; k < L; k++) {
+    r_col[k] = rad[L - 1 - k];
+    if (c->has_cloud && kcloud < 0 && c->press[L - 1 - k] >= c->cloudtop) kcloud = k;
+  }
+  for (int i = 0; i < W; i++) {
+    for (int k = 0; k < L; k++) e_col[k] = ext[(size_t)(L - 1 - k) * W + i];
+    int last;
+    column_transit(c, L, e_col, r_col, kcloud, tau, &spec[i], &last);
+    if (tau_out) memcpy(tau_out + (size_t)i * L, tau, sizeof(double) * L);
+    if (last_out) last_out[i] = last;
+  }
+  free(ext); free(rad); free(e_col); free(r_col); free(tau);
+  return 0;
+}
+
 static int solve(const rt_oracle_cfg *c, const double *prof, double *spec,
                  double *tau_out, int *last_out, double *intens_out) {
   const int L = c->nlayers, W = c->nwave, A = c->nangles;
@@ -308,7 +373,7 @@ static int solve(const rt_oracle_cfg *c, const double *prof, double *spec,
 
 int orc_run_transit(const rt_oracle_cfg *c, const double *prof, double *spec,
                     double *tau_out, int *last_out) {
-  if (c->solution != ORC_SOL_ECLIPSE) return -1;
+  if (c->solution == ORC_SOL_TRANSIT) return solve_transit(c, prof, spec, tau_out, last_out);
   return solve(c, prof, spec, tau_out, last_out, NULL);
 }
 

@@ -207,6 +207,9 @@ class OracleEngine:
         c.refradius = float(k["refradius"]) * 1e5
         c.scat_iH2 = self.species.index("H2") if "H2" in self.species else -1
         c.scat_iHe = self.species.index("He") if "He" in self.species else -1
+        if c.solution == 1:
+            # stellar radius in solar radii (Rsun of code/constants.py:11)
+            c.starrad = float(k["starrad"]) * 6.96e10
         if "cloudtop" in k:
             c.has_cloud, c.cloudtop = 1, 10.0 ** float(k["cloudtop"]) * 1e6
         self.c = c

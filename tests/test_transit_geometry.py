@@ -1,0 +1,121 @@
+"""Transit (transmission) geometry, SURVEY.md 8f-1: oracle known answers on CPU,
+device parity and the worker's `solution = transit` path on GPU."""
+import numpy as np
+import pytest
+
+RTOL = 1e-10
+TKEYS = {"solution": "transit", "starrad": 1.145}
+
+
+def _case(tmp_path, **kw):
+    from bart_amd import synth
+    ek = dict(TKEYS)
+    ek.update(kw.pop("extra_keys", {}))
+    return synth.make_case(str(tmp_path), extra_keys=ek, **kw)
+
+
+def test_no_absorber_gives_bottom_radius(tmp_path):
+    """tau == 0 on every chord: the planet is the opaque sphere below the
+    lowest layer, M = (r_bottom / R_star)^2."""
+    from oracle import rt_oracle as orc
+    c = _case(tmp_path, nwave=8, opmol=(), cia=False)
+    e = orc.OracleEngine(c.tcfg)
+    spec, tau, last = e.run(c.profiles(), want_tau=True)
+    _, rad = e.extinction(c.profiles())
+    np.testing.assert_allclose(spec, (rad[0] / (1.145 * 6.96e10)) ** 2, rtol=1e-13)
+    assert np.all(tau == 0)
+
+
+def test_opaque_atmosphere_gives_top_radius(tmp_path):
+    from bart_amd import synth
+    from oracle import rt_oracle as orc
+    c = _case(tmp_path, nwave=8, nlayers=40, opmol=("H2O",), cia=False)
+    op = orc.read_opacity(c.opacity)
+    synth.write_opacity(c.opacity, op["ids"], op["temps"], op["press"], op["wn"],
+                        kappa=np.full(op["kappa"].shape, 1e12))
+    e = orc.OracleEngine(c.tcfg)
+    spec, tau, last = e.run(c.profiles(), want_tau=True)
+    _, rad = e.extinction(c.profiles())
+    rs = 1.145 * 6.96e10
+    assert np.all(last == 1)                       # the first chord below the top is opaque
+    assert np.all(spec < (rad[-1] / rs) ** 2) and np.all(spec > (rad[-2] / rs) ** 2)
+
+
+def test_chord_optical_depth_of_a_uniform_shell(tmp_path):
+    """Constant extinction e: tau(b) = 2 e sqrt(r_top^2 - b^2) exactly (the
+    trapezoid in the path coordinate is exact for a constant integrand)."""
+    from bart_amd import synth
+    from oracle import rt_oracle as orc
+    c = _case(tmp_path, nwave=4, nlayers=30, opmol=("H2O",), cia=False, toomuch=1e30)
+    op = orc.read_opacity(c.opacity)
+    e0 = orc.OracleEngine(c.tcfg)
+    prof = c.profiles(temp=np.full(30, 1000.0))
+    # kappa ~ 1/rho_H2O so that e = kappa * rho is the same in every layer
+    s = e0.species.index("H2O")
+    rho = prof[1 + s] * e0.mass[s] * orc.AMU * e0.press / (orc.KB * 1000.0)
+    kap = np.zeros(op["kappa"].shape)
+    kap[:] = (1e-9 / rho)[:, None, None, None]
+    synth.write_opacity(c.opacity, op["ids"], op["temps"], op["press"], op["wn"], kappa=kap)
+    e = orc.OracleEngine(c.tcfg)
+    spec, tau, last = e.run(prof, want_tau=True)
+    _, rad = e.extinction(prof)
+    rtop = rad[::-1]
+    np.testing.assert_allclose(tau[0], 2e-9 * np.sqrt(rtop[0] ** 2 - rtop ** 2), rtol=1e-9, atol=0)
+
+
+def test_more_absorber_means_deeper_transit(tmp_path):
+    from oracle import rt_oracle as orc
+    c = _case(tmp_path, nwave=64)
+    e = orc.OracleEngine(c.tcfg)
+    a = e.run(c.profiles())
+    ab = c.abund0.copy()
+    ab[:, 2:] *= 10.0
+    b = e.run(c.profiles(abund=ab))
+    assert np.all(b >= a) and np.any(b > a * 1.0001)
+    assert 0.010 < a.min() < a.max() < 0.03          # HD 209458b-like depths (BART_transit.cfg:46)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(nwave=333), dict(nwave=100, nlayers=37, toomuch=1e30),
+                                dict(nwave=130, nlayers=120, opmol=("H2O", "CO")),
+                                dict(nwave=90, opmol=(), cia=True)])
+def test_device_matches_oracle(tmp_path, kw):
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    from test_gpu_parity import walkers
+    c = _case(tmp_path, **kw)
+    engine.init(c.tcfg)
+    try:
+        profs = walkers(c, 3, seed=6)
+        spec = engine.run_batch(profs)
+        o = orc.OracleEngine(c.tcfg)
+        ref = o.run_batch(profs)
+        np.testing.assert_allclose(spec, ref, rtol=RTOL)
+        trm.run_transit(profs[1], trm.get_no_samples())
+        tau, last = engine.get_tau()
+        _, rtau, rlast = o.run(profs[1], want_tau=True)
+        assert np.array_equal(last, rlast)
+        np.testing.assert_allclose(tau, rtau, rtol=1e-9, atol=1e-300)
+        trm.set_radius(90000.0); o.set_radius(90000.0)      # BARTfunc.py:350-351
+        np.testing.assert_allclose(trm.run_transit(profs[0], trm.get_no_samples()), o.run(profs[0]),
+                                   rtol=RTOL)
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
+def test_worker_transit_solution(tmp_path):
+    """solution = transit: Rp is a fitted parameter fed through set_radius, the
+    bands are plain filter averages of the modulation (BARTfunc.py:391-393)."""
+    from bart_amd import BARTfunc, synthcfg
+    case, cfg = synthcfg.make_worker_case(
+        str(tmp_path), nwave=1500, solution="transit",
+        params=(-2.0, 0.0, 1.0, 0.0, 0.98, 97000.0, -0.5), extra_keys=dict(TKEYS))
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        assert w.nradfit == 1 and w.nPT == 5
+        a = w.step(np.array([-2.0, 0.0, 1.0, 0.0, 0.98, 97000.0, -0.5]))[0]
+        b = w.step(np.array([-2.0, 0.0, 1.0, 0.0, 0.98, 99000.0, -0.5]))[0]
+        assert np.all(b > a) and 0.012 < a.min() < a.max() < 0.03
+    finally:
+        w.close()

@@ -182,7 +182,17 @@ class Worker:
                 else:
                     trm.set_scattering(1, p[0, off + self.ncloud])
         core = np.concatenate([p[:, :self.nPT], p[:, off + self.ncloud + self.nray:]], axis=1)
-        band, status = engine.step_batch(core, self.nfilters)
+        lo, hi = engine.local_range()
+        if hi - lo != self.nwave:
+            # wavenumber-sharded node: profiles on every rank, RT on the local
+            # block, RCCL all-gather of the spectra, band integration on the full grid
+            import torch
+            d_par = torch.from_numpy(np.ascontiguousarray(core)).cuda()
+            band_d, status_d, _ = engine.step_batch_sharded(d_par, self.nfilters)
+            torch.cuda.synchronize()
+            band, status = band_d.cpu().numpy(), status_d.cpu().numpy()
+        else:
+            band, status = engine.step_batch(core, self.nfilters)
         for s in status[status > 0]:
             self.nbad[int(s)] += 1
         return band

@@ -8,10 +8,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
+CLI = os.path.join(HERE, "transit")
 SOURCES = ["capi.hip", "engine.hip", "kernels.hip", "step.hip", "lbl.hip", "transit_geom.hip",
            "io.cpp"]
 HEADERS = ["engine.hpp", "kernels.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "io.hpp",
-           "../../include/bartrt.h"]
+           "transit_main.cpp", "../../include/bartrt.h"]
 
 
 def _hipcc() -> str:
@@ -43,6 +44,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
     subprocess.check_call(cmd)
+    # the standalone `transit` executable (C ABI only), found next to the library
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(CSRC, "transit_main.cpp"),
+                           "-o", CLI, "-L" + HERE, "-lbartrt", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -187,6 +187,53 @@ int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
   });
 }
 
+int bartrt_get_atm_profile(double *prof, int nprof) {
+  NEED_ENGINE();
+  Engine *e = g_eng;
+  if (!prof || nprof != (e->S + 1) * e->L) return fail(BARTRT_EINVAL, "get_atm_profile: bad length");
+  for (int l = 0; l < e->L; l++) {
+    prof[l] = e->atm.temp[l];
+    for (int s = 0; s < e->S; s++) prof[(size_t)(s + 1) * e->L + l] = e->atm.abund[(size_t)l * e->S + s];
+  }
+  return BARTRT_OK;
+}
+
+int bartrt_get_radius(double *rad, int nlayers) {
+  NEED_ENGINE();
+  if (!rad || nlayers != g_eng->L) return fail(BARTRT_EINVAL, "get_radius: bad length");
+  return guarded([&] {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(rad, g_eng->d_rad, sizeof(double) * nlayers, hipMemcpyDeviceToHost));
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_get_nangles(void) { NEED_ENGINE(); return g_eng->A; }
+
+int bartrt_get_angles(double *deg, int n) {
+  NEED_ENGINE();
+  if (!deg || n != g_eng->A) return fail(BARTRT_EINVAL, "get_angles: bad length");
+  std::memcpy(deg, g_eng->angles.data(), sizeof(double) * n);
+  return BARTRT_OK;
+}
+
+int bartrt_get_intensity(double *intens, int nangles, int nwave) {
+  NEED_ENGINE();
+  Engine *e = g_eng;
+  if (e->solution != 0) return fail(BARTRT_EINVAL, "get_intensity: eclipse geometry only");
+  if (!intens || nangles != e->A || nwave != e->W()) return fail(BARTRT_EINVAL, "get_intensity: bad shape");
+  return guarded([&] {
+    e->want_intens = true;
+    try {
+      e->run_dev(e->d_prof, 1, e->d_spec, e->d_ok, e->stream, false);
+    } catch (...) { e->want_intens = false; throw; }
+    e->want_intens = false;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(intens, e->d_intens, sizeof(double) * (size_t)nangles * nwave, hipMemcpyDeviceToHost));
+    return BARTRT_OK;
+  });
+}
+
 int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext, int nlayers, int nwave) {
   NEED_ENGINE();
   Engine *e = g_eng;

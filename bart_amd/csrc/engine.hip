@@ -41,7 +41,7 @@ Engine::~Engine() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_dlnp); fr(d_mass);
   fr(d_tgrid); fr(d_cia_temp); fr(d_diam); fr(d_opmol); fr(d_prof); fr(d_coef); fr(d_spec);
-  fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_ok); fr(d_tau); fr(d_last);
+  fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
@@ -328,6 +328,7 @@ void Engine::ensure_walkers(int n) {
   re(d_kstop, (size_t)cap);
   re(d_ok, (size_t)cap);
   re(d_spec, (size_t)cap * W());
+  re(d_rad, (size_t)cap * L);
   if (solution == 1) {
     re(d_rtop, (size_t)cap * L);
     re(d_ds, (size_t)cap * L * L);
@@ -375,6 +376,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.has_cloud = has_cloud; pa.cloudtop = cloudtop;
   pa.coef = d_coef; pa.idx = d_idx; pa.kstop = d_kstop;
   pa.ok = d_okp ? d_okp : d_ok;
+  pa.rad_out = d_rad;
   pa.rtop = solution == 1 ? d_rtop : nullptr;
   pa.ds = solution == 1 ? d_ds : nullptr;
   HIPCHK(launch_prep(pa, st));
@@ -388,6 +390,11 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.spec = d_spec_out;
   r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;
   r.last_out = (want_tau && n == 1) ? d_last : nullptr;
+  r.intens_out = nullptr;
+  if (want_intens && n == 1 && solution == 0) {
+    if (!d_intens) HIPCHK(hipMalloc(&d_intens, sizeof(double) * (size_t)A * W()));
+    r.intens_out = d_intens;
+  }
   int block = 256;
   if ((long)((r.W + 255) / 256) * n < 512 || solution == 1) block = 64;
   r.ntiles = (r.W + block - 1) / block;

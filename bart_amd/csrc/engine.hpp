@@ -45,6 +45,9 @@ struct Engine {
   double *d_prof = nullptr, *d_coef = nullptr, *d_spec = nullptr;
   int *d_idx = nullptr, *d_kstop = nullptr;
   double *d_rtop = nullptr, *d_ds = nullptr;  // transit geometry workspaces
+  double *d_rad = nullptr;     // [cap][L] hydrostatic radii of the last run
+  double *d_intens = nullptr;  // [A][W] of the last single-walker run with want_intens
+  bool want_intens = false;
   unsigned char *d_ok = nullptr;
   double *d_tau = nullptr;  // [W][L] of the last single-walker run
   int *d_last = nullptr;

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
     }
     c[2 + 2 * M + 2 * C] = ray;
   }
+  if (p.rad_out)
+    for (int l = threadIdx.x; l < L; l += blockDim.x) p.rad_out[(size_t)w * L + l] = bad ? 0.0 : sR[l];
   if (p.rtop && !bad) {
     double *rt = p.rtop + (size_t)w * L, *ds = p.ds + (size_t)w * L * L;
     for (int k = threadIdx.x; k < L; k += blockDim.x) rt[k] = sR[L - 1 - k];
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   for (int a = 0; a < AMAX; a++) {
     if (AT <= 0 && a >= A) break;
     F += p.wgt[a] * (I[a] + (surf ? Bprev * fprev[a] : 0.0));
+    if (p.intens_out && valid) p.intens_out[(size_t)a * W + i] = I[a] + (surf ? Bprev * fprev[a] : 0.0);
   }
   if (valid) {
     p.spec[(size_t)w * W + i] = F;
@@ -456,7 +459,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const char *e = std::getenv("BARTRT_KERNEL");  // "generic" forces the fallback (A/B runs)
     return e && std::string(e) == "generic";
   }();
-  if (!generic_only && a.A == 5 && !a.ext) {
+  if (!generic_only && a.A == 5 && !a.ext && !a.intens_out) {
 #define BARTRT_FAST(MM, CC)                                                        \
   if (a.M == MM && a.C == CC) {                                                    \
     hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC>), dim3(nblocks), dim3(block), sh, st, a); \

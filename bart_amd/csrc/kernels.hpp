@@ -55,6 +55,7 @@ struct PrepArgs {
   int *idx;                // [nw][L][idx_stride]
   int *kstop;              // [nw] deepest layer index k to integrate to
   unsigned char *ok;       // [nw]
+  double *rad_out;         // optional [nw][L] hydrostatic radii, cm, atm layer order
   // transit geometry only (null otherwise): radii top -> bottom and the chord
   // segments ds[k][j] = s_{j-1} - s_j, s_j = sqrt(r_j^2 - r_k^2), j = 1..k
   double *rtop;            // [nw][L]
@@ -77,6 +78,7 @@ struct RtArgs {
   double *spec;            // [nw][W]
   double *tau_out;         // optional [W][L] (single walker), may be null
   int *last_out;           // optional [W]
+  double *intens_out;      // optional [A][W] intensities per ray angle (single walker)
   // transit geometry
   const double *rtop, *ds;
   double inv_starrad2;

@@ -1,0 +1,145 @@
+"""In-process batched MCMC driver for the GPU worker.
+
+The reference runs one OS process per chain and MC3 moves 6-9 doubles per step
+over MPI (code/BARTfunc.py:309-399).  With the forward model batched on the GPU
+the natural shape is the opposite: ONE process per GPU evaluates every chain of
+the ensemble in a single ``Worker.step`` call.  This module is that loop:
+differential-evolution MCMC (ter Braak 2006; the reference's ``walk = demc``)
+and its snooker variant (ter Braak & Vrugt 2008; ``walk = snooker``) over the
+keys of the reference's ``[MCMC]`` section -- ``params, pmin, pmax, stepsize,
+nchains, numit, burnin, data, uncert, walk, grtest`` (examples/demo/
+BART_eclipse.cfg:43-102).  ``stepsize = 0`` keeps a parameter fixed; proposals
+outside [pmin, pmax] and models the worker rejects (``-1`` sentinels) are
+refused, as in the reference.
+
+On a wavenumber-sharded node every rank runs this same loop with the same seed:
+the proposals are identical everywhere, each rank computes its block of every
+spectrum and the all-gather inside the model call reassembles them.
+"""
+from __future__ import annotations
+
+import configparser
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class SamplerConfig:
+    params: np.ndarray
+    pmin: np.ndarray
+    pmax: np.ndarray
+    stepsize: np.ndarray
+    data: np.ndarray
+    uncert: np.ndarray
+    nchains: int = 10
+    numit: int = 10000
+    burnin: int = 500
+    walk: str = "demc"
+    grtest: bool = True
+    seed: int = 0
+
+    @classmethod
+    def from_cfg(cls, path: str, section: str = "MCMC") -> "SamplerConfig":
+        cp = configparser.ConfigParser()
+        cp.optionxform = str
+        cp.read([path])
+        d = dict(cp.items(section))
+        arr = lambda k: np.array([float(x) for x in d[k].split()])
+        return cls(params=arr("params"), pmin=arr("pmin"), pmax=arr("pmax"),
+                   stepsize=arr("stepsize"), data=arr("data"), uncert=arr("uncert"),
+                   nchains=int(d.get("nchains", 10)), numit=int(float(d.get("numit", 10000))),
+                   burnin=int(d.get("burnin", 500)), walk=d.get("walk", "demc"),
+                   grtest=d.get("grtest", "True").strip() == "True",
+                   seed=int(d.get("seed", 0)))
+
+
+def gelman_rubin(chains: np.ndarray) -> np.ndarray:
+    """chains [nchains, nsamples, npar] -> potential scale reduction per parameter."""
+    m, n, _ = chains.shape
+    mean_c = chains.mean(axis=1)
+    W = chains.var(axis=1, ddof=1).mean(axis=0)
+    B = n * mean_c.var(axis=0, ddof=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.sqrt(((n - 1) / n * W + B / n) / W)
+
+
+def run(model, cfg: SamplerConfig, log=None):
+    """model(params[nchains, npars]) -> bandflux[nchains, ndata] (-1 rows = rejected).
+    Returns dict(chain [nchains, nsteps, npars], chisq [nchains, nsteps], bestp,
+    best_chisq, accept_rate, grstat)."""
+    rng = np.random.default_rng(cfg.seed)
+    free = np.where(cfg.stepsize > 0)[0]
+    nfree, nch = len(free), cfg.nchains
+    nsteps = max(1, int(np.ceil(cfg.numit / nch)))
+    npars = len(cfg.params)
+
+    def chisq_of(p):
+        m = np.asarray(model(p))
+        bad = np.any(m < 0, axis=1) & np.all(m == -1.0, axis=1)
+        c = np.sum(((m - cfg.data) / cfg.uncert) ** 2, axis=1)
+        c[bad] = np.inf
+        return c
+
+    # start: the configured point jittered by the stepsizes, inside the box
+    x = np.tile(cfg.params, (nch, 1))
+    x[:, free] += cfg.stepsize[free] * rng.normal(size=(nch, nfree))
+    x = np.clip(x, cfg.pmin, cfg.pmax)
+    x[0] = cfg.params
+    c = chisq_of(x)
+    for _ in range(20):                      # re-draw chains that start on a rejected model
+        bad = ~np.isfinite(c)
+        if not bad.any():
+            break
+        xb = np.tile(cfg.params, (int(bad.sum()), 1))
+        xb[:, free] += 0.1 * cfg.stepsize[free] * rng.normal(size=(len(xb), nfree))
+        x[bad] = xb
+        x = np.clip(x, cfg.pmin, cfg.pmax)
+        c = chisq_of(x)
+    if not np.isfinite(c).any():
+        raise RuntimeError("no chain starts on a physical model: check params/pmin/pmax")
+    chain = np.zeros((nch, nsteps, npars))
+    chis = np.zeros((nch, nsteps))
+    naccept = 0
+    gamma0 = 2.38 / np.sqrt(2 * max(nfree, 1))
+    for t in range(nsteps):
+        prop = x.copy()
+        r1 = np.array([rng.choice(np.delete(np.arange(nch), i)) for i in range(nch)])
+        r2 = np.array([rng.choice(np.delete(np.arange(nch), [i, r1[i]])) if nch > 2 else r1[i]
+                       for i in range(nch)])
+        logjac = np.zeros(nch)
+        if cfg.walk == "snooker" and nch > 3 and t % 10 != 0:
+            # snooker update: move along the line through a third chain
+            z = np.array([rng.choice(np.delete(np.arange(nch), [i, r1[i], r2[i]])) for i in range(nch)])
+            d = x[:, free] - x[z][:, free]
+            nd = np.linalg.norm(d, axis=1, keepdims=True)
+            nd[nd == 0] = 1.0
+            u = d / nd
+            proj = np.sum((x[r1][:, free] - x[r2][:, free]) * u, axis=1, keepdims=True)
+            g = rng.uniform(1.2, 2.2, size=(nch, 1))
+            prop[:, free] = x[:, free] + g * proj * u
+            nd_new = np.linalg.norm(prop[:, free] - x[z][:, free], axis=1)
+            logjac = (nfree - 1) * (np.log(np.maximum(nd_new, 1e-300)) - np.log(nd[:, 0]))
+        else:
+            gam = 1.0 if t % 10 == 0 else gamma0
+            jit = 1e-3 * cfg.stepsize[free] * rng.normal(size=(nch, nfree))
+            prop[:, free] = x[:, free] + gam * (x[r1][:, free] - x[r2][:, free]) + jit
+        inside = np.all((prop >= cfg.pmin) & (prop <= cfg.pmax), axis=1)
+        cp = np.full(nch, np.inf)
+        if inside.any():
+            cp[inside] = chisq_of(prop[inside])
+        with np.errstate(invalid="ignore", over="ignore"):
+            loga = -0.5 * (cp - c) + logjac
+        acc = np.log(rng.random(nch)) < loga
+        acc &= np.isfinite(cp)
+        x[acc], c[acc] = prop[acc], cp[acc]
+        naccept += int(acc.sum())
+        chain[:, t], chis[:, t] = x, c
+        if log is not None and (t + 1) % max(1, nsteps // 10) == 0:
+            log("step %d/%d  best chisq %.4f  acceptance %.2f" % (
+                t + 1, nsteps, float(np.min(chis[:, :t + 1])), naccept / ((t + 1) * nch)))
+    ib = np.unravel_index(np.argmin(chis), chis.shape)
+    post = chain[:, min(cfg.burnin, nsteps - 1):]
+    gr = gelman_rubin(post[:, :, free]) if cfg.grtest and post.shape[1] > 3 and nch > 1 else None
+    return {"chain": chain, "chisq": chis, "bestp": chain[ib], "best_chisq": float(chis[ib]),
+            "accept_rate": naccept / (nsteps * nch), "grstat": gr, "free": free}

@@ -129,6 +129,17 @@ int bartrt_get_pressure(double *out, int n);   /* barye, atm order */
  * index 0 = top (the tau.dat convention read by code/cf.py:68-94). */
 int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers);
 
+/* Outputs of the standalone run (reference: `transit -c cfg`, code/bestFit.py:421-427,
+ * code/cf.py:46-64).  get_atm_profile: the (S+1)*L profile array of the atmosphere
+ * file itself.  get_radius: hydrostatic radii (cm, atm order) of the last run's
+ * first profile.  get_intensity: I[nangles][nwave_local] of the last
+ * single-profile eclipse run (the `outintens` content). */
+int bartrt_get_atm_profile(double *prof, int nprof);
+int bartrt_get_radius(double *rad, int nlayers);
+int bartrt_get_nangles(void);
+int bartrt_get_angles(double *deg, int n);
+int bartrt_get_intensity(double *intens, int nangles, int nwave);
+
 /* Line-by-line engines only (cfg has `linedb`, no `opacityfile`): the Voigt
  * extinction of one profile, ext[nlayers][nwave_local] in cm-1, atm layer order. */
 int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext,

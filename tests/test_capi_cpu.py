@@ -56,9 +56,13 @@ def test_missing_and_malformed_inputs(lib, tmp_path):
         trm.transit_init(1, ["transit"])
     case = synth.make_case(str(tmp_path / "c"), nwave=16, nlayers=10)
     bad = dict(case.keys)
-    bad["solution"] = "transit"
+    bad["solution"] = "transit"                 # transit geometry needs the stellar radius
     synth.write_tcfg(str(tmp_path / "t.cfg"), bad)
-    with pytest.raises(trm.TransitError, match="not built yet"):
+    with pytest.raises(trm.TransitError, match="starrad"):
+        trm.transit_init(3, ["transit", "-c", str(tmp_path / "t.cfg")])
+    bad["solution"] = "sideways"
+    synth.write_tcfg(str(tmp_path / "t.cfg"), bad)
+    with pytest.raises(trm.TransitError, match="unknown solution"):
         trm.transit_init(3, ["transit", "-c", str(tmp_path / "t.cfg")])
     bad = dict(case.keys)
     del bad["gsurf"]

@@ -1,0 +1,78 @@
+"""The standalone `transit` executable and its output files,
+read back the way the reference's post-processing reads them."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bart_amd", "transit")
+
+
+def read_spectrum(path):
+    """Parsing rule of code/readtransit.py:38-62: skip one header line, first
+    column wavelength (um), last column the value."""
+    rows = [ln.split() for ln in open(path).read().strip().split("\n")[1:]]
+    return 1e4 / np.array([float(r[0]) for r in rows]), np.array([float(r[-1]) for r in rows])
+
+
+def read_tau_dat(path, nlayers):
+    """Parsing rule of code/cf.py:68-94."""
+    lines = open(path).readlines()
+    while lines[0].startswith("#") or not lines[0].strip():
+        lines.pop(0)
+    tau_lines, wn_lines = lines[1:-1:3], lines[0:-1:3]
+    tau = np.zeros((len(tau_lines), nlayers))
+    wns = np.zeros(len(wn_lines))
+    for i in range(len(tau_lines)):
+        tau[i] = tau_lines[i].split()
+        wns[i] = float(wn_lines[i].split()[1])
+    return tau.T, wns
+
+
+def test_cli_usage_without_gpu():
+    r = subprocess.run([CLI], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([CLI, "-c", "/nonexistent.cfg"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_outputs(tmp_path):
+    from bart_amd import synth
+    from oracle import rt_oracle as orc
+    d = str(tmp_path)
+    c = synth.make_case(d, nwave=200, nlayers=40, extra_keys={
+        "outspec": os.path.join(d, "spec.dat"), "outtoomuch": os.path.join(d, "toom.dat"),
+        "outintens": os.path.join(d, "intens.dat"), "outsample": os.path.join(d, "sample.dat"),
+        "savefiles": "yes"})
+    r = subprocess.run([CLI, "-c", c.tcfg], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    o = orc.OracleEngine(c.tcfg)
+    ref, rtau, rlast = o.run(c.profiles(), want_tau=True)
+    wn, spec = read_spectrum(os.path.join(d, "spec.dat"))
+    np.testing.assert_allclose(wn, o.wn, rtol=1e-8)
+    np.testing.assert_allclose(spec, ref, rtol=2e-9)              # 9 significant digits on file
+    tau, wns = read_tau_dat(os.path.join(d, "tau.dat"), 40)
+    assert tau.shape == (40, 200)
+    np.testing.assert_allclose(wns, o.wn, rtol=1e-8)
+    np.testing.assert_allclose(tau.T, rtau, rtol=2e-9, atol=1e-300)
+    _, inten = read_spectrum(os.path.join(d, "intens.dat"))       # last column = 80 deg ray
+    np.testing.assert_allclose(inten, o.intensity(c.profiles())[-1], rtol=2e-9)
+    wl, rtm = np.loadtxt(os.path.join(d, "toom.dat"), unpack=True)
+    _, rad = o.extinction(c.profiles())
+    reached = rtau[np.arange(200), rlast] > 10.0
+    np.testing.assert_allclose(rtm[reached], rad[::-1][rlast[reached]] / 1e5, rtol=1e-8)
+    assert np.all(rtm[~reached] == 0)
+    assert "radius sampling" in open(os.path.join(d, "sample.dat")).read()
+
+
+@pytest.mark.gpu
+def test_cli_just_opacity(tmp_path):
+    from bart_amd import synth_lbl
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=200, nwave=60, nlayers=5, with_table=True,
+                                tlow=800.0, thigh=1600.0, tempdelt=800.0)
+    r = subprocess.run([CLI, "-c", c.tcfg, "--justOpacity"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(c.keys["opacityfile"]) > 5 * 2 * 2 * 60 * 8

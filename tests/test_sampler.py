@@ -1,0 +1,75 @@
+"""The in-process batched sampler: on an analytic model on CPU,
+end to end on the GPU worker (recovering the parameters that generated the data)."""
+import os
+
+import numpy as np
+import pytest
+
+from bart_amd import sampler
+
+
+def _linear_model(truth):
+    x = np.linspace(0, 1, 12)
+
+    def model(p):
+        p = np.atleast_2d(p)
+        out = p[:, :1] + p[:, 1:2] * x[None, :]
+        out[p[:, 1] > 4.5] = -1.0            # a "rejected" region, like the -1 sentinels
+        return out
+    return model, model(np.array(truth))[0]
+
+
+@pytest.mark.parametrize("walk", ["demc", "snooker"])
+def test_recovers_a_gaussian_posterior(walk):
+    model, data = _linear_model([1.0, 2.0])
+    cfg = sampler.SamplerConfig(params=np.array([0.5, 1.0, 7.0]), pmin=np.array([-5.0, -5.0, 0.0]),
+                                pmax=np.array([5.0, 5.0, 10.0]), stepsize=np.array([0.1, 0.1, 0.0]),
+                                data=data, uncert=np.full(12, 0.05), nchains=8, numit=16000,
+                                burnin=500, walk=walk, seed=3)
+    res = sampler.run(model, cfg)
+    post = res["chain"][:, 500:, :].reshape(-1, 3)
+    assert np.all(post[:, 2] == 7.0)                      # stepsize 0: fixed
+    assert abs(post[:, 0].mean() - 1.0) < 0.02 and abs(post[:, 1].mean() - 2.0) < 0.04
+    # analytic posterior widths of a straight-line fit
+    x = np.linspace(0, 1, 12)
+    cov = np.linalg.inv(np.array([[12, x.sum()], [x.sum(), (x ** 2).sum()]]) / 0.05 ** 2)
+    assert abs(post[:, 0].std() / np.sqrt(cov[0, 0]) - 1) < 0.25
+    assert abs(post[:, 1].std() / np.sqrt(cov[1, 1]) - 1) < 0.25
+    assert 0.05 < res["accept_rate"] < 0.7 and res["best_chisq"] < 1e-2
+    assert np.all(res["grstat"] < 1.1)
+    assert np.all(post[:, 1] <= 4.5)                      # never accepted a rejected model
+
+
+def test_config_from_reference_style_cfg(tmp_path):
+    p = tmp_path / "BART.cfg"
+    p.write_text("[MCMC]\nparams = -2.0 0.0 1.0\npmin = -5 -2 -2\npmax = -1 1 1\n"
+                 "stepsize = 0.01 0.01 0.0\ndata = 1e-3 2e-3\nuncert = 1e-5 1e-5\n"
+                 "numit = 5e4\nnchains = 3\nburnin = 500\nwalk = snooker\ngrtest = True\n")
+    c = sampler.SamplerConfig.from_cfg(str(p))
+    assert c.numit == 50000 and c.nchains == 3 and c.walk == "snooker" and c.grtest
+    assert np.array_equal(c.stepsize, [0.01, 0.01, 0.0])
+
+
+@pytest.mark.gpu
+def test_retrieval_end_to_end(tmp_path):
+    """Synthetic eclipse depths generated with known parameters are fitted back
+    through the whole device path (T(p) -> RT -> bands) by the batched sampler."""
+    from bart_amd import BARTfunc, retrieve, synthcfg
+    truth = np.array([-2.0, 0.0, 1.0, 0.0, 0.98, -0.5])
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=1200, params=tuple(truth))
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    data = w.step(truth)[0]
+    w.close()
+    with open(cfg, "a") as f:
+        f.write("pmin = -5.0 -2.0 -2.0 0.0 0.55 -9.0\npmax = -1.0 1.0 1.0 1.0 1.2 1.5\n")
+        f.write("stepsize = 0.01 0.0 0.0 0.0 0.001 0.05\n")
+        f.write("data = " + " ".join("%.10e" % d for d in data) + "\n")
+        f.write("uncert = " + " ".join("%.10e" % (0.01 * d) for d in data) + "\n")
+        f.write("numit = 4000\nnchains = 16\nburnin = 50\nwalk = demc\nseed = 5\n")
+    res = retrieve.main(["-c", cfg, "--out", str(tmp_path / "out")])
+    assert res["best_chisq"] < 1.0
+    post = res["chain"][:, 100:, :]
+    for i in (0, 4, 5):                                   # the three free parameters
+        assert abs(np.median(post[:, :, i]) - truth[i]) < 4 * max(post[:, :, i].std(), 1e-3)
+    assert os.path.exists(tmp_path / "out" / "output.npy")
+    assert "models/s" in open(tmp_path / "out" / "MCMC.log").read()

@@ -121,20 +121,26 @@ def run_batch_sharded(d_prof, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    return allgather_blocks(local, group)
+    return allgather_blocks(local, group, total=trm.get_no_samples())
 
 
-def allgather_blocks(local, group=None):
+def allgather_blocks(local, group=None, total=None):
     """local [n, W_r] on rank r (block sizes may differ by one sample) ->
-    [n, sum_r W_r] on every rank."""
+    [n, sum_r W_r] on every rank.  With ``total`` (the full sample count) the
+    block sizes follow from the engine's integer split W*r//n and ONE collective
+    per call is issued; without it the sizes are exchanged first."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = local.shape[0]
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device),
-                    group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if total is not None:
+        sizes = [total * (r + 1) // world - total * r // world for r in range(world)]
+        assert sizes[dist.get_rank(group)] == local.shape[1]
+    else:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([local.shape[1]], dtype=torch.int64,
+                                            device=local.device), group=group)
+        sizes = [int(s.item()) for s in sizes]
     wmax = max(sizes)
     send = local
     if local.shape[1] != wmax:
@@ -143,6 +149,8 @@ def allgather_blocks(local, group=None):
     out = torch.empty((world * n, wmax), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, send.contiguous(), group=group)
     out = out.view(world, n, wmax)
+    if min(sizes) == wmax:
+        return out.permute(1, 0, 2).reshape(n, world * wmax)
     return torch.cat([out[r, :, :sizes[r]] for r in range(world)], dim=1)
 
 

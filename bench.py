@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--sweep", default="64,256,1024",
                     help="extra batch sizes reported under batch_sweep (N=1 only; '' = none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
 
@@ -108,7 +110,8 @@ def main():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or (a.force_collective and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -119,7 +122,7 @@ def main():
                                    "bartrt_bench_%s" % os.environ.get("MASTER_PORT", "single"))
     case = synth.make_case(wd, nlayers=a.nlayers, nwave=a.nwave, write=(local_rank == 0),
                            reuse=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     engine.init(case.tcfg, shard=(rank, world) if world > 1 else None, device=local_rank)
     lo, hi = engine.local_range()
@@ -135,14 +138,14 @@ def main():
 
         def step(i):
             engine.run_batch_dev(d_prof[i % nsets], d_local)
-            if world > 1:
-                return engine.allgather_blocks(d_local)
+            if use_dist:
+                return engine.allgather_blocks(d_local, total=a.nwave)
             return d_local
 
         for i in range(warmup):
             out = step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         if record:
@@ -151,12 +154,12 @@ def main():
         for i in range(steps):
             out = step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kern_ms, nlaunch = engine.timing_end() if record else (0.0, 0)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -215,7 +218,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     from bart_amd import transit_module as trm

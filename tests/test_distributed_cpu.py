@@ -36,6 +36,8 @@ WORKER = textwrap.dedent("""
     out = engine.allgather_blocks(local)
     assert out.shape == (n, W), out.shape
     assert torch.equal(out, full)
+    out2 = engine.allgather_blocks(local, total=W)      # static sizes: one collective
+    assert torch.equal(out2, full)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert abs(t.item() - 0.1 * world) < 1e-12

@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", 
-             "-Wall", "-Wno-unused-result"]
+             "-Wall", "-Wno-unused-result", *os.environ.get("BARTRT_CXXFLAGS", "").split()]
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]

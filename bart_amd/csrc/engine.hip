@@ -292,7 +292,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     }
     pa.ref_lnp = std::log(refpress / atm.press[ix]);
   }
-  pa.L = L; pa.S = S; pa.M = M; pa.Nt = Nt; pa.C = C;
+  pa.L = L; pa.S = S; pa.M = M; pa.Nt = Nt; pa.C = C; pa.W = Wl;
   pa.press = d_press; pa.dlnp = d_dlnp; pa.mass = d_mass; pa.tgrid = d_tgrid;
   pa.opmol = d_opmol; pa.cia_temp = d_cia_temp;
   pa.iH2 = iH2; pa.iHe = iHe;
@@ -300,6 +300,8 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   RtArgs &r = rt;
   r.L = L; r.M = M; r.Nt = Nt; r.C = C; r.A = A; r.W = Wl;
   r.kappa = d_kappa; r.cia = d_cia; r.wn = d_wn;
+  r.kappa_bytes = (unsigned long long)L * Nt * M * Wl * 8ull;
+  r.cia_bytes = (unsigned long long)cia_planes.size() * 8ull;
   for (int a = 0; a < A; a++) {
     double lo_a = a == 0 ? 0.0 : 0.5 * (angles[a - 1] + angles[a]);
     double hi_a = a == A - 1 ? 90.0 : 0.5 * (angles[a] + angles[a + 1]);

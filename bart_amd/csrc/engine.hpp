@@ -43,7 +43,8 @@ struct Engine {
   // workspaces (grown on demand, never inside a timed launch sequence twice)
   int cap_walkers = 0;
   double *d_prof = nullptr, *d_coef = nullptr, *d_spec = nullptr;
-  int *d_idx = nullptr, *d_kstop = nullptr;
+  idx_t *d_idx = nullptr;
+  int *d_kstop = nullptr;
   double *d_rtop = nullptr, *d_ds = nullptr;  // transit geometry workspaces
   double *d_rad = nullptr;     // [cap][L] hydrostatic radii of the last run
   double *d_intens = nullptr;  // [A][W] of the last single-walker run with want_intens

@@ -16,6 +16,10 @@
 #include <cstdlib>
 #include <string>
 
+#ifndef BARTRT_WPE
+#define BARTRT_WPE 4
+#endif
+
 namespace bartrt {
 
 // ---------------------------------------------------------------------------
@@ -105,11 +109,11 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   __syncthreads();
   const int NC = coef_stride(M, C), NI = idx_stride(C);
   double *coef = p.coef + (size_t)w * L * NC;
-  int *idx = p.idx + (size_t)w * L * NI;
+  idx_t *idx = p.idx + (size_t)w * L * NI;
   for (int k = threadIdx.x; k < L; k += blockDim.x) {
     const int l = L - 1 - k;
     double *c = coef + (size_t)k * NC;
-    int *ix = idx + (size_t)k * NI;
+    idx_t *ix = idx + (size_t)k * NI;
     if (bad) {
       for (int j = 0; j < NC; j++) c[j] = 0.0;
       for (int j = 0; j < NI; j++) ix[j] = 0;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
       j = bracket_dev(p.tgrid, p.Nt, T);
       f = (T - p.tgrid[j]) / (p.tgrid[j + 1] - p.tgrid[j]);
     }
-    ix[0] = j;
+    ix[0] = (idx_t)(((size_t)l * p.Nt + j) * M * p.W) * 8;
     for (int m = 0; m < M; m++) {
       const int s = p.opmol[m];
       const double rho = prof[(size_t)(s + 1) * L + l] * p.mass[s] * kAMU * nd;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
         fc = (Tc - tg[jc]) / (tg[jc + 1] - tg[jc]);
       }
       // a single-temperature table is stored twice so plane jc+1 exists
-      ix[1 + cc] = p.cia_toff[cc] + cc + jc;
+      ix[1 + cc] = (idx_t)(p.cia_toff[cc] + cc + jc) * p.W * 8;
       c[2 + 2 * M + 2 * cc] = n1 * n2 * (1.0 - fc);
       c[3 + 2 * M + 2 * cc] = n1 * n2 * fc;
     }
@@ -208,17 +212,17 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   const int A = AT > 0 ? AT : p.A;
   const int M = MT >= 0 ? MT : p.M;
   const int C = CT >= 0 ? CT : p.C;
-  const int L = p.L, W = p.W, Nt = p.Nt;
+  const int L = p.L, W = p.W;
   const int NC = coef_stride(M, C), NI = idx_stride(C);
   int tile, w;
   block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
-  int *sI = reinterpret_cast<int *>(smem + (size_t)L * NC);
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
   {
     const double *gC = p.coef + (size_t)w * L * NC;
-    const int *gI = p.idx + (size_t)w * L * NI;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
     for (int t = threadIdx.x; t < L * NC; t += blockDim.x) sC[t] = gC[t];
     for (int t = threadIdx.x; t < L * NI; t += blockDim.x) sI[t] = gI[t];
   }
@@ -243,11 +247,11 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   const int kend = p.kstop[w];
   for (int k = 0; k <= kend; ++k) {
     const double *c = sC + k * NC;
-    const int *ix = sI + k * NI;
+    const idx_t *ix = sI + k * NI;
     const int l = L - 1 - k;
     double e = c[2 + 2 * M + 2 * C] * nu4;
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
-    const double *kb = p.kappa + ((size_t)l * Nt + ix[0]) * MW + ii;
+    const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + ii;
 #pragma unroll
     for (int m = 0; m < (MT >= 0 ? MT : kMaxMol); m++) {
       if (MT < 0 && m >= M) break;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
 #pragma unroll
     for (int cc = 0; cc < (CT >= 0 ? CT : kMaxCia); cc++) {
       if (CT < 0 && cc >= C) break;
-      const double *ab = p.cia + (size_t)ix[1 + cc] * W + ii;
+      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + ii;
       e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[W];
     }
     const double dtau = active ? 0.5 * (eprev + e) * c[0] : 0.0;
@@ -332,24 +336,27 @@ __device__ __forceinline__ double rcp_core(double d) {
 }
 
 // Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
-// bases (SGPR) + one 32-bit lane offset for every load, and the next layer's
-// 2M+2C loads issued before the current layer's arithmetic so that a lone wave
-// on a SIMD keeps HBM requests in flight while it computes.
-template <int AT, int MT, int CT>
-__global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
+// bases (SGPR) + one 32-bit lane offset for every load, and a ring of PF layers
+// of 2M+2C loads kept in flight ahead of the arithmetic (the slot a layer has
+// just consumed is refilled with layer k+PF), so that the one or two waves a
+// SIMD holds at small batch sizes cover the HBM latency by themselves.
+template <int AT, int MT, int CT, int PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+void rt_eclipse_fast(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
   constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
-  const int L = p.L, W = p.W, Nt = p.Nt;
+  constexpr int NR = NLD > 0 ? NLD : 1;
+  const int L = p.L, W = p.W;
   int tile, w;
   block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
-  int *sI = reinterpret_cast<int *>(smem + (size_t)L * NC);
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
   {
     const double *gC = p.coef + (size_t)w * L * NC;
-    const int *gI = p.idx + (size_t)w * L * NI;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
     for (int t = threadIdx.x; t < L * NC; t += blockDim.x) sC[t] = gC[t];
     for (int t = threadIdx.x; t < L * NI; t += blockDim.x) sI[t] = gI[t];
   }
@@ -364,46 +371,76 @@ __global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
   const double nu4 = (nu * nu) * (nu * nu);
   const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
 
-  auto load_layer = [&](int k, double (&r)[NLD > 0 ? NLD : 1]) {
-    const int *ix = sI + k * NI;
-    const int l = L - 1 - k;
-    if (M > 0) {
-      const int t0 = __builtin_amdgcn_readfirstlane(ix[0]);
-      const char *row = reinterpret_cast<const char *>(p.kappa) + ((size_t)l * Nt + t0) * planeB;
+  // Loop-invariant 32-bit lane offsets of the 2M+2C values of a layer relative
+  // to that layer's plane base; per layer only the two scalar plane bases change,
+  // so every load is "SGPR base + VGPR offset" with no per-layer vector address
+  // arithmetic.
+  unsigned voff[NR];
 #pragma unroll
-      for (int m = 0; m < M; m++) {
-        r[2 * m] = *reinterpret_cast<const double *>(row + m * rowB + off);
-        r[2 * m + 1] = *reinterpret_cast<const double *>(row + planeB + m * rowB + off);
-      }
+  for (int m = 0; m < M; m++) {
+    voff[2 * m] = off + (unsigned)(m * rowB);
+    voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
+  }
+#pragma unroll
+  for (int cc = 0; cc < C; cc++) {
+    voff[2 * M + 2 * cc] = off;
+    voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
+  }
+  // Buffer loads: 128-bit descriptors over the whole grid / CIA block (built
+  // from wave-uniform values), lane offset in a VGPR, the layer's plane offset
+  // in an SGPR -- no per-layer vector address arithmetic at all.
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0,
+                                                      (int)p.kappa_bytes, 0x00020000);
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0,
+                                                      (int)p.cia_bytes, 0x00020000);
+  auto load_layer = [&](int k, double (&r)[NR]) {
+    const idx_t *ix = sI + k * NI;
+    if (M > 0) {
+      const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
+#pragma unroll
+      for (int j = 0; j < 2 * M; j++)
+        r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
     }
 #pragma unroll
     for (int cc = 0; cc < C; cc++) {
-      const int j = __builtin_amdgcn_readfirstlane(ix[1 + cc]);
-      const char *row = reinterpret_cast<const char *>(p.cia) + (size_t)j * rowB;
-      r[2 * M + 2 * cc] = *reinterpret_cast<const double *>(row + off);
-      r[2 * M + 2 * cc + 1] = *reinterpret_cast<const double *>(row + rowB + off);
+      const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
+      r[2 * M + 2 * cc] = __builtin_bit_cast(
+          double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc], so, 0));
+      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(
+          double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + 1], so, 0));
     }
   };
 
   double I[A], fprev[A];
 #pragma unroll
   for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }  // fprev: E_{a,k-1}
-  double cur[NLD > 0 ? NLD : 1], nxt[NLD > 0 ? NLD : 1];
   double tau = 0.0, eprev = 0.0, Bprev = 0.0;
   bool active = true;
-  int last = 0;
   const int kend = p.kstop[w];
-  load_layer(0, cur);
-  for (int k = 0; k <= kend; ++k) {
-    if (k < kend) load_layer(k + 1, nxt);
-    const double *c = sC + k * NC;
-    double e = c[2 + 2 * M + 2 * C] * nu4;
+
+  // One layer's arithmetic.  Straight-line: layer indices past the end are
+  // clamped and masked instead of branched around, so that inside an unrolled
+  // block the compiler waits (counted vmcnt) on exactly the loads a layer
+  // needs and leaves the younger ones in flight.
+  auto layer = [&](int k, const double (&r)[NR]) {
+    const int kc = k < kend ? k : kend;
+    const bool live = active && k <= kend;
+    // the layer record is read from LDS in one batch (all reads issued
+    // together, one wait); masking by multiplication keeps the reads of the
+    // path length and of c2/T out of conditional blocks
+    const double *c = sC + kc * NC;
+    double cf[NC];
 #pragma unroll
-    for (int j = 0; j < NLD; j++) e = fma(c[2 + j], cur[j], e);
-    const double dtau = active ? 0.5 * (eprev + e) * c[0] : 0.0;
+    for (int j = 0; j < NC; j++) cf[j] = c[j];
+    const double lv = live ? 0.5 : 0.0;
+    double e = cf[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+    for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
+    const double dtau = (eprev + e) * cf[0] * lv;
     tau += dtau;
-    const double B = bnum * rcp_core(exp_core(fmin(c[1] * nu, 700.0)) - 1.0);
-    const double hb = active ? 0.5 * (Bprev + B) : 0.0;
+    const double B = bnum * rcp_core(exp_core(fmin(cf[1] * nu, 700.0)) - 1.0);
+    const double hb = (Bprev + B) * lv;
 #pragma unroll
     for (int a = 0; a < A; a++) {
       const double E = exp_core(fmax(-tau * p.invmu[a], -745.0));
@@ -412,26 +449,48 @@ __global__ __launch_bounds__(256) void rt_eclipse_fast(RtArgs p) {
     }
     Bprev = B;
     eprev = e;
-    if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tau;
-    if (active) {
-      last = k;
-      if (tau > p.toomuch) active = false;
-    }
-    if (!__any(active)) break;
+    active = active && !(live && tau > p.toomuch);
+  };
+  auto clampk = [&](int k) { return k < kend ? k : kend; };
+
+  if (PF <= 1) {
+    // one slot, refilled with the next layer right after it is consumed:
+    // fewest registers, most resident waves (large batches hide latency by
+    // occupancy and mostly hit in L2 anyway)
+    double s0[NR];
+    load_layer(0, s0);
+    for (int k = 0; k <= kend; k++) {
+      double cur[NR];
 #pragma unroll
-    for (int j = 0; j < NLD; j++) cur[j] = nxt[j];
+      for (int j = 0; j < NR; j++) cur[j] = s0[j];
+      load_layer(clampk(k + 1), s0);
+      layer(k, cur);
+      if (!__any(active)) break;
+    }
+  } else {
+    // two pairs of slots; each pair is reloaded two layers before it is used
+    // and the loads that cross the loop's back edge were issued two layers
+    // earlier, so a SIMD holding a single wave still covers the HBM latency
+    double a0[NR], a1[NR], b0[NR], b1[NR];
+    load_layer(clampk(0), a0);
+    load_layer(clampk(1), a1);
+    for (int k0 = 0; k0 <= kend; k0 += 4) {
+      load_layer(clampk(k0 + 2), b0);
+      load_layer(clampk(k0 + 3), b1);
+      layer(k0, a0);
+      layer(k0 + 1, a1);
+      load_layer(clampk(k0 + 4), a0);
+      load_layer(clampk(k0 + 5), a1);
+      layer(k0 + 2, b0);
+      layer(k0 + 3, b1);
+      if (!__any(active)) break;
+    }
   }
   double F = 0.0;
   const bool surf = p.cloud_on && active;
 #pragma unroll
   for (int a = 0; a < A; a++) F += p.wgt[a] * (I[a] + (surf ? Bprev * fprev[a] : 0.0));
-  if (valid) {
-    p.spec[(size_t)w * W + i] = F;
-    if (p.tau_out) {
-      for (int k = last + 1; k < L; k++) p.tau_out[(size_t)i * L + k] = tau;
-      p.last_out[i] = last;
-    }
-  }
+  if (valid) p.spec[(size_t)w * W + i] = F;
 }
 
 // ---------------------------------------------------------------------------
@@ -454,16 +513,26 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   const int ntiles8 = (a.ntiles + 7) / 8 * 8;
   const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * (size_t)a.L * coef_stride(a.M, a.C) +
-                    sizeof(int) * (size_t)a.L * idx_stride(a.C);
+                    sizeof(idx_t) * (size_t)a.L * idx_stride(a.C);
   static const bool generic_only = [] {
     const char *e = std::getenv("BARTRT_KERNEL");  // "generic" forces the fallback (A/B runs)
     return e && std::string(e) == "generic";
   }();
-  if (!generic_only && a.A == 5 && !a.ext && !a.intens_out) {
-#define BARTRT_FAST(MM, CC)                                                        \
-  if (a.M == MM && a.C == CC) {                                                    \
-    hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC>), dim3(nblocks), dim3(block), sh, st, a); \
-    return hipGetLastError();                                                      \
+  // prefetch depth: deep ring when few waves per SIMD must hide HBM latency by
+  // themselves, shallow (fewer registers, more resident waves) for big batches
+  static const int pf_env = [] {
+    const char *e = std::getenv("BARTRT_PF");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int pf = pf_env > 0 ? pf_env : (block == 64 ? 2 : 1);
+  // the specialised kernel addresses the tables through 32-bit buffer offsets
+  const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
+  if (!generic_only && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {
+#define BARTRT_FAST(MM, CC)                                                                      \
+  if (a.M == MM && a.C == CC) {                                                                  \
+    if (pf >= 2) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, 2>), dim3(nblocks), dim3(block), sh, st, a);      \
+    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, 1>), dim3(nblocks), dim3(block), sh, st, a);              \
+    return hipGetLastError();                                                                    \
   }
     BARTRT_FAST(1, 0) BARTRT_FAST(1, 1) BARTRT_FAST(1, 2)
     BARTRT_FAST(2, 0) BARTRT_FAST(2, 1) BARTRT_FAST(2, 2)

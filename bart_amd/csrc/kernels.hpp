@@ -27,11 +27,14 @@ constexpr int kMaxMol = 16;
 //   [.. +2C)       (n1 n2 (1-f), n1 n2 f) / amagat^2 per CIA table
 //   [last]         Rayleigh coefficient (multiplies wn^4)
 __host__ __device__ inline int coef_stride(int M, int C) { return 3 + 2 * M + 2 * C; }
-// Integer record: [0] table temperature index, [1+c] first CIA plane of pair c.
+// Offset record (64-bit BYTE offsets, so the kernels add one scalar to a base
+// pointer per layer): [0] start of the (layer, lower temperature) plane of the
+// opacity grid, [1+c] start of the lower CIA plane of pair c.
+using idx_t = long long;
 __host__ __device__ inline int idx_stride(int C) { return 1 + C; }
 
 struct PrepArgs {
-  int L, S, M, Nt, C, nwalkers;
+  int L, S, M, Nt, C, W, nwalkers;
   const double *prof;      // [nw][(S+1)][L]
   const double *press;     // [L] barye, atm order (0 = bottom)
   const double *dlnp;      // [L-1] log(p[i]/p[i+1])
@@ -52,7 +55,7 @@ struct PrepArgs {
   double scat_value, cloudtop;
   // outputs
   double *coef;            // [nw][L][coef_stride]
-  int *idx;                // [nw][L][idx_stride]
+  idx_t *idx;              // [nw][L][idx_stride]
   int *kstop;              // [nw] deepest layer index k to integrate to
   unsigned char *ok;       // [nw]
   double *rad_out;         // optional [nw][L] hydrostatic radii, cm, atm layer order
@@ -66,10 +69,11 @@ struct RtArgs {
   int L, M, Nt, C, A, W, nwalkers, ntiles;
   const double *kappa;     // [L][Nt][M][W]
   const double *cia;       // [planes][W]
+  unsigned long long kappa_bytes, cia_bytes;  // extents of the two tables
   const double *ext;       // optional line-by-line extinction [nw][L][W] (atm layer order)
   const double *wn;        // [W]
   const double *coef;
-  const int *idx;
+  const idx_t *idx;
   const int *kstop;
   int cloud_on;            // kstop marks a cloud deck (adds surface emission)
   double toomuch;

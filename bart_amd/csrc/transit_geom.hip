@@ -17,7 +17,7 @@ namespace bartrt {
 
 __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   extern __shared__ double smem[];
-  const int M = p.M, C = p.C, L = p.L, W = p.W, Nt = p.Nt;
+  const int M = p.M, C = p.C, L = p.L, W = p.W;
   const int NC = coef_stride(M, C), NI = idx_stride(C);
   const int b = blockIdx.x;
   const int xcd = b & 7, jb = b >> 3;
@@ -26,12 +26,12 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
-  int *sI = reinterpret_cast<int *>(smem + (size_t)L * NC);
-  // pair sums, [L][64], 8-byte aligned after the int block
-  double *sP = smem + (size_t)L * NC + ((size_t)L * NI + 1) / 2;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  // pair sums, [L][64], after the offset records
+  double *sP = smem + (size_t)L * NC + (size_t)L * NI;
   {
     const double *gC = p.coef + (size_t)w * L * NC;
-    const int *gI = p.idx + (size_t)w * L * NI;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
     for (int t = threadIdx.x; t < L * NC; t += 64) sC[t] = gC[t];
     for (int t = threadIdx.x; t < L * NI; t += 64) sI[t] = gI[t];
   }
@@ -52,15 +52,15 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   int last = 0;
   for (int k = 0; k <= kend; ++k) {
     const double *c = sC + k * NC;
-    const int *ix = sI + k * NI;
+    const idx_t *ix = sI + k * NI;
     const int l = L - 1 - k;
     double e = c[2 + 2 * M + 2 * C] * nu4;
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
-    const double *kb = p.kappa + ((size_t)l * Nt + ix[0]) * MW + ii;
+    const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + ii;
     for (int m = 0; m < M; m++)
       e += c[2 + 2 * m] * kb[(size_t)m * W] + c[3 + 2 * m] * kb[MW + (size_t)m * W];
     for (int cc = 0; cc < C; cc++) {
-      const double *ab = p.cia + (size_t)ix[1 + cc] * W + ii;
+      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + ii;
       e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[W];
     }
     if (k > 0) {
@@ -97,7 +97,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   const int ntiles8 = (a.ntiles + 7) / 8 * 8;
   const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
-                                      ((size_t)a.L * idx_stride(a.C) + 1) / 2 + (size_t)a.L * 64);
+                                      (size_t)a.L * idx_stride(a.C) + (size_t)a.L * 64);
   if (sh > 160 * 1024) return hipErrorInvalidValue;
   if (sh > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_transit),

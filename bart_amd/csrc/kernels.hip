@@ -524,7 +524,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const char *e = std::getenv("BARTRT_PF");
     return e ? std::atoi(e) : 0;
   }();
-  const int pf = pf_env > 0 ? pf_env : (block == 64 ? 2 : 1);
+  const int pf = pf_env > 0 ? pf_env : 2;  // measured: the paired ring wins at every batch size
   // the specialised kernel addresses the tables through 32-bit buffer offsets
   const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
   if (!generic_only && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {

@@ -20,6 +20,9 @@
 #define BARTRT_WPE 4
 #endif
 
+// split (producer/consumer) kernel below this many 64-wavenumber columns per launch
+constexpr long kSplitMaxColumns = 640;  // measured crossover: ~4 walkers at W = 1e4
+
 namespace bartrt {
 
 // ---------------------------------------------------------------------------
@@ -335,6 +338,33 @@ __device__ __forceinline__ double rcp_core(double d) {
   return fma(y, e, y);
 }
 
+// exp() of N independent arguments with the Horner steps interleaved across
+// the arguments: one wave alone on a SIMD then overlaps the N dependent FMA
+// chains instead of paying the fp64 pipeline latency N x 12 times in a row.
+template <int N>
+__device__ __forceinline__ void exp_core_n(const double (&x)[N], double (&out)[N]) {
+  double n[N], r[N], q[N];
+#pragma unroll
+  for (int a = 0; a < N; a++) {
+    n[a] = __builtin_rint(x[a] * 1.4426950408889634074);
+    r[a] = fma(n[a], -6.93147180369123816490e-01, x[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < N; a++) r[a] = fma(n[a], -1.90821492927058770002e-10, r[a]);
+  constexpr double cf[11] = {2.763263963904103e-07, 2.755724091857897e-06, 2.4801485482328494e-05,
+                             0.00019841269890047113, 0.0013888888952314775, 0.008333333333319601,
+                             0.0416666666664881, 0.1666666666666668, 0.5000000000000019, 1.0, 1.0};
+#pragma unroll
+  for (int a = 0; a < N; a++) q[a] = 2.5110037605963777e-08;
+#pragma unroll
+  for (int j = 0; j < 11; j++) {
+#pragma unroll
+    for (int a = 0; a < N; a++) q[a] = fma(q[a], r[a], cf[j]);
+  }
+#pragma unroll
+  for (int a = 0; a < N; a++) out[a] = __builtin_amdgcn_ldexp(q[a], (int)n[a]);
+}
+
 // Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
 // bases (SGPR) + one 32-bit lane offset for every load, and a ring of PF layers
 // of 2M+2C loads kept in flight ahead of the arithmetic (the slot a layer has
@@ -439,13 +469,18 @@ void rt_eclipse_fast(RtArgs p) {
     for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
     const double dtau = (eprev + e) * cf[0] * lv;
     tau += dtau;
-    const double B = bnum * rcp_core(exp_core(fmin(cf[1] * nu, 700.0)) - 1.0);
+    // Planck exponent and the A slant-path exponents in one interleaved batch
+    double xs[A + 1], es[A + 1];
+    xs[A] = fmin(cf[1] * nu, 700.0);
+#pragma unroll
+    for (int a = 0; a < A; a++) xs[a] = fmax(-tau * p.invmu[a], -745.0);
+    exp_core_n<A + 1>(xs, es);
+    const double B = bnum * rcp_core(es[A] - 1.0);
     const double hb = (Bprev + B) * lv;
 #pragma unroll
     for (int a = 0; a < A; a++) {
-      const double E = exp_core(fmax(-tau * p.invmu[a], -745.0));
-      I[a] = fma(hb, fprev[a] - E, I[a]);
-      fprev[a] = E;
+      I[a] = fma(hb, fprev[a] - es[a], I[a]);
+      fprev[a] = es[a];
     }
     Bprev = B;
     eprev = e;
@@ -493,6 +528,180 @@ void rt_eclipse_fast(RtArgs p) {
   if (valid) p.spec[(size_t)w * W + i] = F;
 }
 
+// Few-walker variant (1-4 walkers at W = 1e4): the layer loop is split over TWO
+// waves per 64 wavenumbers.  Wave 0 (producer) streams the tables and advances
+// the optical depth and the Planck term; wave 1 (consumer) turns each tau into
+// the A transmittances and accumulates the intensities.  The halves are about
+// equal in issue slots, so the serial time per layer halves at unchanged total
+// work -- it pays only while most SIMDs hold no wave at all (1 walker: 40 vs
+// 53 us; from ~8 walkers on the single-wave kernel is as fast or faster).
+// Hand-off: an LDS ring of two 4-layer halves [tau, (B_{k-1}+B_k)/2 * live]
+// per lane and ONE raw workgroup barrier per 4 layers (the consumer reads half
+// b while the producer fills half b+1).
+template <int AT, int MT, int CT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+void rt_eclipse_split(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NR = NLD > 0 ? NLD : 1;
+  const int L = p.L, W = p.W;
+  int tile, w;
+  block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  double *sX = smem + (size_t)L * NC + (size_t)L * NI;  // [2 halves][4 layers][tau, hb][64]
+  int *sFlag = reinterpret_cast<int *>(sX + 1024);      // [half] producer saw every lane finished
+  double *sEnd = sX + 1024 + 2;                         // [64] B of the last layer (cloud deck term)
+  {
+    const double *gC = p.coef + (size_t)w * L * NC;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
+    for (int t = threadIdx.x; t < L * NC; t += 128) sC[t] = gC[t];
+    for (int t = threadIdx.x; t < L * NI; t += 128) sI[t] = gI[t];
+    if (threadIdx.x < 2) sFlag[threadIdx.x] = 0;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
+  const int i = tile * 64 + lane;
+  const bool valid = i < W;
+  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
+  const int kend = p.kstop[w];
+  const int nblk = kend / 4 + 1;  // 4-layer blocks; both waves run the same count
+
+  if (role == 0) {
+    // ---------------- producer: extinction, tau, Planck ----------------
+    const unsigned off = ii * 8u;
+    const double nu = p.wn[ii];
+    const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+    const double nu4 = (nu * nu) * (nu * nu);
+    const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
+    unsigned voff[NR];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      voff[2 * m] = off + (unsigned)(m * rowB);
+      voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      voff[2 * M + 2 * cc] = off;
+      voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
+    }
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0,
+                                                        (int)p.kappa_bytes, 0x00020000);
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0,
+                                                        (int)p.cia_bytes, 0x00020000);
+    auto load_layer = [&](int k, double (&r)[NR]) {
+      const idx_t *ix = sI + k * NI;
+      if (M > 0) {
+        const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
+#pragma unroll
+        for (int j = 0; j < 2 * M; j++)
+          r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
+      }
+#pragma unroll
+      for (int cc = 0; cc < C; cc++) {
+        const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
+        r[2 * M + 2 * cc] = __builtin_bit_cast(
+            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc], so, 0));
+        r[2 * M + 2 * cc + 1] = __builtin_bit_cast(
+            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + 1], so, 0));
+      }
+    };
+    double tau = 0.0, eprev = 0.0, Bprev = 0.0;
+    bool active = true;
+    auto layer = [&](int k, const double (&r)[NR]) {
+      const int kc = k < kend ? k : kend;
+      const bool live = active && k <= kend;
+      const double *c = sC + kc * NC;
+      double cf[NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) cf[j] = c[j];
+      const double lv = live ? 0.5 : 0.0;
+      double e = cf[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+      for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
+      tau += (eprev + e) * cf[0] * lv;
+      const double B = bnum * rcp_core(exp_core(fmin(cf[1] * nu, 700.0)) - 1.0);
+      double *slot = sX + (k & 7) * 128;   // half (k/4)&1, layer k&3
+      slot[lane] = tau;
+      slot[64 + lane] = (Bprev + B) * lv;
+      Bprev = B;
+      eprev = e;
+      active = active && !(live && tau > p.toomuch);
+    };
+    // LDS writes of a 4-layer block complete, then meet the consumer (raw
+    // barrier: a __syncthreads() fence would also drain the table loads in flight)
+    auto handoff = [&]() {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    auto clampk = [&](int k) { return k < kend ? k : kend; };
+    double a0[NR], a1[NR], b0[NR], b1[NR];
+    load_layer(clampk(0), a0);
+    load_layer(clampk(1), a1);
+    for (int blk = 0; blk < nblk; blk++) {
+      const int k0 = blk * 4;
+      load_layer(clampk(k0 + 2), b0);
+      load_layer(clampk(k0 + 3), b1);
+      layer(k0, a0);
+      layer(k0 + 1, a1);
+      load_layer(clampk(k0 + 4), a0);
+      load_layer(clampk(k0 + 5), a1);
+      layer(k0 + 2, b0);
+      layer(k0 + 3, b1);
+      // the exit decision travels with the block, so both waves leave after
+      // the same barrier
+      const bool stop = !__any(active);
+      if (lane == 0) sFlag[blk & 1] = stop ? 1 : 0;
+      handoff();
+      if (stop) break;
+    }
+    sEnd[lane] = (p.cloud_on && active) ? Bprev : 0.0;
+    handoff();
+  } else {
+    // ---------------- consumer: transmittances and intensities ----------------
+    double I[A], fprev[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }
+    for (int blk = 0; blk < nblk; blk++) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int stop = sFlag[blk & 1];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double *slot = sX + ((blk & 1) * 4 + u) * 128;
+        const double tau = slot[lane], hb = slot[64 + lane];
+        double xs[A], es[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) xs[a] = fmax(-tau * p.invmu[a], -745.0);
+        exp_core_n<A>(xs, es);
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+          I[a] = fma(hb, fprev[a] - es[a], I[a]);
+          fprev[a] = es[a];
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane(stop)) break;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const double bsurf = sEnd[lane];
+    double F = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; a++) F += p.wgt[a] * (I[a] + bsurf * fprev[a]);
+    if (valid) p.spec[(size_t)w * W + i] = F;
+  }
+}
+
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
@@ -514,20 +723,39 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * (size_t)a.L * coef_stride(a.M, a.C) +
                     sizeof(idx_t) * (size_t)a.L * idx_stride(a.C);
-  static const bool generic_only = [] {
-    const char *e = std::getenv("BARTRT_KERNEL");  // "generic" forces the fallback (A/B runs)
-    return e && std::string(e) == "generic";
+  static const std::string kmode = [] {
+    const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split (A/B runs)
+    return std::string(e ? e : "");
   }();
-  // prefetch depth: deep ring when few waves per SIMD must hide HBM latency by
-  // themselves, shallow (fewer registers, more resident waves) for big batches
   static const int pf_env = [] {
     const char *e = std::getenv("BARTRT_PF");
     return e ? std::atoi(e) : 0;
   }();
   const int pf = pf_env > 0 ? pf_env : 2;  // measured: the paired ring wins at every batch size
-  // the specialised kernel addresses the tables through 32-bit buffer offsets
+  // the specialised kernels address the tables through 32-bit buffer offsets
   const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
-  if (!generic_only && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {
+  if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {
+    // few walkers: not enough single-wave columns to fill 1024 SIMDs -> two
+    // waves per 64 wavenumbers (producer / consumer)
+    const long columns = (long)a.nwalkers * ((a.W + 63) / 64);
+    const bool split = kmode == "split" || (kmode != "mono" && columns <= kSplitMaxColumns);
+    if (split) {
+      RtArgs b = a;
+      b.ntiles = (a.W + 63) / 64;
+      const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+      const size_t shs = sh + sizeof(double) * (1024 + 2 + 64);
+#define BARTRT_SPLIT(MM, CC)                                                                     \
+  if (a.M == MM && a.C == CC) {                                                                  \
+    hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC>), dim3(nb), dim3(128), shs, st, b);          \
+    return hipGetLastError();                                                                    \
+  }
+      BARTRT_SPLIT(1, 0) BARTRT_SPLIT(1, 1) BARTRT_SPLIT(1, 2)
+      BARTRT_SPLIT(2, 0) BARTRT_SPLIT(2, 1) BARTRT_SPLIT(2, 2)
+      BARTRT_SPLIT(3, 0) BARTRT_SPLIT(3, 1) BARTRT_SPLIT(3, 2)
+      BARTRT_SPLIT(4, 0) BARTRT_SPLIT(4, 1) BARTRT_SPLIT(4, 2)
+      BARTRT_SPLIT(5, 1) BARTRT_SPLIT(6, 1)
+#undef BARTRT_SPLIT
+    }
 #define BARTRT_FAST(MM, CC)                                                                      \
   if (a.M == MM && a.C == CC) {                                                                  \
     if (pf >= 2) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, 2>), dim3(nblocks), dim3(block), sh, st, a);      \

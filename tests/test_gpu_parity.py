@@ -118,25 +118,49 @@ def test_kernel_variants_match_oracle(tmp_path, kw):
         trm.free_memory()
 
 
-def test_generic_kernel_agrees_with_specialised(small_case, monkeypatch):
-    """BARTRT_KERNEL=generic is read once per process: run it in a child."""
+@pytest.mark.parametrize("mode", ["generic", "mono", "split"])
+def test_every_kernel_variant_matches_oracle(small_case, mode):
+    """The three RT kernels (generic fallback, single-wave specialised,
+    producer/consumer split) on the same batch.  BARTRT_KERNEL is read once per
+    process, so each variant runs in a child."""
     import subprocess, sys, os
-    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
     c = small_case
-    profs = walkers(c, 2, seed=8)
+    profs = walkers(c, 5, seed=8)
     np.save(os.path.join(c.dir, "p.npy"), profs)
+    out = os.path.join(c.dir, "s_%s.npy" % mode)
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
             "from bart_amd import engine, transit_module as trm\n"
             "engine.init(%r); s = engine.run_batch(np.load(%r)); np.save(%r, s); trm.free_memory()\n"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), c.tcfg,
-               os.path.join(c.dir, "p.npy"), os.path.join(c.dir, "s_generic.npy")))
-    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_KERNEL="generic"))
-    engine.init(c.tcfg)
-    try:
-        fast = engine.run_batch(profs)
-    finally:
-        trm.free_memory()
-    np.testing.assert_allclose(fast, np.load(os.path.join(c.dir, "s_generic.npy")), rtol=1e-12)
+               os.path.join(c.dir, "p.npy"), out))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_KERNEL=mode),
+                          timeout=300)
+    ref = orc.OracleEngine(c.tcfg).run_batch(profs)
+    np.testing.assert_allclose(np.load(out), ref, rtol=RTOL)
+
+
+def test_cloud_deck_through_every_kernel(small_case):
+    """The surface term of an opaque deck takes a different route in each kernel."""
+    import subprocess, sys, os
+    from oracle import rt_oracle as orc
+    c = small_case
+    profs = walkers(c, 3, seed=12)
+    np.save(os.path.join(c.dir, "pc.npy"), profs)
+    o = orc.OracleEngine(c.tcfg)
+    o.set_cloudtop(-1.0)
+    ref = o.run_batch(profs)
+    for mode in ("generic", "mono", "split"):
+        out = os.path.join(c.dir, "sc_%s.npy" % mode)
+        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+                "from bart_amd import engine, transit_module as trm\n"
+                "engine.init(%r); trm.set_cloudtop(-1.0)\n"
+                "s = engine.run_batch(np.load(%r)); np.save(%r, s); trm.free_memory()\n"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), c.tcfg,
+                   os.path.join(c.dir, "pc.npy"), out))
+        subprocess.check_call([sys.executable, "-c", code],
+                              env=dict(os.environ, BARTRT_KERNEL=mode), timeout=300)
+        np.testing.assert_allclose(np.load(out), ref, rtol=RTOL)
 
 
 def test_shards_reassemble_full_spectrum(small_case):

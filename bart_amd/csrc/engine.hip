@@ -294,7 +294,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   }
   pa.L = L; pa.S = S; pa.M = M; pa.Nt = Nt; pa.C = C; pa.W = Wl;
   pa.press = d_press; pa.dlnp = d_dlnp; pa.mass = d_mass; pa.tgrid = d_tgrid;
-  pa.opmol = d_opmol; pa.cia_temp = d_cia_temp;
+  pa.opmol = d_opmol; pa.cia_temp = d_cia_temp; pa.ncia_temps = (int)cia_temp.size();
   pa.iH2 = iH2; pa.iHe = iHe;
 
   RtArgs &r = rt;

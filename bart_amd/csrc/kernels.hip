@@ -44,14 +44,35 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   double *sMu = sm + L;      // mean molecular mass
   double *sR = sm + 2 * L;   // radius
   const int w = blockIdx.x;
-  const double *prof = p.prof + (size_t)w * (S + 1) * L;
+  // Everything this kernel reads from HBM (the walker's profile and the few
+  // small constant arrays) is pulled into LDS in ONE batch of independent
+  // loads; the phases below then run out of LDS.  The kernel is pure latency:
+  // each dependent trip to memory it avoids is worth a microsecond.
+  double *sProf = sm + 4 * L;                       // [(S+1)][L]
+  double *sPress = sProf + (size_t)(S + 1) * L;     // [L]
+  double *sDlnp = sPress + L;                       // [L]
+  double *sMass = sDlnp + L;                        // [S]
+  double *sTg = sMass + S;                          // [Nt]
+  double *sCiaT = sTg + p.Nt;                       // [ncia_temps]
+  {
+    const double *gp = p.prof + (size_t)w * (S + 1) * L;
+    for (int t = threadIdx.x; t < (S + 1) * L; t += blockDim.x) sProf[t] = gp[t];
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+      sPress[t] = p.press[t];
+      sDlnp[t] = t + 1 < L ? p.dlnp[t] : 0.0;
+    }
+    for (int t = threadIdx.x; t < S; t += blockDim.x) sMass[t] = p.mass[t];
+    for (int t = threadIdx.x; t < p.Nt; t += blockDim.x) sTg[t] = p.tgrid[t];
+    for (int t = threadIdx.x; t < p.ncia_temps; t += blockDim.x) sCiaT[t] = p.cia_temp[t];
+  }
+  const double *prof = sProf;
   __shared__ int sBad;
   if (threadIdx.x == 0) sBad = 0;
   __syncthreads();
   for (int l = threadIdx.x; l < L; l += blockDim.x) {
     double T = prof[l];
     double mu = 0.0;
-    for (int s = 0; s < S; s++) mu += prof[(size_t)(s + 1) * L + l] * p.mass[s];
+    for (int s = 0; s < S; s++) mu += prof[(size_t)(s + 1) * L + l] * sMass[s];
     sT[l] = T;
     sMu[l] = mu;
     if (!(T > 0.0) || !(T < 1e30) || !(mu > 0.0)) sBad = 1;
@@ -68,7 +89,7 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
     const double rgas = kKB / kAMU;
     const double invG = 1.0 / (p.gsurf * p.refradius * p.refradius);
     for (int i = threadIdx.x; i + 1 < L; i += blockDim.x)
-      sH[i] = 0.5 * (sT[i] / sMu[i] + sT[i + 1] / sMu[i + 1]) * (rgas * p.dlnp[i]) * invG;
+      sH[i] = 0.5 * (sT[i] / sMu[i] + sT[i + 1] / sMu[i + 1]) * (rgas * sDlnp[i]) * invG;
     if (threadIdx.x == 0 && !bad) {
       const int ix = p.ref_idx;
       const double r0 = p.refradius, g0 = p.gsurf;
@@ -124,25 +145,25 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
       continue;
     }
     const double T = sT[l];
-    const double nd = p.press[l] / (kKB * T);
+    const double nd = sPress[l] / (kKB * T);
     c[0] = (k == 0) ? 0.0 : (sR[l + 1] - sR[l]);
     c[1] = (kH * kLS / kKB) / T;
     int j = 0;
     double f = 0.0;
     if (M > 0) {
-      j = bracket_dev(p.tgrid, p.Nt, T);
-      f = (T - p.tgrid[j]) / (p.tgrid[j + 1] - p.tgrid[j]);
+      j = bracket_dev(sTg, p.Nt, T);
+      f = (T - sTg[j]) / (sTg[j + 1] - sTg[j]);
     }
     ix[0] = (idx_t)(((size_t)l * p.Nt + j) * M * p.W) * 8;
     for (int m = 0; m < M; m++) {
       const int s = p.opmol[m];
-      const double rho = prof[(size_t)(s + 1) * L + l] * p.mass[s] * kAMU * nd;
+      const double rho = prof[(size_t)(s + 1) * L + l] * sMass[s] * kAMU * nd;
       c[2 + 2 * m] = rho * (1.0 - f);
       c[3 + 2 * m] = rho * f;
     }
     for (int cc = 0; cc < C; cc++) {
       const int nt = p.cia_nt[cc];
-      const double *tg = p.cia_temp + p.cia_toff[cc];
+      const double *tg = sCiaT + p.cia_toff[cc];
       const double Tc = T < tg[0] ? tg[0] : (T > tg[nt - 1] ? tg[nt - 1] : T);
       const double n1 = prof[(size_t)(p.cia_s1[cc] + 1) * L + l] * nd / kAMAGAT;
       const double n2 = prof[(size_t)(p.cia_s2[cc] + 1) * L + l] * nd / kAMAGAT;
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
     int ks = L - 1;
     if (p.has_cloud) {
       for (int k = 0; k < L; k++)
-        if (p.press[L - 1 - k] >= p.cloudtop) { ks = k; break; }
+        if (sPress[L - 1 - k] >= p.cloudtop) { ks = k; break; }
     }
     p.kstop[w] = ks;
     if (p.ok) p.ok[w] = bad ? 0 : 1;
@@ -705,7 +726,8 @@ void rt_eclipse_split(RtArgs p) {
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
-  size_t sh = sizeof(double) * 4 * a.L;
+  size_t sh = sizeof(double) * ((size_t)4 * a.L + (size_t)(a.S + 1) * a.L + 2 * a.L + a.S + a.Nt +
+                               a.ncia_temps + 1);
   hipLaunchKernelGGL(prep_profiles, dim3(a.nwalkers), dim3(128), sh, st, a);
   return hipGetLastError();
 }

@@ -43,6 +43,7 @@ struct PrepArgs {
   const int *opmol;        // [M] species index
   int cia_s1[kMaxCia], cia_s2[kMaxCia], cia_nt[kMaxCia], cia_toff[kMaxCia];
   const double *cia_temp;  // concatenated
+  int ncia_temps;          // length of cia_temp
   // hydrostatic reference (code/makeatm.py:183-263)
   int ref_idx;             // layer closest to refpress
   int ref_exact;           // press[ref_idx] == refpress

@@ -124,11 +124,18 @@ def run_batch_sharded(d_prof, group=None):
     return allgather_blocks(local, group, total=trm.get_no_samples())
 
 
-def allgather_blocks(local, group=None, total=None):
+def allgather_blocks(local, group=None, total=None, async_op=False, out=None):
     """local [n, W_r] on rank r (block sizes may differ by one sample) ->
     [n, sum_r W_r] on every rank.  With ``total`` (the full sample count) the
     block sizes follow from the engine's integer split W*r//n and ONE collective
-    per call is issued; without it the sizes are exchanged first."""
+    per call is issued; without it the sizes are exchanged first.
+
+    ``async_op=True`` returns ``(work, finish)``: the collective is enqueued on
+    RCCL's stream behind the kernels already queued on the current stream, the
+    current stream is NOT made to wait, and ``finish()`` (wait + reassembly) is
+    called when the spectra are needed -- so the next batch's kernels overlap
+    the xGMI traffic of this one.  ``out`` may supply the [world*n, wmax]
+    receive buffer (double buffering)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -146,12 +153,19 @@ def allgather_blocks(local, group=None, total=None):
     if local.shape[1] != wmax:
         send = torch.zeros((n, wmax), dtype=local.dtype, device=local.device)
         send[:, :local.shape[1]] = local
-    out = torch.empty((world * n, wmax), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
-    out = out.view(world, n, wmax)
-    if min(sizes) == wmax:
-        return out.permute(1, 0, 2).reshape(n, world * wmax)
-    return torch.cat([out[r, :, :sizes[r]] for r in range(world)], dim=1)
+    if out is None:
+        out = torch.empty((world * n, wmax), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, send.contiguous(), group=group, async_op=async_op)
+
+    def finish():
+        if work is not None:
+            work.wait()                      # the current stream waits; the host does not
+        o = out.view(world, n, wmax)
+        if min(sizes) == wmax:
+            return o.permute(1, 0, 2).reshape(n, world * wmax)
+        return torch.cat([o[r, :, :sizes[r]] for r in range(world)], dim=1)
+
+    return (work, finish) if async_op else finish()
 
 
 # ---- per-step converters --------------------------------------------------

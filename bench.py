@@ -134,16 +134,37 @@ def main():
         nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
         profs_h = make_profiles(case, nwalk * nsets, seed=20260103).reshape(nsets, nwalk, -1)
         d_prof = torch.from_numpy(profs_h).to(dev)
-        d_local = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
+        # two sets of buffers: on N > 1 the all-gather of step i runs on RCCL's
+        # stream while the kernels of step i+1 run on the compute stream
+        d_local = [torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev) for _ in range(2)]
+        wmax = -(-a.nwave // world)           # largest block of the integer split
+        recv = [torch.empty((world * nwalk, wmax), dtype=torch.float64, device=dev)
+                for _ in range(2)] if use_dist else None
+        pending = [None, None]
 
         def step(i):
-            engine.run_batch_dev(d_prof[i % nsets], d_local)
+            b = i & 1
+            out_prev = None
+            if use_dist and pending[b] is not None:
+                out_prev = pending[b]()              # spectra of step i-2, reassembled
+                pending[b] = None
+            engine.run_batch_dev(d_prof[i % nsets], d_local[b])
             if use_dist:
-                return engine.allgather_blocks(d_local, total=a.nwave)
-            return d_local
+                _, pending[b] = engine.allgather_blocks(d_local[b], total=a.nwave, async_op=True,
+                                                        out=recv[b])
+                return out_prev
+            return d_local[b]
 
+        def drain():
+            outs = [f() for f in pending if f is not None]
+            pending[0] = pending[1] = None
+            return outs
+
+        out = None
         for i in range(warmup):
             out = step(i)
+        if use_dist:
+            out = (drain() or [out])[-1]
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -152,7 +173,10 @@ def main():
             engine.timing_begin()
         t0 = time.perf_counter()
         for i in range(steps):
-            out = step(i)
+            o = step(i)
+            out = o if o is not None else out
+        if use_dist:
+            out = (drain() or [out])[-1]
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

@@ -309,7 +309,14 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     r.wgt[a] = kPI * (sh * sh - sl * sl);
     r.invmu[a] = 1.0 / std::cos(angles[a] * kPI / 180.0);
   }
-  if (!have_table && cfg_has(cfg, "linedb")) lbl_init(*this, cfg["linedb"]);
+  if (!have_table && cfg_has(cfg, "linedb")) {
+    lbl_init(*this, cfg["linedb"]);
+    const char *m = std::getenv("BARTRT_LBL");
+    // measured on the config-5 shape (tools/lbl_bench.py): tiles rarely turn opaque
+    // as a whole, so the lazy fused kernel (55 ms) loses to the eager two-pass form
+    // (43 ms) that exposes all layers as parallel work; BARTRT_LBL=lazy selects it
+    lbl_eager = !(m && std::string(m) == "lazy");
+  }
   HIPCHK(hipMalloc(&d_tau, sizeof(double) * (size_t)Wl * L));
   HIPCHK(hipMalloc(&d_last, sizeof(int) * (size_t)Wl));
   ensure_walkers(16);
@@ -349,8 +356,15 @@ void Engine::ensure_pin(size_t bytes) {
 void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
                      unsigned char *d_okp, hipStream_t st, bool want_tau) {
   if (n <= 0) return;
+  if (lbl && solution == 0 && !want_tau && !want_intens && !lbl_eager) {
+    // lazy fused path: layers' line sums are evaluated only as deep as the
+    // optical depth requires
+    run_chunk(d_prof_in, n, d_spec_out, d_okp, st, false, nullptr, true);
+    return;
+  }
   if (lbl) {
-    // line-by-line extinction needs [walkers][L][W] doubles: bounded chunks
+    // eager path (optical-depth / intensity outputs, transit geometry):
+    // [walkers][L][W] extinction first, in bounded chunks
     const size_t per = (size_t)L * W() * sizeof(double);
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)2 << 30) / per));
     const int nprof = (S + 1) * L;
@@ -366,7 +380,8 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
 }
 
 void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
-                       unsigned char *d_okp, hipStream_t st, bool want_tau, const double *d_ext) {
+                       unsigned char *d_okp, hipStream_t st, bool want_tau, const double *d_ext,
+                       bool lbl_fused) {
   // coefficient workspaces are sized by cap_walkers; the caller's profile and
   // spectrum buffers are used in place
   if (n > cap_walkers) ensure_walkers(n);
@@ -410,7 +425,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     }
     HIPCHK(hipEventRecord(ev[ev_used], st));
   }
-  if (solution == 1) HIPCHK(launch_transit(r, st));
+  if (lbl_fused) lbl_rt_eclipse(*this, d_prof_in, n, r, st);
+  else if (solution == 1) HIPCHK(launch_transit(r, st));
   else HIPCHK(launch_rt(r, block, st));
   if (timing) {
     HIPCHK(hipEventRecord(ev[ev_used + 1], st));

@@ -49,6 +49,7 @@ struct Engine {
   double *d_rad = nullptr;     // [cap][L] hydrostatic radii of the last run
   double *d_intens = nullptr;  // [A][W] of the last single-walker run with want_intens
   bool want_intens = false;
+  bool lbl_eager = true;       // full extinction first (default); BARTRT_LBL=lazy: fused kernel
   unsigned char *d_ok = nullptr;
   double *d_tau = nullptr;  // [W][L] of the last single-walker run
   int *d_last = nullptr;
@@ -73,7 +74,7 @@ struct Engine {
   void run_dev(const double *d_prof_in, int n, double *d_spec_out, unsigned char *d_okp,
                hipStream_t st, bool want_tau);
   void run_chunk(const double *d_prof_in, int n, double *d_spec_out, unsigned char *d_okp,
-                 hipStream_t st, bool want_tau, const double *d_ext);
+                 hipStream_t st, bool want_tau, const double *d_ext, bool lbl_fused = false);
 };
 
 struct HipError {

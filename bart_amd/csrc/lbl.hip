@@ -225,11 +225,124 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
   }
 }
 
+// Fused lazy line-by-line + eclipse RT (see lbl.hpp).  One workgroup of 256
+// lanes per (wavenumber tile, walker); same per-layer arithmetic as
+// rt_eclipse, with the layer's line sum computed in place.
+__global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *state,
+                                                         const double *smax, RtArgs p) {
+  extern __shared__ double smem[];
+  __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
+  const int C = p.C, L = p.L, W = p.W, A = p.A;
+  const int NC = coef_stride(0, C), NI = idx_stride(C);
+  const int w = blockIdx.y;
+  const int tile0 = blockIdx.x * 256;
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  {
+    const double *gC = p.coef + (size_t)w * L * NC;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
+    for (int t = threadIdx.x; t < L * NC; t += 256) sC[t] = gC[t];
+    for (int t = threadIdx.x; t < L * NI; t += 256) sI[t] = gI[t];
+  }
+  __syncthreads();
+  const int i = tile0 + threadIdx.x;
+  const bool valid = i < W;
+  const int ii = valid ? i : W - 1;
+  const double nu = p.wn[ii];
+  const double nu_a = p.wn[tile0], nu_b = p.wn[min(tile0 + 255, W - 1)];
+  const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+  const double nu4 = (nu * nu) * (nu * nu);
+  double I[kMaxAngles], fprev[kMaxAngles];
+#pragma unroll
+  for (int a = 0; a < kMaxAngles; a++) { I[a] = 0.0; fprev[a] = 1.0; }
+  double tau = 0.0, eprev = 0.0, Bprev = 0.0;
+  bool active = true;
+  const int kend = p.kstop[w];
+  for (int k = 0; k <= kend; ++k) {
+    const int l = L - 1 - k;
+    const int st = w * L + l;
+    const double *sv = state + (size_t)st * (2 + 3 * d.niso);
+    const double T = sv[0];
+    double acc = 0.0;
+    for (int g = 0; g < d.ngroup; g++) {
+      double cmax = 0.0;
+      for (int q = 0; q < d.niso; q++)
+        if (d.iso_group[q] == g)
+          cmax = fmax(cmax, d.nwidth * fmax(sv[3 + 3 * q], (nu_b + 1.0) * sv[2 + 3 * q] * 1.001));
+      // window from the bucket index (a bucket too wide on either side; the
+      // exact per-line cut is applied below)
+      const double lo = nu_a - cmax * 1.01, hi = nu_b + cmax * 1.01;
+      int b0 = (int)floor((lo - d.bmin) / d.bstep), b1 = (int)floor((hi - d.bmin) / d.bstep) + 1;
+      b0 = b0 < 0 ? 0 : (b0 > d.nbucket ? d.nbucket : b0);
+      b1 = b1 < 0 ? 0 : (b1 > d.nbucket ? d.nbucket : b1);
+      const long j0 = d.bucket[d.boff[g] + b0], j1 = d.bucket[d.boff[g] + b1];
+      const double thresh = d.ethresh * smax[(size_t)st * d.ngroup + g];
+      for (long base = j0; base < j1; base += 256) {
+        const long j = base + threadIdx.x;
+        double cut = -1.0, n0 = 0.0, amp = 0.0, xs = 0.0, yy = 1.0;
+        if (j < j1) {
+          const int q = d.liso[j];
+          n0 = d.nu0[j];
+          const double S = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * q], T);
+          if (S >= thresh && S > 0.0) {
+            const double aD = n0 * sv[2 + 3 * q], aL = sv[3 + 3 * q];
+            cut = d.nwidth * fmax(aD, aL);
+            xs = kSqrtLn2 / aD;
+            amp = S * kSqrtLn2 * kInvSqrtPi / aD;
+            yy = aL * xs;
+          }
+        }
+        s_nu0[threadIdx.x] = n0; s_amp[threadIdx.x] = amp; s_xs[threadIdx.x] = xs;
+        s_y[threadIdx.x] = yy; s_cut[threadIdx.x] = cut;
+        __syncthreads();
+        if (active) {   // lanes (and whole waves) already past toomuch skip the line sum
+          const int cnt = (int)min((long)256, j1 - base);
+          for (int t = 0; t < cnt; t++) {
+            const double dv = fabs(nu - s_nu0[t]);
+            if (dv <= s_cut[t]) acc += s_amp[t] * voigt_k(dv * s_xs[t], s_y[t]);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const double *c = sC + k * NC;
+    const idx_t *ix = sI + k * NI;
+    double e = acc + c[2 + 2 * C] * nu4;
+    for (int cc = 0; cc < C; cc++) {
+      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + ii;
+      e += c[2 + 2 * cc] * ab[0] + c[3 + 2 * cc] * ab[W];
+    }
+    const double dtau = active ? 0.5 * (eprev + e) * c[0] : 0.0;
+    tau += dtau;
+    const double B = bnum / (exp(c[1] * nu) - 1.0);
+    const double hb = active ? 0.5 * (Bprev + B) : 0.0;
+#pragma unroll
+    for (int a = 0; a < kMaxAngles; a++) {
+      if (a >= A) break;
+      const double E = exp(-tau * p.invmu[a]);
+      I[a] += hb * (fprev[a] - E);
+      fprev[a] = E;
+    }
+    Bprev = B;
+    eprev = e;
+    if (active && tau > p.toomuch) active = false;
+    if (!__syncthreads_or(active ? 1 : 0)) break;
+  }
+  double F = 0.0;
+  const bool surf = p.cloud_on && active;
+#pragma unroll
+  for (int a = 0; a < kMaxAngles; a++) {
+    if (a >= A) break;
+    F += p.wgt[a] * (I[a] + (surf ? Bprev * fprev[a] : 0.0));
+  }
+  if (valid) p.spec[(size_t)w * W + i] = F;
+}
+
 // ---------------------------------------------------------------------------
 Lbl::~Lbl() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_nu0); fr(d_elow); fr(d_gf); fr(d_ztab); fr(d_ztemp); fr(d_liso);
-  fr(d_state); fr(d_smax); fr(d_ext);
+  fr(d_state); fr(d_smax); fr(d_ext); fr(d_bucket);
 }
 
 template <class T>
@@ -286,6 +399,24 @@ void lbl_init(Engine &e, const std::string &path) {
     d.gend[g] = (long)nu0.size();
   }
   b->nlines = (long)nu0.size();
+  {
+    // coarse bucket index per group (1 cm-1 buckets over the kept range)
+    d.bmin = std::floor(e.wn_full.front() - 500.0);
+    d.bstep = 1.0;
+    d.nbucket = (int)std::ceil((e.wn_full.back() + 500.0 - d.bmin) / d.bstep) + 1;
+    std::vector<long> bucket;
+    for (int g = 0; g < d.ngroup; g++) {
+      d.boff[g] = (int)bucket.size();
+      long j = d.gstart[g];
+      for (int q = 0; q <= d.nbucket; q++) {
+        const double edge = d.bmin + q * d.bstep;
+        while (j < d.gend[g] && nu0[j] < edge) j++;
+        bucket.push_back(q == d.nbucket ? d.gend[g] : j);
+      }
+    }
+    b->d_bucket = upv(bucket);
+    d.bucket = b->d_bucket;
+  }
   b->d_nu0 = upv(nu0); b->d_elow = upv(elow); b->d_gf = upv(gf); b->d_liso = upv(liso);
   b->d_ztab = upv(ztab); b->d_ztemp = upv(ztemp);
   d.nu0 = b->d_nu0; d.elow = b->d_elow; d.gf = b->d_gf; d.liso = b->d_liso;
@@ -341,6 +472,31 @@ void lbl_extinction(Engine &e, const double *d_prof, int nwalkers, hipStream_t s
   AccArgs aa{};
   aa.per_group = 0; aa.out = e.lbl->d_ext;
   run_states(e, sa, aa, st);
+}
+
+void lbl_rt_eclipse(Engine &e, const double *d_prof, int nwalkers, const RtArgs &r, hipStream_t st) {
+  Lbl *b = e.lbl;
+  const LblDev &d = b->dev;
+  const long nstate = (long)nwalkers * e.L;
+  ensure_states(e, nstate, false);
+  StateArgs sa{};
+  sa.nstate = (int)nstate; sa.table_mode = 0; sa.prof = d_prof;
+  sa.L = e.L; sa.S = e.S; sa.iH2 = e.iH2; sa.iHe = e.iHe;
+  sa.press = e.d_press; sa.mass = e.d_mass; sa.diam = e.d_diam;
+  sa.state = b->d_state;
+  hipLaunchKernelGGL(lbl_states, dim3(sa.nstate), dim3(64), 0, st, sa, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(b->d_smax, 0, sizeof(double) * (size_t)nstate * d.ngroup, st));
+  const int nb = (int)std::max<long>(1, std::min<long>(64, b->nlines / 4096 + 1));
+  hipLaunchKernelGGL(lbl_smax, dim3(nb, sa.nstate, d.ngroup), dim3(256), 0, st, d, b->d_state,
+                     b->d_smax, sa.nstate);
+  HIPCHK(hipGetLastError());
+  const int ntile = (r.W + 255) / 256;
+  const size_t sh = sizeof(double) * (size_t)e.L * coef_stride(0, e.C) +
+                    sizeof(idx_t) * (size_t)e.L * idx_stride(e.C);
+  hipLaunchKernelGGL(lbl_rt_eclipse_k, dim3(ntile, nwalkers), dim3(256), sh, st, d, b->d_state,
+                     b->d_smax, r);
+  HIPCHK(hipGetLastError());
 }
 
 void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<double> &tgrid) {

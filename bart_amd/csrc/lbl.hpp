@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "io.hpp"
+#include "kernels.hpp"
 
 namespace bartrt {
 
@@ -30,6 +31,12 @@ struct LblDev {
   int iso_zoff[kMaxIso], iso_nt[kMaxIso], iso_toff[kMaxIso];
   const double *ztab, *ztemp;    // concatenated partition functions / their temperatures
   double nwidth, ethresh;
+  // coarse index of the sorted lists: bucket[boff[g] + b] = first line of group g
+  // with nu0 >= bmin + b * bstep (b = 0..nbucket; entry nbucket = gend[g])
+  const long *bucket;
+  int boff[kMaxGroup];
+  int nbucket;
+  double bmin, bstep;
 };
 
 struct Lbl {
@@ -38,6 +45,7 @@ struct Lbl {
   long nlines = 0;
   double *d_nu0 = nullptr, *d_elow = nullptr, *d_gf = nullptr, *d_ztab = nullptr, *d_ztemp = nullptr;
   int *d_liso = nullptr;
+  long *d_bucket = nullptr;
   // per-call workspaces
   double *d_state = nullptr;     // [nstate][3*niso + 2]
   double *d_smax = nullptr;      // [nstate][ngroup]
@@ -50,6 +58,13 @@ struct Lbl {
 void lbl_init(Engine &e, const std::string &path);
 // ext[w][l][W_local] (atm layer order) for nwalkers profiles, into e.lbl->d_ext.
 void lbl_extinction(Engine &e, const double *d_prof, int nwalkers, hipStream_t st);
+// Fused lazy form for eclipse spectra: per wavenumber tile the layers are
+// visited from the top, each layer's line extinction is summed when it is
+// reached, and the tile stops once every sample passed `toomuch` -- the deep,
+// pressure-broadened layers (where almost all line-wing work sits) are never
+// evaluated for opaque tiles.  `r` carries the coefficient records of
+// prep_profiles (CIA, Rayleigh, path lengths) and the output pointer.
+void lbl_rt_eclipse(Engine &e, const double *d_prof, int nwalkers, const RtArgs &r, hipStream_t st);
 // Computes o[L][Nt][M][W] for the cfg's tlow/thigh/tempdelt and writes the
 // opacity file (molecule order = TLI database order).
 void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<double> &tgrid);

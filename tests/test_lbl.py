@@ -117,3 +117,26 @@ def test_opacity_grid_generated_from_lines(tmp_path):
         np.testing.assert_allclose(spec, orc.OracleEngine(c.tcfg).run(prof), rtol=1e-10)
     finally:
         trm.free_memory()
+
+
+@pytest.mark.gpu
+def test_lazy_fused_kernel_matches_eager(tmp_path):
+    """BARTRT_LBL=lazy (layers' line sums evaluated only as deep as tau requires)
+    gives the same spectra as the default eager two-pass form."""
+    import os, subprocess, sys
+    from bart_amd import synth_lbl
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=1200, nwave=600, nlayers=24, cia=True)
+    prof = np.array([c.profiles().ravel(), c.profiles(temp=c.temp0 * 0.9).ravel()])
+    np.save(os.path.join(c.dir, "p.npy"), prof)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("eager", "lazy"):
+        out = os.path.join(c.dir, "s_%s.npy" % mode)
+        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+                "from bart_amd import engine, transit_module as trm\n"
+                "engine.init(%r); np.save(%r, engine.run_batch(np.load(%r))); trm.free_memory()\n"
+                % (root, c.tcfg, out, os.path.join(c.dir, "p.npy")))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_LBL=mode),
+                              timeout=300)
+        outs[mode] = np.load(out)
+    np.testing.assert_allclose(outs["lazy"], outs["eager"], rtol=1e-12)

@@ -31,9 +31,33 @@ constexpr double kInvSqrtPi = 0.5641895835477563;
 // Re w(x + i y), x >= 0, y > 0.
 __device__ inline double voigt_k(double x, double y) {
   const double r2 = x * x + y * y;
+  if (r2 >= 225.0) {
+    // far wings (almost every line-point pair of a pressure-broadened layer):
+    // asymptotic series w = i/(sqrt(pi) z) (1 + 1/(2 z^2) + 3/(4 z^4) + ...),
+    // 2 / 3 / 5 terms for |z| >= 100 / 30 / 15 (<= 1.3e-11 / 9e-11 / 1.7e-11)
+    const double inv = 1.0 / r2, inv2 = inv * inv;
+    const double tr = (x * x - y * y) * inv2, ti = -2.0 * x * y * inv2;  // t = 1/z^2
+    double hr, hi;
+    if (r2 >= 1.0e4) { hr = 0.75; hi = 0.0; }
+    else {
+      if (r2 >= 900.0) { hr = 15.0 / 8.0; hi = 0.0; }
+      else {
+        hr = fma(945.0 / 32.0, tr, 105.0 / 16.0); hi = (945.0 / 32.0) * ti;
+        const double ar = fma(hr, tr, -hi * ti) + 15.0 / 8.0, ai = fma(hr, ti, hi * tr);
+        hr = ar; hi = ai;
+      }
+      const double ar = fma(hr, tr, -hi * ti) + 0.75, ai = fma(hr, ti, hi * tr);
+      hr = ar; hi = ai;
+    }
+    // h = c0 + t h ; s = 1 + t h
+    double ar = fma(hr, tr, -hi * ti) + 0.5, ai = fma(hr, ti, hi * tr);
+    const double sr = fma(ar, tr, -ai * ti) + 1.0, si = fma(ar, ti, ai * tr);
+    // Re[i s / z] = (y s_r - x s_i) / |z|^2
+    return kInvSqrtPi * (y * sr - x * si) * inv;
+  }
   if (r2 >= 64.0) {
-    // Laplace continued fraction, 4 (|z| >= 15) or 8 levels
-    const int K = r2 >= 225.0 ? 4 : 8;
+    // Laplace continued fraction, 8 levels (8 <= |z| < 15, <= 1.7e-12)
+    const int K = 8;
     double fr = x, fi = y;
     for (int k = K; k >= 1; k--) {
       const double s = (0.5 * k) / (fr * fr + fi * fi);

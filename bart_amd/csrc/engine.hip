@@ -432,7 +432,6 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     HIPCHK(hipEventRecord(ev[ev_used + 1], st));
     ev_used += 2;
   }
-  if (want_tau && n == 1) tau_valid = true;
 }
 
 }  // namespace bartrt

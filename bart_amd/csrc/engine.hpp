@@ -53,7 +53,6 @@ struct Engine {
   unsigned char *d_ok = nullptr;
   double *d_tau = nullptr;  // [W][L] of the last single-walker run
   int *d_last = nullptr;
-  bool tau_valid = false;
   double *h_pin = nullptr;  // pinned staging
   size_t h_pin_bytes = 0;
   hipStream_t stream = nullptr;

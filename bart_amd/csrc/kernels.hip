@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <string>
 
+// upper bound on resident waves per SIMD the specialised kernels are compiled
+// for: lets the compiler spend registers on loads in flight (measured best: 3-4)
 #ifndef BARTRT_WPE
 #define BARTRT_WPE 4
 #endif
@@ -223,11 +225,10 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
 // its L2), so all walkers of one wavenumber tile are placed on one XCD, walker
 // index fastest: they stream the same grid rows at about the same time and
 // the XCD's L2 serves the repeats.
-__device__ inline void block_to_work(int b, int ntiles8, int nwalkers, int &tile, int &walker) {
+__device__ inline void block_to_work(int b, int nwalkers, int &tile, int &walker) {
   const int xcd = b & 7, j = b >> 3;
   walker = j % nwalkers;
   tile = (j / nwalkers) * 8 + xcd;
-  (void)ntiles8;
 }
 
 template <int AT, int MT, int CT>
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   const int L = p.L, W = p.W;
   const int NC = coef_stride(M, C), NI = idx_stride(C);
   int tile, w;
-  block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
@@ -400,7 +401,7 @@ void rt_eclipse_fast(RtArgs p) {
   constexpr int NR = NLD > 0 ? NLD : 1;
   const int L = p.L, W = p.W;
   int tile, w;
-  block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
@@ -568,7 +569,7 @@ void rt_eclipse_split(RtArgs p) {
   constexpr int NR = NLD > 0 ? NLD : 1;
   const int L = p.L, W = p.W;
   int tile, w;
-  block_to_work(blockIdx.x, 0, p.nwalkers, tile, w);
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;

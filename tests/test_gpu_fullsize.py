@@ -1,0 +1,83 @@
+"""GPU, BASELINE.json's full headline shape (100 layers x 1e4 wavenumbers, 4
+molecules, 27 table temperatures, 864 MB grid): size-independent properties of
+the domain, plus the oracle on slices of the grid it can finish in seconds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_case(tmp_path_factory):
+    from bart_amd import synth
+    return synth.make_case(str(tmp_path_factory.mktemp("case_full")), nlayers=100, nwave=10000)
+
+
+def _profiles(case, n, seed):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.make_profiles(case, n, seed)
+
+
+def test_full_grid_properties(full_case):
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = full_case
+    engine.init(c.tcfg)
+    try:
+        n = trm.get_no_samples()
+        assert n == 10000 and engine.nlayers() == 100
+        profs = _profiles(c, 12, seed=77)
+        spec = engine.run_batch(profs)
+        assert spec.shape == (12, 10000) and np.all(np.isfinite(spec)) and spec.min() > 0
+        # (1) every spectrum is below the Planck flux of its hottest layer
+        wn = trm.get_waveno_arr(n)
+        for w in range(12):
+            tmax = profs[w, :100].max()
+            bmax = 2 * orc.H * wn ** 3 * orc.LS ** 2 / np.expm1(orc.H * orc.LS * wn / (orc.KB * tmax))
+            assert np.all(spec[w] <= np.pi * bmax * (1 + 1e-12))
+        # (2) walkers are independent: any order, any batch size, same bits
+        perm = np.random.default_rng(1).permutation(12)
+        assert np.array_equal(engine.run_batch(profs[perm]), spec[perm])
+        # one walker takes the producer/consumer kernel: same arithmetic, other schedule
+        np.testing.assert_allclose(engine.run_batch(profs[3:4])[0], spec[3], rtol=1e-13)
+        big = engine.run_batch(np.tile(profs[:4], (40, 1)))          # 160 walkers: other kernel path
+        np.testing.assert_allclose(big[:4], spec[:4], rtol=1e-13)
+        assert np.array_equal(big[4:8], big[:4])
+        # (3) isothermal closed form with the engine's own optical depths
+        iso = c.profiles(temp=np.full(100, 1400.0)).ravel()
+        s_iso = trm.run_transit(iso, n)
+        tau, last = engine.get_tau()
+        tl = tau[np.arange(n), last]
+        B = 2 * orc.H * wn ** 3 * orc.LS ** 2 / np.expm1(orc.H * orc.LS * wn / (orc.KB * 1400.0))
+        ang = np.radians([0, 20, 40, 60, 80])
+        edges = np.radians([0, 10, 30, 50, 70, 90])
+        wgt = np.pi * np.diff(np.sin(edges) ** 2)
+        closed = sum(wg * B * (1 - np.exp(-tl / np.cos(a))) for a, wg in zip(ang, wgt))
+        np.testing.assert_allclose(s_iso, closed, rtol=1e-11)
+        # (4) the oracle on three 150-sample slices of the full grid
+        for lo in (0, 4321, 9850):
+            o = orc.OracleEngine(c.tcfg, wn_lo=lo, wn_hi=lo + 150)
+            for w in (0, 7):
+                np.testing.assert_allclose(spec[w, lo:lo + 150], o.run(profs[w]), rtol=1e-10)
+    finally:
+        trm.free_memory()
+
+
+def test_full_grid_shards_concatenate(full_case):
+    """8 wavenumber blocks (the 8-GPU layout, one after the other on this GPU)
+    reassemble the unsharded spectra bit for bit."""
+    from bart_amd import engine, transit_module as trm
+    c = full_case
+    profs = _profiles(c, 10, seed=5)
+    engine.init(c.tcfg)
+    full = engine.run_batch(profs)
+    trm.free_memory()
+    parts = []
+    for r in range(8):
+        engine.init(c.tcfg, shard=(r, 8))
+        assert engine.local_range() == (1250 * r, 1250 * (r + 1))
+        parts.append(engine.run_batch(np.tile(profs, (8, 1)))[:10])   # 80 walkers per step, as at N = 8
+        trm.free_memory()
+    assert np.array_equal(np.concatenate(parts, axis=1), full)

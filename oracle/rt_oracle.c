@@ -230,10 +230,15 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
   if (kend == 0) last = 0;
   for (int k = last + 1; k < L; k++) tau[k] = tau[last]; /* not computed deeper */
   double *f = (double *)malloc(sizeof(double) * L);
+  double *bk = (double *)malloc(sizeof(double) * L);
+  double *ek = (double *)malloc(sizeof(double) * L);
+  for (int k = 0; k <= last; k++) bk[k] = orc_planck(wn, t_col[k]);
   for (int a = 0; a < A; a++) {
     double mu = cos(c->angles_deg[a] * ORC_PI / 180.0);
-    for (int k = 0; k <= last; k++)
-      f[k] = orc_planck(wn, t_col[k]) * exp(-tau[k] / mu);
+    for (int k = 0; k <= last; k++) {
+      ek[k] = exp(-tau[k] / mu);
+      f[k] = bk[k] * ek[k];
+    }
     double I;
     if (c->integ == ORC_INTEG_SIMPSON) {
       I = simpson_nu(tau, f, last + 1) / mu;
@@ -248,14 +253,14 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
        * across one layer), and is the discretisation BART's own
        * contribution functions use (code/cf.py:123-131). */
       I = 0.0;
-      for (int k = 1; k <= last; k++)
-        I += 0.5 * (orc_planck(wn, t_col[k - 1]) + orc_planck(wn, t_col[k])) *
-             (exp(-tau[k - 1] / mu) - exp(-tau[k] / mu));
+      for (int k = 1; k <= last; k++) I += 0.5 * (bk[k - 1] + bk[k]) * (ek[k - 1] - ek[k]);
     }
     /* opaque cloud deck reached before toomuch: it emits as a surface */
     if (kcloud >= 0 && last == kcloud && !(tau[last] > c->toomuch)) I += f[last];
     intens[a] = I;
   }
+  free(bk);
+  free(ek);
   free(f);
   free(path);
   *last_out = last;

@@ -356,6 +356,9 @@ void Engine::ensure_pin(size_t bytes) {
 void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
                      unsigned char *d_okp, hipStream_t st, bool want_tau) {
   if (n <= 0) return;
+  // per-walker workspaces (records, flags) are sized by cap_walkers; the
+  // caller's profile and spectrum buffers are used in place
+  if (n > cap_walkers && d_prof_in != d_prof) ensure_walkers(n);
   if (lbl && solution == 0 && !want_tau && !want_intens && !lbl_eager) {
     // lazy fused path: layers' line sums are evaluated only as deep as the
     // optical depth requires
@@ -372,7 +375,7 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
       const int m = std::min(chunk, n - off);
       lbl_extinction(*this, d_prof_in + (size_t)off * nprof, m, st);
       run_chunk(d_prof_in + (size_t)off * nprof, m, d_spec_out + (size_t)off * W(),
-                d_okp ? d_okp + off : d_ok + (off < cap_walkers ? off : 0), st, want_tau, lbl->d_ext);
+                (d_okp ? d_okp : d_ok) + off, st, want_tau, lbl->d_ext);
     }
     return;
   }

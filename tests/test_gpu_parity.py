@@ -121,8 +121,9 @@ def test_kernel_variants_match_oracle(tmp_path, kw):
 @pytest.mark.parametrize("mode", ["generic", "mono", "split"])
 def test_every_kernel_variant_matches_oracle(small_case, mode):
     """The three RT kernels (generic fallback, single-wave specialised,
-    producer/consumer split) on the same batch.  BARTRT_KERNEL is read once per
-    process, so each variant runs in a child."""
+    producer/consumer split) on the same batch, without and with an opaque cloud
+    deck (its surface term takes a different route in each kernel).
+    BARTRT_KERNEL is read once per process, so each variant runs in a child."""
     import subprocess, sys, os
     from oracle import rt_oracle as orc
     c = small_case
@@ -131,36 +132,20 @@ def test_every_kernel_variant_matches_oracle(small_case, mode):
     out = os.path.join(c.dir, "s_%s.npy" % mode)
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
             "from bart_amd import engine, transit_module as trm\n"
-            "engine.init(%r); s = engine.run_batch(np.load(%r)); np.save(%r, s); trm.free_memory()\n"
-            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), c.tcfg,
-               os.path.join(c.dir, "p.npy"), out))
+            "p = np.load(%r); engine.init(%r); a = engine.run_batch(p)\n"
+            "trm.set_cloudtop(-1.0); b = engine.run_batch(p)\n"
+            "np.save(%r, np.array([a, b])); trm.free_memory()\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               os.path.join(c.dir, "p.npy"), c.tcfg, out))
     subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_KERNEL=mode),
-                          timeout=300)
-    ref = orc.OracleEngine(c.tcfg).run_batch(profs)
-    np.testing.assert_allclose(np.load(out), ref, rtol=RTOL)
-
-
-def test_cloud_deck_through_every_kernel(small_case):
-    """The surface term of an opaque deck takes a different route in each kernel."""
-    import subprocess, sys, os
-    from oracle import rt_oracle as orc
-    c = small_case
-    profs = walkers(c, 3, seed=12)
-    np.save(os.path.join(c.dir, "pc.npy"), profs)
+                          timeout=600)
+    got = np.load(out)
     o = orc.OracleEngine(c.tcfg)
+    np.testing.assert_allclose(got[0], o.run_batch(profs), rtol=RTOL)
     o.set_cloudtop(-1.0)
     ref = o.run_batch(profs)
-    for mode in ("generic", "mono", "split"):
-        out = os.path.join(c.dir, "sc_%s.npy" % mode)
-        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
-                "from bart_amd import engine, transit_module as trm\n"
-                "engine.init(%r); trm.set_cloudtop(-1.0)\n"
-                "s = engine.run_batch(np.load(%r)); np.save(%r, s); trm.free_memory()\n"
-                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), c.tcfg,
-                   os.path.join(c.dir, "pc.npy"), out))
-        subprocess.check_call([sys.executable, "-c", code],
-                              env=dict(os.environ, BARTRT_KERNEL=mode), timeout=300)
-        np.testing.assert_allclose(np.load(out), ref, rtol=RTOL)
+    np.testing.assert_allclose(got[1], ref, rtol=RTOL)
+    assert not np.allclose(got[0], got[1])
 
 
 def test_shards_reassemble_full_spectrum(small_case):

@@ -22,8 +22,14 @@
 #define BARTRT_WPE 4
 #endif
 
-// split (producer/consumer) kernel below this many 64-wavenumber columns per launch
-constexpr long kSplitMaxColumns = 640;  // measured crossover: ~4 walkers at W = 1e4
+// Kernel choice by 64-wavenumber columns per launch (measured at W = 1e4, L = 100:
+// 157 columns per walker).  <= 4 walkers: layer-parallel (1 walker 27 us against
+// 39 split / 54 single-wave; 4 walkers 52 / 55 / 61); 5-9 walkers: producer/consumer
+// split (9 walkers 77 us against 89 layer-parallel / 88 single-wave); from 10
+// walkers on the single-wave kernel wins (90 / 95 / 98 us).
+constexpr long kLpMaxColumns = 640;
+constexpr long kSplitMaxColumns = 1440;
+constexpr int kLpChunk = 13;  // layers per wave of the layer-parallel kernel
 
 namespace bartrt {
 
@@ -725,6 +731,210 @@ void rt_eclipse_split(RtArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// Layer-parallel variant for small and medium batches.  Only the running sum
+// tau_k is serial along a column; the extinction of a layer, its Planck term
+// and its A transmittances are independent once tau_k is known.  A workgroup
+// therefore takes ONE 64-wavenumber column and gives every wave a chunk of CH
+// consecutive layers:
+//   phase A  table loads + extinction of the chunk's layers, optical depth
+//            relative to the chunk's first layer (kept in registers), and the
+//            chunk's first / last extinction, total and maximum -> LDS
+//   barrier
+//   phase B  every wave rebuilds the optical depth at its chunk's start from
+//            the published totals (same chain in every wave), finds out whether
+//            the column was cut (`toomuch`) above it, and sums its layers' terms
+//            of the transmittance trapezoid; per-wave partial fluxes meet in LDS.
+// Work per column is that of the single-wave kernel plus one boundary layer per
+// chunk, but it comes in L/CH short waves: 10 walkers x 157 columns become
+// 12 560 waves that the dispatcher spreads evenly over the 1 024 SIMDs (1 570
+// long waves leave half of the SIMDs with two and half with one), and a lone
+// walker's latency drops by about the number of chunks.
+template <int AT, int MT, int CT, int CH>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+void rt_eclipse_lp(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NR = NLD > 0 ? NLD : 1;
+  const int L = p.L, W = p.W;
+  int tile, w;
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+  const int nwv = blockDim.x >> 6;  // waves = chunks
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  double *sPub = smem + (size_t)L * NC + (size_t)L * NI;  // [chunk][first, last, total, max][64]
+  double *sF = sPub + (size_t)nwv * 256;                  // [chunk][64] partial fluxes
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k0 = c * CH;
+  const int i = tile * 64 + lane;
+  const bool valid = i < W;
+  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
+  const int kend = p.kstop[w];
+  const double nu = p.wn[ii];
+  auto clampk = [&](int k) { return k < kend ? k : kend; };
+  {
+    // every wave stages the records of its own chunk and reads them back without
+    // a workgroup barrier; the other chunks' records are only needed after the
+    // barrier that ends phase A
+    const int n = (L - k0 < CH ? L - k0 : CH);
+    const double *gC = p.coef + ((size_t)w * L + k0) * NC;
+    const idx_t *gI = p.idx + ((size_t)w * L + k0) * NI;
+    for (int t = lane; t < n * NC; t += 64) sC[k0 * NC + t] = gC[t];
+    for (int t = lane; t < n * NI; t += 64) sI[k0 * NI + t] = gI[t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  // ---------------- phase A ----------------
+  double tl[CH];  // tau_{k0+j} - tau_{k0}
+#pragma unroll
+  for (int j = 0; j < CH; j++) tl[j] = 0.0;
+  if (k0 <= kend) {
+    const unsigned off = ii * 8u;
+    const double nu4 = (nu * nu) * (nu * nu);
+    const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
+    unsigned voff[NR];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      voff[2 * m] = off + (unsigned)(m * rowB);
+      voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      voff[2 * M + 2 * cc] = off;
+      voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
+    }
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0,
+                                                        (int)p.kappa_bytes, 0x00020000);
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0,
+                                                        (int)p.cia_bytes, 0x00020000);
+    auto load_layer = [&](int k, double (&r)[NR]) {
+      const idx_t *ix = sI + k * NI;
+      if (M > 0) {
+        const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
+#pragma unroll
+        for (int j = 0; j < 2 * M; j++)
+          r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
+      }
+#pragma unroll
+      for (int cc = 0; cc < C; cc++) {
+        const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
+        r[2 * M + 2 * cc] = __builtin_bit_cast(
+            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc], so, 0));
+        r[2 * M + 2 * cc + 1] = __builtin_bit_cast(
+            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + 1], so, 0));
+      }
+    };
+    // D layers of loads are requested ahead of the arithmetic (the loop is fully
+    // unrolled, and the compiler hoists further loads as registers allow:
+    // D = 2..6 measured the same)
+    constexpr int D = 2 < CH ? 2 : CH - 1;
+    double r[D + 1][NR];
+#pragma unroll
+    for (int j = 0; j < D; j++) load_layer(clampk(k0 + j), r[j]);
+    double efirst = 0.0, eprev = 0.0, t = 0.0, tmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+      const int k = k0 + j;
+      if (j + D < CH) load_layer(clampk(k + D), r[(j + D) % (D + 1)]);
+      const double *cr = sC + clampk(k) * NC;
+      double cf[NC];
+#pragma unroll
+      for (int q = 0; q < NC; q++) cf[q] = cr[q];
+      double e = cf[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+      for (int q = 0; q < NLD; q++) e = fma(cf[2 + q], r[j % (D + 1)][q], e);
+      if (j == 0) {
+        efirst = e;
+      } else {
+        t += (eprev + e) * cf[0] * (k <= kend ? 0.5 : 0.0);
+        tmax = fmax(tmax, t);
+      }
+      tl[j] = t;
+      eprev = e;
+    }
+    double *pb = sPub + c * 256 + lane;
+    pb[0] = efirst;
+    pb[64] = eprev;
+    pb[128] = t;
+    pb[192] = tmax;
+  }
+  __syncthreads();
+
+  // ---------------- phase B ----------------
+  double F = 0.0;
+  if (k0 <= kend) {
+    // optical depth at this chunk's first layer (t0) and at the layer above it
+    // (tup), and whether the column was cut before this chunk
+    double t0 = 0.0, tup = 0.0;
+    bool cut = false;
+    for (int cc = 0; cc < c; cc++) {
+      const double *pb = sPub + cc * 256 + lane;
+      cut = cut || (t0 + pb[192] > p.toomuch);
+      tup = t0 + pb[128];
+      const int kb = (cc + 1) * CH;  // <= k0 <= kend
+      t0 = tup + (pb[64] + pb[256]) * sC[kb * NC] * 0.5;
+    }
+    if (__any(!cut)) {
+      const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+      double I[A], fprev[A], Bprev = 0.0;
+#pragma unroll
+      for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }
+      if (c > 0) {
+        double xs[A + 1], es[A + 1];
+        xs[A] = fmin(sC[(k0 - 1) * NC + 1] * nu, 700.0);
+#pragma unroll
+        for (int a = 0; a < A; a++) xs[a] = fmax(-tup * p.invmu[a], -745.0);
+        exp_core_n<A + 1>(xs, es);
+        Bprev = bnum * rcp_core(es[A] - 1.0);
+#pragma unroll
+        for (int a = 0; a < A; a++) fprev[a] = es[a];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const int k = k0 + j;
+        const bool live = !cut && k <= kend;
+        const double tau = t0 + tl[j];
+        double xs[A + 1], es[A + 1];
+        xs[A] = fmin(sC[clampk(k) * NC + 1] * nu, 700.0);
+#pragma unroll
+        for (int a = 0; a < A; a++) xs[a] = fmax(-tau * p.invmu[a], -745.0);
+        exp_core_n<A + 1>(xs, es);
+        const double B = bnum * rcp_core(es[A] - 1.0);
+        const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+          I[a] = fma(hb, fprev[a] - es[a], I[a]);
+          fprev[a] = es[a];
+        }
+        Bprev = B;
+        cut = cut || (live && tau > p.toomuch);
+        if (k == kend && p.cloud_on) {  // deck reached below toomuch: its surface emission
+          const double bs = cut ? 0.0 : B;
+#pragma unroll
+          for (int a = 0; a < A; a++) I[a] = fma(bs, es[a], I[a]);
+        }
+        if (!__any(!cut)) break;
+      }
+#pragma unroll
+      for (int a = 0; a < A; a++) F = fma(p.wgt[a], I[a], F);
+    }
+  }
+  sF[c * 64 + lane] = F;
+  __syncthreads();
+  if (c == 0) {
+    double s = 0.0;
+    for (int cc = 0; cc < nwv; cc++) s += sF[cc * 64 + lane];
+    if (valid) p.spec[(size_t)w * W + i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
   size_t sh = sizeof(double) * ((size_t)4 * a.L + (size_t)(a.S + 1) * a.L + 2 * a.L + a.S + a.Nt +
@@ -747,7 +957,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   const size_t sh = sizeof(double) * (size_t)a.L * coef_stride(a.M, a.C) +
                     sizeof(idx_t) * (size_t)a.L * idx_stride(a.C);
   static const std::string kmode = [] {
-    const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split (A/B runs)
+    const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split | lp (A/B runs)
     return std::string(e ? e : "");
   }();
   static const int pf_env = [] {
@@ -758,10 +968,37 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   // the specialised kernels address the tables through 32-bit buffer offsets
   const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
   if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {
-    // few walkers: not enough single-wave columns to fill 1024 SIMDs -> two
-    // waves per 64 wavenumbers (producer / consumer)
+    // too few single-wave columns to load the 1 024 SIMDs evenly -> several
+    // waves per 64 wavenumbers: one per chunk of layers (layer-parallel), or a
+    // producer / consumer pair
     const long columns = (long)a.nwalkers * ((a.W + 63) / 64);
-    const bool split = kmode == "split" || (kmode != "mono" && columns <= kSplitMaxColumns);
+    static const int lp_ch_env = [] {
+      const char *e = std::getenv("BARTRT_LP_CH");
+      return e ? std::atoi(e) : 0;
+    }();
+    const int lp_ch = lp_ch_env > 0 ? lp_ch_env : kLpChunk;
+    const int lp_waves = (a.L + lp_ch - 1) / lp_ch;
+    if ((kmode == "lp" || (kmode.empty() && columns <= kLpMaxColumns)) && lp_waves <= 16) {
+      RtArgs b = a;
+      b.ntiles = (a.W + 63) / 64;
+      const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+      const size_t shl = sh + sizeof(double) * (size_t)lp_waves * (256 + 64);
+#define BARTRT_LP(MM, CC, CHH)                                                                     \
+  if (a.M == MM && a.C == CC && lp_ch == CHH) {                                                    \
+    hipLaunchKernelGGL((rt_eclipse_lp<5, MM, CC, CHH>), dim3(nb), dim3(64 * lp_waves), shl, st, b);\
+    return hipGetLastError();                                                                      \
+  }
+      BARTRT_LP(1, 0, 13) BARTRT_LP(1, 1, 13) BARTRT_LP(1, 2, 13)
+      BARTRT_LP(2, 0, 13) BARTRT_LP(2, 1, 13) BARTRT_LP(2, 2, 13)
+      BARTRT_LP(3, 0, 13) BARTRT_LP(3, 1, 13) BARTRT_LP(3, 2, 13)
+      BARTRT_LP(4, 0, 13) BARTRT_LP(4, 1, 13) BARTRT_LP(4, 2, 13)
+      BARTRT_LP(5, 1, 13) BARTRT_LP(6, 1, 13)
+#ifdef BARTRT_LP_EXPERIMENT  // chunk-size A/B (BARTRT_LP_CH): 7, 10, 17 lose; 25 about equal
+      BARTRT_LP(4, 1, 7) BARTRT_LP(4, 1, 10) BARTRT_LP(4, 1, 17) BARTRT_LP(4, 1, 25)
+#endif
+#undef BARTRT_LP
+    }
+    const bool split = kmode == "split" || (kmode.empty() && columns <= kSplitMaxColumns);
     if (split) {
       RtArgs b = a;
       b.ntiles = (a.W + 63) / 64;

@@ -11,12 +11,12 @@ export TMPDIR=/tmp
 B="--steps 200 --warmup 20 --no-cpu --sweep="
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$out/stats_w10" -o s -- python3 "$root/bench.py" $B > "$out/stats_w10.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/stats_w1" -o s -- python3 "$root/bench.py" $B --walkers 1 > "$out/stats_w1.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/stats_w256" -o s -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --sweep= --walkers 256 > "$out/stats_w256.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o p -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o p -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_write.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_calib" -o p -- python3 "$root/tools/pmc_calib.py" > "$out/pmc_calib.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w10" --output-format csv -- python3 "$root/bench.py" $B > "$out/stats_w10.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w1" --output-format csv -- python3 "$root/bench.py" $B --walkers 1 > "$out/stats_w1.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w256" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --sweep= --walkers 256 > "$out/stats_w256.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_calib" --output-format csv -- python3 "$root/tools/pmc_calib.py" > "$out/pmc_calib.log" 2>&1
 cd "$root"
 python3 tools/collect_profiles.py "${tag}_w10" "$out/stats_w10" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_calib"
 python3 tools/collect_profiles.py "${tag}_w1" "$out/stats_w1"

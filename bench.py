@@ -31,18 +31,45 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+# HD 209458b system values of the demo TEP file (examples/demo/HD209458b.tep) and the
+# T(p) parameter box of the demo retrieval (examples/demo/BART_eclipse.cfg:78-83)
+_RSUN, _AU = 6.95508e10, 1.4959787066e13
+_PT_SYS = dict(r_star=1.145 * _RSUN, t_star=6075.0, t_int=100.0, sma=0.047 * _AU, grav=897.70)
+_PT_MIN = np.array([-5.0, -2.0, -2.0, 0.0, 0.55])
+_PT_MAX = np.array([-1.0, 1.0, 1.0, 1.0, 1.2])
+
+
+def _pt_line(p_bar, x):
+    """Line et al. (2013) T(p) as the per-step callable evaluates it
+    (code/PT.py:589-701): x = log10 kappa, log10 gamma1, log10 gamma2, alpha, beta."""
+    from scipy.special import expn
+    kappa, g1, g2 = 10.0 ** x[0], 10.0 ** x[1], 10.0 ** x[2]
+    alpha, beta = x[3], x[4]
+    t_irr = beta * np.sqrt(_PT_SYS["r_star"] / (2.0 * _PT_SYS["sma"])) * _PT_SYS["t_star"]
+    tau = kappa * (p_bar * 1e6) / _PT_SYS["grav"]
+
+    def xi(g):
+        return 2.0 / 3.0 * (1.0 + (1.0 / g) * (1.0 + (g * tau / 2.0 - 1.0) * np.exp(-g * tau))
+                            + g * (1.0 - tau ** 2 / 2.0) * expn(2, g * tau))
+
+    return (0.75 * (_PT_SYS["t_int"] ** 4 * (2.0 / 3.0 + tau) + t_irr ** 4 * (1.0 - alpha) * xi(g1)
+                    + t_irr ** 4 * alpha * xi(g2))) ** 0.25
+
+
 def make_profiles(case, n, seed):
-    """Walker profiles as the per-step callable builds them: PT_line-like T(p)
-    inside [Tmin, Tmax] and abundance log-factors U(-2, 1)."""
+    """Walker profiles as the per-step callable builds them: T(p)
+    from PT_line with parameters uniform in the demo's pmin/pmax, draws whose
+    temperatures leave [Tmin, Tmax] = [400, 3000] K rejected as the worker rejects
+    them (code/BARTfunc.py:327-329); abundance log-factors U(-2, 1), H2/He
+    renormalised at their ratio."""
     rng = np.random.default_rng(seed)
     L = len(case.press_bar)
-    lp = np.log10(case.press_bar)
     out = np.empty((n, (len(case.species) + 1) * L))
-    for w in range(n):
-        t_top = rng.uniform(700, 1500)
-        t_bot = rng.uniform(1500, 2600)
-        x = 1.0 / (1.0 + np.exp(-(lp - rng.uniform(-2.0, 0.5)) / rng.uniform(0.4, 1.0)))
-        t = np.clip(t_top + (t_bot - t_top) * x, 410.0, 2990.0)
+    w = 0
+    while w < n:
+        t = _pt_line(case.press_bar, rng.uniform(_PT_MIN, _PT_MAX))
+        if not (t.min() > 400.0 and t.max() < 3000.0):
+            continue
         ab = case.abund0.copy()
         for s in range(2, ab.shape[1]):
             ab[:, s] *= 10 ** rng.uniform(-2, 1)
@@ -51,6 +78,7 @@ def make_profiles(case, n, seed):
         ab[:, 1] = r * q / (1 + r)
         ab[:, 0] = q / (1 + r)
         out[w] = case.profiles(t, ab).ravel()
+        w += 1
     return out
 
 

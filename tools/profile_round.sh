@@ -9,7 +9,6 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 B="--steps 200 --warmup 20 --no-cpu --sweep="
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$out/stats_w10" --output-format csv -- python3 "$root/bench.py" $B > "$out/stats_w10.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/stats_w1" --output-format csv -- python3 "$root/bench.py" $B --walkers 1 > "$out/stats_w1.log" 2>&1
@@ -21,6 +20,8 @@ cd "$root"
 python3 tools/collect_profiles.py "${tag}_w10" "$out/stats_w10" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_calib"
 python3 tools/collect_profiles.py "${tag}_w1" "$out/stats_w1"
 python3 tools/collect_profiles.py "${tag}_w256" "$out/stats_w256"
+# the bench line last, so that its `traffic` is this round's PMC figure
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cp "$out/bench.json" "profiles/${tag}_bench.json"
 mkdir -p "$out/profiles" && cp profiles/${tag}_* profiles/pmc_latest.json "$out/profiles/" 2>/dev/null
 tail -c 600 "$out/bench.json"

@@ -393,6 +393,57 @@ __device__ __forceinline__ void exp_core_n(const double (&x)[N], double (&out)[N
   for (int a = 0; a < N; a++) out[a] = __builtin_amdgcn_ldexp(q[a], (int)n[a]);
 }
 
+// The 2M+2C table values one lane needs for a layer, fetched with buffer loads:
+// one 128-bit descriptor over the opacity grid and one over the CIA block (built
+// from wave-uniform values), a loop-invariant 32-bit lane offset per value in a
+// VGPR, and the layer's plane offset (from the LDS offset record) as the scalar
+// operand -- a layer costs no vector address arithmetic at all.
+template <int M, int C>
+struct TableLoader {
+  static constexpr int NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1, NI = 1 + C;
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  unsigned voff[NR];
+  decltype(__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, (short)0, 0, 0)) rs_k, rs_c;
+  const idx_t *sI;
+
+  // ii: this lane's wavenumber index; sI: the walker's offset records in LDS
+  __device__ __forceinline__ TableLoader(const RtArgs &p, unsigned ii, const idx_t *sI_) : sI(sI_) {
+    const unsigned off = ii * 8u;  // byte offset of this lane inside a table row
+    const size_t rowB = (size_t)p.W * 8, planeB = (size_t)M * p.W * 8;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      voff[2 * m] = off + (unsigned)(m * rowB);
+      voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      voff[2 * M + 2 * cc] = off;
+      voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
+    }
+    rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
+    rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
+  }
+
+  // issue the loads of layer k into r (no wait)
+  __device__ __forceinline__ void load(int k, double (&r)[NR]) const {
+    const idx_t *ix = sI + k * NI;
+    if (M > 0) {
+      const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
+#pragma unroll
+      for (int j = 0; j < 2 * M; j++)
+        r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        r[2 * M + 2 * cc + h] = __builtin_bit_cast(
+            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + h], so, 0));
+    }
+  }
+};
+
 // Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
 // bases (SGPR) + one 32-bit lane offset for every load, and a ring of PF layers
 // of 2M+2C loads kept in flight ahead of the arithmetic (the slot a layer has
@@ -423,52 +474,11 @@ void rt_eclipse_fast(RtArgs p) {
   const int i = tile * blockDim.x + threadIdx.x;
   const bool valid = i < W;
   const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
-  const unsigned off = ii * 8u;  // byte offset of this lane inside a table row
   const double nu = p.wn[ii];
   const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
   const double nu4 = (nu * nu) * (nu * nu);
-  const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
-
-  // Loop-invariant 32-bit lane offsets of the 2M+2C values of a layer relative
-  // to that layer's plane base; per layer only the two scalar plane bases change,
-  // so every load is "SGPR base + VGPR offset" with no per-layer vector address
-  // arithmetic.
-  unsigned voff[NR];
-#pragma unroll
-  for (int m = 0; m < M; m++) {
-    voff[2 * m] = off + (unsigned)(m * rowB);
-    voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
-  }
-#pragma unroll
-  for (int cc = 0; cc < C; cc++) {
-    voff[2 * M + 2 * cc] = off;
-    voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
-  }
-  // Buffer loads: 128-bit descriptors over the whole grid / CIA block (built
-  // from wave-uniform values), lane offset in a VGPR, the layer's plane offset
-  // in an SGPR -- no per-layer vector address arithmetic at all.
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0,
-                                                      (int)p.kappa_bytes, 0x00020000);
-  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0,
-                                                      (int)p.cia_bytes, 0x00020000);
-  auto load_layer = [&](int k, double (&r)[NR]) {
-    const idx_t *ix = sI + k * NI;
-    if (M > 0) {
-      const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
-#pragma unroll
-      for (int j = 0; j < 2 * M; j++)
-        r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
-    }
-#pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
-      r[2 * M + 2 * cc] = __builtin_bit_cast(
-          double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc], so, 0));
-      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(
-          double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + 1], so, 0));
-    }
-  };
+  const TableLoader<M, C> tab(p, ii, sI);
+  auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
 
   double I[A], fprev[A];
 #pragma unroll
@@ -602,44 +612,11 @@ void rt_eclipse_split(RtArgs p) {
 
   if (role == 0) {
     // ---------------- producer: extinction, tau, Planck ----------------
-    const unsigned off = ii * 8u;
     const double nu = p.wn[ii];
     const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
     const double nu4 = (nu * nu) * (nu * nu);
-    const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
-    unsigned voff[NR];
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-      voff[2 * m] = off + (unsigned)(m * rowB);
-      voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
-    }
-#pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      voff[2 * M + 2 * cc] = off;
-      voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
-    }
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0,
-                                                        (int)p.kappa_bytes, 0x00020000);
-    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0,
-                                                        (int)p.cia_bytes, 0x00020000);
-    auto load_layer = [&](int k, double (&r)[NR]) {
-      const idx_t *ix = sI + k * NI;
-      if (M > 0) {
-        const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
-#pragma unroll
-        for (int j = 0; j < 2 * M; j++)
-          r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
-      }
-#pragma unroll
-      for (int cc = 0; cc < C; cc++) {
-        const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
-        r[2 * M + 2 * cc] = __builtin_bit_cast(
-            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc], so, 0));
-        r[2 * M + 2 * cc + 1] = __builtin_bit_cast(
-            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + 1], so, 0));
-      }
-    };
+    const TableLoader<M, C> tab(p, ii, sI);
+    auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
     double tau = 0.0, eprev = 0.0, Bprev = 0.0;
     bool active = true;
     auto layer = [&](int k, const double (&r)[NR]) {
@@ -794,42 +771,9 @@ void rt_eclipse_lp(RtArgs p) {
 #pragma unroll
   for (int j = 0; j < CH; j++) tl[j] = 0.0;
   if (k0 <= kend) {
-    const unsigned off = ii * 8u;
     const double nu4 = (nu * nu) * (nu * nu);
-    const size_t rowB = (size_t)W * 8, planeB = (size_t)M * W * 8;
-    unsigned voff[NR];
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-      voff[2 * m] = off + (unsigned)(m * rowB);
-      voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
-    }
-#pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      voff[2 * M + 2 * cc] = off;
-      voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
-    }
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0,
-                                                        (int)p.kappa_bytes, 0x00020000);
-    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0,
-                                                        (int)p.cia_bytes, 0x00020000);
-    auto load_layer = [&](int k, double (&r)[NR]) {
-      const idx_t *ix = sI + k * NI;
-      if (M > 0) {
-        const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
-#pragma unroll
-        for (int j = 0; j < 2 * M; j++)
-          r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
-      }
-#pragma unroll
-      for (int cc = 0; cc < C; cc++) {
-        const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
-        r[2 * M + 2 * cc] = __builtin_bit_cast(
-            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc], so, 0));
-        r[2 * M + 2 * cc + 1] = __builtin_bit_cast(
-            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + 1], so, 0));
-      }
-    };
+    const TableLoader<M, C> tab(p, ii, sI);
+    auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
     // D layers of loads are requested ahead of the arithmetic (the loop is fully
     // unrolled, and the compiler hoists further loads as registers allow:
     // D = 2..6 measured the same)

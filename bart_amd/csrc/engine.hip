@@ -39,8 +39,8 @@ Engine::~Engine() {
   delete step;
   delete lbl;
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
-  fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_dlnp); fr(d_mass);
-  fr(d_tgrid); fr(d_cia_temp); fr(d_diam); fr(d_opmol); fr(d_prof); fr(d_coef); fr(d_spec);
+  fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_mass);
+  fr(d_prep_consts); fr(d_diam); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
@@ -253,20 +253,16 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     }
   }
   d_cia = dev_upload(cia_planes);
-  d_cia_temp = dev_upload(cia_temp);
 
   std::vector<double> dlnp(std::max(L - 1, 1), 0.0);
   for (int l = 0; l + 1 < L; l++) dlnp[l] = std::log(atm.press[l] / atm.press[l + 1]);
   d_press = dev_upload(atm.press);
-  d_dlnp = dev_upload(dlnp);
   d_mass = dev_upload(mass);
   {
     std::vector<double> diam(S);
     for (int s = 0; s < S; s++) diam[s] = mol.diam[mol.find_name(atm.species[s])] * 1e-8;
     d_diam = dev_upload(diam);
   }
-  d_tgrid = dev_upload(tgrid);
-  d_opmol = dev_upload(opmol);
 
   // hydrostatic reference layer (makeatm.py:229-247)
   {
@@ -293,8 +289,31 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     pa.ref_lnp = std::log(refpress / atm.press[ix]);
   }
   pa.L = L; pa.S = S; pa.M = M; pa.Nt = Nt; pa.C = C; pa.W = Wl;
-  pa.press = d_press; pa.dlnp = d_dlnp; pa.mass = d_mass; pa.tgrid = d_tgrid;
-  pa.opmol = d_opmol; pa.cia_temp = d_cia_temp; pa.ncia_temps = (int)cia_temp.size();
+  {
+    // prep_profiles' constants in one block (layout: kernels.hpp, PrepArgs::consts)
+    std::vector<double> blob(atm.press);
+    blob.insert(blob.end(), dlnp.begin(), dlnp.end());
+    blob.resize(2 * (size_t)L, 0.0);
+    blob.insert(blob.end(), mass.begin(), mass.end());
+    auto with_inverse_spacing = [&](const double *g, int n) {
+      blob.insert(blob.end(), g, g + n);
+      for (int j = 0; j < n; j++) blob.push_back(j + 1 < n ? 1.0 / (g[j + 1] - g[j]) : 0.0);
+    };
+    with_inverse_spacing(tgrid.data(), Nt);
+    const size_t at = blob.size();
+    blob.insert(blob.end(), cia_temp.begin(), cia_temp.end());
+    blob.resize(at + 2 * cia_temp.size(), 0.0);
+    for (int c = 0; c < C; c++)
+      for (int j = 0; j + 1 < pa.cia_nt[c]; j++) {
+        const double *g = cia_temp.data() + pa.cia_toff[c];
+        blob[at + cia_temp.size() + pa.cia_toff[c] + j] = 1.0 / (g[j + 1] - g[j]);
+      }
+    d_prep_consts = dev_upload(blob);
+  }
+  pa.consts = d_prep_consts;
+  if (M > kMaxMol) throw IoError{"more opacity-table molecules than the kernels are built for (16)"};
+  for (int m = 0; m < M; m++) pa.opmol[m] = opmol[m];
+  pa.ncia_temps = (int)cia_temp.size();
   pa.iH2 = iH2; pa.iHe = iHe;
 
   RtArgs &r = rt;

@@ -35,9 +35,8 @@ struct Engine {
   int device = 0;
   // device-resident inputs
   double *d_kappa = nullptr, *d_cia = nullptr, *d_wn = nullptr, *d_wn_full = nullptr;
-  double *d_press = nullptr, *d_dlnp = nullptr, *d_mass = nullptr, *d_tgrid = nullptr;
-  double *d_cia_temp = nullptr, *d_diam = nullptr;
-  int *d_opmol = nullptr;
+  double *d_press = nullptr, *d_mass = nullptr, *d_diam = nullptr;
+  double *d_prep_consts = nullptr;  // PrepArgs::consts
   PrepArgs prep{};  // static part filled at init
   RtArgs rt{};
   // workspaces (grown on demand, never inside a timed launch sequence twice)

@@ -35,10 +35,11 @@ namespace bartrt {
 
 // ---------------------------------------------------------------------------
 // Largest j with g[j] <= t, clamped to [0, n-2].  Starts from the uniform-grid
-// guess (tlow/thigh/tempdelt grids are uniform) and walks to the exact bracket.
-__device__ inline int bracket_dev(const double *g, int n, double t) {
+// guess (tlow/thigh/tempdelt grids are uniform; ginv[0] = 1/(g[1]-g[0])) and
+// walks to the exact bracket.
+__device__ inline int bracket_dev(const double *g, const double *ginv, int n, double t) {
   if (n <= 2) return 0;
-  double x = (t - g[0]) / (g[1] - g[0]);
+  double x = (t - g[0]) * ginv[0];
   int j = x > 0.0 ? (x < (double)(n - 2) ? (int)x : n - 2) : 0;
   while (j < n - 2 && g[j + 1] <= t) j++;
   while (j > 0 && g[j] > t) j--;
@@ -51,72 +52,64 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   double *sT = sm;           // temperature, atm order
   double *sMu = sm + L;      // mean molecular mass
   double *sR = sm + 2 * L;   // radius
+  double *sH = sm + 3 * L;   // hydrostatic step terms
   const int w = blockIdx.x;
-  // Everything this kernel reads from HBM (the walker's profile and the few
-  // small constant arrays) is pulled into LDS in ONE batch of independent
-  // loads; the phases below then run out of LDS.  The kernel is pure latency:
-  // each dependent trip to memory it avoids is worth a microsecond.
+  // Everything this kernel reads from HBM (the walker's profile and the block of
+  // per-engine constants) is pulled into LDS in ONE batch of independent loads;
+  // the phases below then run out of LDS.  The kernel is pure latency: each
+  // dependent trip to memory it avoids is worth most of a microsecond.
   double *sProf = sm + 4 * L;                       // [(S+1)][L]
+  // from sPress on: the layout of p.consts
   double *sPress = sProf + (size_t)(S + 1) * L;     // [L]
   double *sDlnp = sPress + L;                       // [L]
   double *sMass = sDlnp + L;                        // [S]
   double *sTg = sMass + S;                          // [Nt]
-  double *sCiaT = sTg + p.Nt;                       // [ncia_temps]
-  {
-    const double *gp = p.prof + (size_t)w * (S + 1) * L;
-    for (int t = threadIdx.x; t < (S + 1) * L; t += blockDim.x) sProf[t] = gp[t];
-    for (int t = threadIdx.x; t < L; t += blockDim.x) {
-      sPress[t] = p.press[t];
-      sDlnp[t] = t + 1 < L ? p.dlnp[t] : 0.0;
-    }
-    for (int t = threadIdx.x; t < S; t += blockDim.x) sMass[t] = p.mass[t];
-    for (int t = threadIdx.x; t < p.Nt; t += blockDim.x) sTg[t] = p.tgrid[t];
-    for (int t = threadIdx.x; t < p.ncia_temps; t += blockDim.x) sCiaT[t] = p.cia_temp[t];
-  }
+  double *sTgInv = sTg + p.Nt;                      // [Nt]
+  double *sCiaT = sTgInv + p.Nt;                    // [ncia_temps]
+  double *sCiaTInv = sCiaT + p.ncia_temps;          // [ncia_temps]
+  stage2_to_lds(sProf, p.prof + (size_t)w * (S + 1) * L, (S + 1) * L, sPress, p.consts,
+                2 * L + S + 2 * p.Nt + 2 * p.ncia_temps, threadIdx.x, blockDim.x);
   const double *prof = sProf;
   __shared__ int sBad;
   if (threadIdx.x == 0) sBad = 0;
   __syncthreads();
-  for (int l = threadIdx.x; l < L; l += blockDim.x) {
-    double T = prof[l];
-    double mu = 0.0;
-    for (int s = 0; s < S; s++) mu += prof[(size_t)(s + 1) * L + l] * sMass[s];
-    sT[l] = T;
-    sMu[l] = mu;
-    if (!(T > 0.0) || !(T < 1e30) || !(mu > 0.0)) sBad = 1;
-  }
-  __syncthreads();
-  const bool bad = sBad != 0;
   // Hydrostatic radii, makeatm.py:229-258 (layers bottom -> top).  The
   // reference steps r_i = r_{i+-1} -+ H_i / g and rescales g by (r_old/r_new)^2,
   // i.e. g r^2 stays g0 R0^2: the step is r -+ (H_i / (g0 R0^2)) r^2.  The
-  // layer terms H_i are formed in parallel; only that two-flop recurrence is
+  // layer terms H_i are formed in parallel (each lane also evaluates its upper
+  // neighbour's T/mu rather than wait for it); only the two-flop recurrence is
   // serial (lane 0 walks down from the reference layer, lane 64 walks up).
-  double *sH = sm + 3 * L;
+  const double rgas = kKB / kAMU;
   {
-    const double rgas = kKB / kAMU;
     const double invG = 1.0 / (p.gsurf * p.refradius * p.refradius);
-    for (int i = threadIdx.x; i + 1 < L; i += blockDim.x)
-      sH[i] = 0.5 * (sT[i] / sMu[i] + sT[i + 1] / sMu[i + 1]) * (rgas * sDlnp[i]) * invG;
-    if (threadIdx.x == 0 && !bad) {
-      const int ix = p.ref_idx;
-      const double r0 = p.refradius, g0 = p.gsurf;
-      if (!p.ref_exact) {
-        const int b = p.ref_ib;
-        double t0 = sT[b] + p.ref_f * (sT[b + 1] - sT[b]);
-        double m0 = sMu[b] + p.ref_f * (sMu[b + 1] - sMu[b]);
-        sR[ix] = r0 + 0.5 * (sT[ix] / sMu[ix] + t0 / m0) * (rgas * p.ref_lnp / g0);
-      } else {
-        sR[ix] = r0;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+      const int lu = l + 1 < L ? l + 1 : l;
+      const double T = prof[l], Tu = prof[lu];
+      double mu = 0.0, muu = 0.0;
+      for (int s = 0; s < S; s++) {
+        mu += prof[(size_t)(s + 1) * L + l] * sMass[s];
+        muu += prof[(size_t)(s + 1) * L + lu] * sMass[s];
       }
+      sT[l] = T;
+      sMu[l] = mu;
+      sH[l] = 0.5 * (T / mu + Tu / muu) * (rgas * sDlnp[l]) * invG;
+      if (!(T > 0.0) || !(T < 1e30) || !(mu > 0.0)) sBad = 1;
     }
   }
   __syncthreads();
+  const bool bad = sBad != 0;
   if (!bad && (threadIdx.x == 0 || threadIdx.x == 64)) {
     const int ix = p.ref_idx;
-    double r = sR[ix];
+    double r = p.refradius;
+    if (!p.ref_exact) {
+      const int b = p.ref_ib;
+      const double t0 = sT[b] + p.ref_f * (sT[b + 1] - sT[b]);
+      const double m0 = sMu[b] + p.ref_f * (sMu[b + 1] - sMu[b]);
+      r += 0.5 * (sT[ix] / sMu[ix] + t0 / m0) * (rgas * p.ref_lnp / p.gsurf);
+    }
     // blocks of 8 terms are fetched from LDS ahead of the dependent chain
     if (threadIdx.x == 0) {
+      sR[ix] = r;
       int i = ix - 1;
       for (; i >= 7; i -= 8) {
         double h[8];
@@ -152,15 +145,17 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
       c[1] = 1.0;
       continue;
     }
+    // one division per layer (1/T); grid spacings come as reciprocals
     const double T = sT[l];
-    const double nd = sPress[l] / (kKB * T);
+    const double invT = 1.0 / T;
+    const double nd = sPress[l] * invT * (1.0 / kKB);
     c[0] = (k == 0) ? 0.0 : (sR[l + 1] - sR[l]);
-    c[1] = (kH * kLS / kKB) / T;
+    c[1] = (kH * kLS / kKB) * invT;
     int j = 0;
     double f = 0.0;
     if (M > 0) {
-      j = bracket_dev(sTg, p.Nt, T);
-      f = (T - sTg[j]) / (sTg[j + 1] - sTg[j]);
+      j = bracket_dev(sTg, sTgInv, p.Nt, T);
+      f = (T - sTg[j]) * sTgInv[j];
     }
     ix[0] = (idx_t)(((size_t)l * p.Nt + j) * M * p.W) * 8;
     for (int m = 0; m < M; m++) {
@@ -171,15 +166,15 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
     }
     for (int cc = 0; cc < C; cc++) {
       const int nt = p.cia_nt[cc];
-      const double *tg = sCiaT + p.cia_toff[cc];
+      const double *tg = sCiaT + p.cia_toff[cc], *tginv = sCiaTInv + p.cia_toff[cc];
       const double Tc = T < tg[0] ? tg[0] : (T > tg[nt - 1] ? tg[nt - 1] : T);
-      const double n1 = prof[(size_t)(p.cia_s1[cc] + 1) * L + l] * nd / kAMAGAT;
-      const double n2 = prof[(size_t)(p.cia_s2[cc] + 1) * L + l] * nd / kAMAGAT;
+      const double n1 = prof[(size_t)(p.cia_s1[cc] + 1) * L + l] * nd * (1.0 / kAMAGAT);
+      const double n2 = prof[(size_t)(p.cia_s2[cc] + 1) * L + l] * nd * (1.0 / kAMAGAT);
       int jc = 0;
       double fc = 0.0;
       if (nt > 1) {
-        jc = bracket_dev(tg, nt, Tc);
-        fc = (Tc - tg[jc]) / (tg[jc + 1] - tg[jc]);
+        jc = bracket_dev(tg, tginv, nt, Tc);
+        fc = (Tc - tg[jc]) * tginv[jc];
       }
       // a single-temperature table is stored twice so plane jc+1 exists
       ix[1 + cc] = (idx_t)(p.cia_toff[cc] + cc + jc) * p.W * 8;
@@ -254,8 +249,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   {
     const double *gC = p.coef + (size_t)w * L * NC;
     const idx_t *gI = p.idx + (size_t)w * L * NI;
-    for (int t = threadIdx.x; t < L * NC; t += blockDim.x) sC[t] = gC[t];
-    for (int t = threadIdx.x; t < L * NI; t += blockDim.x) sI[t] = gI[t];
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, blockDim.x);
   }
   __syncthreads();
 
@@ -466,8 +460,7 @@ void rt_eclipse_fast(RtArgs p) {
   {
     const double *gC = p.coef + (size_t)w * L * NC;
     const idx_t *gI = p.idx + (size_t)w * L * NI;
-    for (int t = threadIdx.x; t < L * NC; t += blockDim.x) sC[t] = gC[t];
-    for (int t = threadIdx.x; t < L * NI; t += blockDim.x) sI[t] = gI[t];
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, blockDim.x);
   }
   __syncthreads();
 
@@ -596,8 +589,7 @@ void rt_eclipse_split(RtArgs p) {
   {
     const double *gC = p.coef + (size_t)w * L * NC;
     const idx_t *gI = p.idx + (size_t)w * L * NI;
-    for (int t = threadIdx.x; t < L * NC; t += 128) sC[t] = gC[t];
-    for (int t = threadIdx.x; t < L * NI; t += 128) sI[t] = gI[t];
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, 128);
     if (threadIdx.x < 2) sFlag[threadIdx.x] = 0;
   }
   __syncthreads();
@@ -759,8 +751,7 @@ void rt_eclipse_lp(RtArgs p) {
     const int n = (L - k0 < CH ? L - k0 : CH);
     const double *gC = p.coef + ((size_t)w * L + k0) * NC;
     const idx_t *gI = p.idx + ((size_t)w * L + k0) * NI;
-    for (int t = lane; t < n * NC; t += 64) sC[k0 * NC + t] = gC[t];
-    for (int t = lane; t < n * NI; t += 64) sI[k0 * NI + t] = gI[t];
+    stage2_to_lds(sC + k0 * NC, gC, n * NC, sI + k0 * NI, gI, n * NI, lane, 64);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -881,8 +872,8 @@ void rt_eclipse_lp(RtArgs p) {
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
-  size_t sh = sizeof(double) * ((size_t)4 * a.L + (size_t)(a.S + 1) * a.L + 2 * a.L + a.S + a.Nt +
-                               a.ncia_temps + 1);
+  size_t sh = sizeof(double) * ((size_t)4 * a.L + (size_t)(a.S + 1) * a.L + 2 * a.L + a.S + 2 * a.Nt +
+                               2 * a.ncia_temps + 1);
   hipLaunchKernelGGL(prep_profiles, dim3(a.nwalkers), dim3(128), sh, st, a);
   return hipGetLastError();
 }

@@ -33,17 +33,53 @@ __host__ __device__ inline int coef_stride(int M, int C) { return 3 + 2 * M + 2 
 using idx_t = long long;
 __host__ __device__ inline int idx_stride(int C) { return 1 + C; }
 
+// Cooperative copy of two arrays of 8-byte words from global memory into LDS.
+// A thread issues up to U independent loads of each array before its first LDS
+// store.  (The plain `for (t = tid; t < n; t += nthreads) dst[t] = src[t]` loop
+// compiles, for a runtime trip count, to load / wait / store per element: n /
+// nthreads serial trips to memory at the head of every workgroup.)
+template <int U = 8, typename TA, typename TB>
+__device__ __forceinline__ void stage2_to_lds(TA *dstA, const TA *srcA, int nA, TB *dstB, const TB *srcB,
+                                              int nB, int tid, int nthreads) {
+  static_assert(sizeof(TA) == 8 && sizeof(TB) == 8, "8-byte words");
+  const int span = U * nthreads;
+  for (int base = 0; base < nA || base < nB; base += span) {
+    TA a[U];
+    TB b[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int t = base + j * nthreads + tid;
+      a[j] = t < nA ? srcA[t] : TA(0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int t = base + j * nthreads + tid;
+      b[j] = t < nB ? srcB[t] : TB(0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int t = base + j * nthreads + tid;
+      if (t < nA) dstA[t] = a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int t = base + j * nthreads + tid;
+      if (t < nB) dstB[t] = b[j];
+    }
+  }
+}
+
 struct PrepArgs {
   int L, S, M, Nt, C, W, nwalkers;
   const double *prof;      // [nw][(S+1)][L]
-  const double *press;     // [L] barye, atm order (0 = bottom)
-  const double *dlnp;      // [L-1] log(p[i]/p[i+1])
-  const double *mass;      // [S] amu
-  const double *tgrid;     // [Nt]
-  const int *opmol;        // [M] species index
+  // per-engine constants in one block, in the order prep_profiles lays them out in
+  // LDS: press[L] (barye, atm order, 0 = bottom), dlnp[L] (log(p[i]/p[i+1]), last
+  // 0), mass[S] (amu), tgrid[Nt], 1/(tgrid[j+1]-tgrid[j]) [Nt], cia_temp[ncia_temps]
+  // (concatenated), its reciprocal spacings [ncia_temps]
+  const double *consts;
+  int opmol[kMaxMol];      // [M] species index
   int cia_s1[kMaxCia], cia_s2[kMaxCia], cia_nt[kMaxCia], cia_toff[kMaxCia];
-  const double *cia_temp;  // concatenated
-  int ncia_temps;          // length of cia_temp
+  int ncia_temps;          // length of the concatenated CIA temperature grids
   // hydrostatic reference (code/makeatm.py:183-263)
   int ref_idx;             // layer closest to refpress
   int ref_exact;           // press[ref_idx] == refpress

@@ -265,8 +265,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
   {
     const double *gC = p.coef + (size_t)w * L * NC;
     const idx_t *gI = p.idx + (size_t)w * L * NI;
-    for (int t = threadIdx.x; t < L * NC; t += 256) sC[t] = gC[t];
-    for (int t = threadIdx.x; t < L * NI; t += 256) sI[t] = gI[t];
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, 256);
   }
   __syncthreads();
   const int i = tile0 + threadIdx.x;

@@ -32,8 +32,7 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   {
     const double *gC = p.coef + (size_t)w * L * NC;
     const idx_t *gI = p.idx + (size_t)w * L * NI;
-    for (int t = threadIdx.x; t < L * NC; t += 64) sC[t] = gC[t];
-    for (int t = threadIdx.x; t < L * NI; t += 64) sI[t] = gI[t];
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, 64);
   }
   __syncthreads();
 

@@ -23,13 +23,14 @@ struct StepArgs {
   int pnode[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double *d_gw = nullptr;
   // device
-  double *d_abund = nullptr;   // [L][S] base abundances
-  double *d_ratio = nullptr;   // [L] H2/He of the base abundances
-  double *d_pbar = nullptr;    // [L] pressure in bar, atm order
-  int *d_imol = nullptr;       // [nmolfit]
-  unsigned char *d_metal = nullptr;  // [S] 1 for metals
+  // abund[L][S] base abundances, ratio[L] H2/He of the base abundances, pbar[L]
+  // pressure in bar (atm order), in one block (step_profiles stages it as it lies)
+  double *d_consts = nullptr;
+  int imol[16] = {0};                // [nmolfit] species index of each fitted molecule
+  unsigned long long metal_mask = 0; // bit s: species s is a metal
   int *d_idx0 = nullptr, *d_npts = nullptr, *d_woff = nullptr;  // [F]
-  double *d_nifilter = nullptr, *d_istarfl = nullptr;          // [nwin]
+  // [nwin] per window sample: filter weight (x rprs^2 / stellar flux for eclipse)
+  double *d_gwt = nullptr;
   // workspaces
   int cap = 0;
   double *d_params = nullptr, *d_prof = nullptr, *d_spec = nullptr, *d_band = nullptr;

@@ -359,7 +359,7 @@ void Engine::ensure_walkers(int n) {
   re(d_rad, (size_t)cap * L);
   if (solution == 1) {
     re(d_rtop, (size_t)cap * L);
-    re(d_ds, (size_t)cap * L * L);
+    re(d_ds, (size_t)cap * chord_table_size(L));
   }
   cap_walkers = cap;
 }
@@ -419,6 +419,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.rtop = solution == 1 ? d_rtop : nullptr;
   pa.ds = solution == 1 ? d_ds : nullptr;
   HIPCHK(launch_prep(pa, st));
+  if (solution == 1) HIPCHK(launch_chord_table(pa, st));
 
   RtArgs r = rt;
   r.nwalkers = n;

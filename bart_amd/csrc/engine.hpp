@@ -13,6 +13,7 @@ namespace bartrt {
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st);
 hipError_t launch_transit(const RtArgs &a, hipStream_t st);
+hipError_t launch_chord_table(const PrepArgs &a, hipStream_t st);  // transit geometry, after launch_prep
 
 struct StepArgs;  // converters around the engine (step.hip)
 struct Lbl;       // line-by-line extinction (lbl.hip)

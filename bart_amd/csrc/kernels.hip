@@ -196,19 +196,9 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   if (p.rad_out)
     for (int l = threadIdx.x; l < L; l += blockDim.x) p.rad_out[(size_t)w * L + l] = bad ? 0.0 : sR[l];
   if (p.rtop && !bad) {
-    double *rt = p.rtop + (size_t)w * L, *ds = p.ds + (size_t)w * L * L;
+    // the chord table itself is filled from these radii by chord_table_fill
+    double *rt = p.rtop + (size_t)w * L;
     for (int k = threadIdx.x; k < L; k += blockDim.x) rt[k] = sR[L - 1 - k];
-    for (int t = threadIdx.x; t < L * L; t += blockDim.x) {
-      const int k = t / L, j = t % L;
-      double v = 0.0;
-      if (j >= 1 && j <= k) {
-        const double rk = sR[L - 1 - k], r0 = sR[L - j], r1 = sR[L - 1 - j];
-        const double s0 = sqrt((r0 - rk) * (r0 + rk));
-        const double s1 = (j == k) ? 0.0 : sqrt((r1 - rk) * (r1 + rk));
-        v = s0 - s1;
-      }
-      ds[t] = v;
-    }
   }
   if (threadIdx.x == 0) {
     int ks = L - 1;
@@ -326,117 +316,6 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     }
   }
 }
-
-// ---------------------------------------------------------------------------
-// exp(x) for finite x <= ~700 without the special-case selects of the library
-// routine: Cody-Waite reduction by ln2, degree-11 interpolant on
-// [-ln2/2, ln2/2] (Chebyshev nodes, max relative error 1.7e-17 before
-// rounding), scaling by ldexp (underflows to 0 for very negative x).
-__device__ __forceinline__ double exp_core(double x) {
-  const double n = __builtin_rint(x * 1.4426950408889634074);
-  double r = fma(n, -6.93147180369123816490e-01, x);
-  r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 2.5110037605963777e-08;
-  p = fma(p, r, 2.763263963904103e-07);
-  p = fma(p, r, 2.755724091857897e-06);
-  p = fma(p, r, 2.4801485482328494e-05);
-  p = fma(p, r, 0.00019841269890047113);
-  p = fma(p, r, 0.0013888888952314775);
-  p = fma(p, r, 0.008333333333319601);
-  p = fma(p, r, 0.0416666666664881);
-  p = fma(p, r, 0.1666666666666668);
-  p = fma(p, r, 0.5000000000000019);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)n);
-}
-
-// 1/d for normal, positive d: hardware estimate + two Newton steps.
-__device__ __forceinline__ double rcp_core(double d) {
-  double y = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-d, y, 1.0);
-  return fma(y, e, y);
-}
-
-// exp() of N independent arguments with the Horner steps interleaved across
-// the arguments: one wave alone on a SIMD then overlaps the N dependent FMA
-// chains instead of paying the fp64 pipeline latency N x 12 times in a row.
-template <int N>
-__device__ __forceinline__ void exp_core_n(const double (&x)[N], double (&out)[N]) {
-  double n[N], r[N], q[N];
-#pragma unroll
-  for (int a = 0; a < N; a++) {
-    n[a] = __builtin_rint(x[a] * 1.4426950408889634074);
-    r[a] = fma(n[a], -6.93147180369123816490e-01, x[a]);
-  }
-#pragma unroll
-  for (int a = 0; a < N; a++) r[a] = fma(n[a], -1.90821492927058770002e-10, r[a]);
-  constexpr double cf[11] = {2.763263963904103e-07, 2.755724091857897e-06, 2.4801485482328494e-05,
-                             0.00019841269890047113, 0.0013888888952314775, 0.008333333333319601,
-                             0.0416666666664881, 0.1666666666666668, 0.5000000000000019, 1.0, 1.0};
-#pragma unroll
-  for (int a = 0; a < N; a++) q[a] = 2.5110037605963777e-08;
-#pragma unroll
-  for (int j = 0; j < 11; j++) {
-#pragma unroll
-    for (int a = 0; a < N; a++) q[a] = fma(q[a], r[a], cf[j]);
-  }
-#pragma unroll
-  for (int a = 0; a < N; a++) out[a] = __builtin_amdgcn_ldexp(q[a], (int)n[a]);
-}
-
-// The 2M+2C table values one lane needs for a layer, fetched with buffer loads:
-// one 128-bit descriptor over the opacity grid and one over the CIA block (built
-// from wave-uniform values), a loop-invariant 32-bit lane offset per value in a
-// VGPR, and the layer's plane offset (from the LDS offset record) as the scalar
-// operand -- a layer costs no vector address arithmetic at all.
-template <int M, int C>
-struct TableLoader {
-  static constexpr int NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1, NI = 1 + C;
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  unsigned voff[NR];
-  decltype(__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, (short)0, 0, 0)) rs_k, rs_c;
-  const idx_t *sI;
-
-  // ii: this lane's wavenumber index; sI: the walker's offset records in LDS
-  __device__ __forceinline__ TableLoader(const RtArgs &p, unsigned ii, const idx_t *sI_) : sI(sI_) {
-    const unsigned off = ii * 8u;  // byte offset of this lane inside a table row
-    const size_t rowB = (size_t)p.W * 8, planeB = (size_t)M * p.W * 8;
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-      voff[2 * m] = off + (unsigned)(m * rowB);
-      voff[2 * m + 1] = off + (unsigned)(planeB + m * rowB);
-    }
-#pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      voff[2 * M + 2 * cc] = off;
-      voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
-    }
-    rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
-    rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
-  }
-
-  // issue the loads of layer k into r (no wait)
-  __device__ __forceinline__ void load(int k, double (&r)[NR]) const {
-    const idx_t *ix = sI + k * NI;
-    if (M > 0) {
-      const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
-#pragma unroll
-      for (int j = 0; j < 2 * M; j++)
-        r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
-    }
-#pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-        r[2 * M + 2 * cc + h] = __builtin_bit_cast(
-            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + h], so, 0));
-    }
-  }
-};
 
 // Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
 // bases (SGPR) + one 32-bit lane offset for every load, and a ring of PF layers

@@ -11,7 +11,25 @@
 // (scalar) loads.  The chord loop stops at the first tau_k > toomuch: deeper
 // rays are opaque and their layers are never read.
 //     M = (r_top^2 - 2 int exp(-tau(b)) b db) / R_star^2      (trapezoid in b)
+//
+// rt_transit is the generic form (any layer count, runtime molecule / CIA
+// counts, line-by-line extinction, tau output).  rt_transit_mfma is the one the
+// batched path runs.  Per wavenumber the chord depths are a lower-triangular
+// matrix-vector product tau = DS P (L^2/2 multiply-adds, P_j = e_{j-1} + e_j), so
+// for 16 wavenumbers at a time it is a [16 x L] x [L x 16-chord tile] matrix
+// product: v_mfma_f64_16x16x4 with M = wavenumber, N = chord, K = layer.  A wave
+// takes 16 wavenumbers; lane (q = l/16, m = l%16) computes the extinction of
+// wavenumber m in the layers j = 4 s + q only, which is exactly the A operand
+// of step s, so the pair sums never leave the lane's registers; the B operands
+// are 512-byte coalesced loads of the chord table prep_profiles wrote in that
+// order.  The result tile leaves chord 16 kt + m of wavenumbers q, q+4, q+8, q+12
+// in lane (q, m): transmission and the trapezoid in b are then per lane, the
+// `toomuch` cut is a ballot over the 16 lanes of a row, and the sum over chords
+// a 16-lane reduction at the very end.
 #include "kernels.hpp"
+
+#include <cstdlib>
+#include <string>
 
 namespace bartrt {
 
@@ -43,7 +61,7 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   const double nu4 = (nu * nu) * (nu * nu);
   const size_t MW = (size_t)M * W;
   const double *rt = p.rtop + (size_t)w * L;
-  const double *dsw = p.ds + (size_t)w * L * L;
+  const double *dsw = p.ds + (size_t)w * chord_table_size(L);
 
   const int kend = p.kstop[w];
   double eprev = 0.0, tau = 0.0, integ = 0.0, gprev = rt[0];
@@ -64,9 +82,8 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
     }
     if (k > 0) {
       sP[(size_t)k * 64 + threadIdx.x] = eprev + e;
-      const double *dk = dsw + (size_t)k * L;
       double t = 0.0;
-      for (int j = 1; j <= k; j++) t = fma(sP[(size_t)j * 64 + threadIdx.x], dk[j], t);
+      for (int j = 1; j <= k; j++) t = fma(sP[(size_t)j * 64 + threadIdx.x], dsw[chord_table_index(L, k, j)], t);
       if (active) {
         tau = t;
         const double g = exp(-t) * rt[k];
@@ -91,6 +108,170 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   }
 }
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kMfmaTiles = 8;  // row tiles of 16 chords: L <= 128
+
+template <int MT, int CT>
+__global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
+  const int L = p.L, W = p.W;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, jb = b >> 3;
+  const int w = jb % p.nwalkers;
+  const int tile = (jb / p.nwalkers) * 8 + xcd;  // 64 wavenumbers per workgroup
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  double *sRt = smem + (size_t)L * NC + (size_t)L * NI;  // radii top -> bottom, [L]
+  stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
+                threadIdx.x, 256);
+  if ((int)threadIdx.x < L) sRt[threadIdx.x] = p.rtop[(size_t)w * L + threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, m = lane & 15;
+  const int i0 = tile * 64 + (threadIdx.x >> 6) * 16;  // this wave's first wavenumber
+  if (i0 >= W) return;
+  const unsigned ii = i0 + m < W ? (unsigned)(i0 + m) : (unsigned)(W - 1);
+  const double nu = p.wn[ii];
+  const double nu4 = (nu * nu) * (nu * nu);
+  const int kend = p.kstop[w];
+  const int nkt = (L + 15) / 16, ns = 4 * nkt;
+  const double *__restrict__ dsm = p.ds + (size_t)w * chord_table_size(L);
+
+  // table loads: per-lane byte offset = plane offset of the lane's layer + row + lane
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
+  const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
+  auto load_layer = [&](int j, double (&r)[NR]) {
+    const idx_t *ix = sI + j * NI;
+    if (M > 0) {
+      const unsigned po = (unsigned)ix[0] + off;
+#pragma unroll
+      for (int mm = 0; mm < M; mm++) {
+        r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
+        r[2 * mm + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + planeB + mm * rowB), 0, 0));
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const unsigned po = (unsigned)ix[1 + cc] + off;
+      r[2 * M + 2 * cc] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)po, 0, 0));
+      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)(po + rowB), 0, 0));
+    }
+  };
+
+  double P[4 * kMfmaTiles];  // pair sums e_{j-1} + e_j of this lane's layers j = 4 s + q
+  double ecarry = 0.0;       // lanes q = 0: extinction of layer j - 1, from row q = 3 one step back
+  double integ[4] = {0.0, 0.0, 0.0, 0.0};
+  double gcarry[4];          // exp(-tau) r of the last chord of the previous tile
+  bool active[4] = {true, true, true, true};
+  const double r_top = sRt[0];
+#pragma unroll
+  for (int r = 0; r < 4; r++) gcarry[r] = r_top;
+
+#pragma unroll
+  for (int kt = 0; kt < kMfmaTiles; kt++) {
+    const int k0 = 16 * kt;
+    if (k0 > kend) break;
+    // ---- extinction of the tile's 16 layers: 4 per lane row
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int s = 4 * kt + t, j = 4 * s + q;
+      const int jc = j < kend ? j : kend;
+      double rv[NR];
+      load_layer(jc, rv);
+      const double *c = sC + jc * NC;
+      double e = c[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+      for (int x = 0; x < NLD; x++) e = fma(c[2 + x], rv[x], e);
+      const double below = __shfl(e, (lane + 48) & 63);  // row q - 1, i.e. layer j - 1 (q >= 1)
+      const double eprev = q == 0 ? ecarry : below;
+      ecarry = below;
+      P[s] = (j >= 1 && j <= kend) ? eprev + e : 0.0;
+    }
+    // ---- tau of chords k0 .. k0 + 15 for the wave's 16 wavenumbers
+    // (one accumulation chain; four interleaved ones and an explicit one-step
+    // prefetch of the table values both measured slower: the loop is fully unrolled
+    // and the compiler already hoists the loads)
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const double *__restrict__ bt = dsm + (size_t)kt * ns * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 4 * kt + 4; s++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], bt[(size_t)s * 64], acc, 0, 0, 0);
+    // ---- lane (q, m): chord k of wavenumbers q + 4 r
+    const int k = k0 + m;
+    const bool kvalid = k >= 1 && k <= kend;
+    const double rk = k < L ? sRt[k] : 0.0;
+    const double dr = kvalid ? sRt[k - 1] - rk : 0.0;
+    bool any_active = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const double tau = acc[r];
+      const double g = exp_core(fmax(-tau, -745.0)) * rk;
+      double gprev = __shfl_up(g, 1, 16);
+      if (m == 0) gprev = gcarry[r];
+      const unsigned long long over = __ballot(kvalid && tau > p.toomuch);
+      const unsigned rowbits = (unsigned)(over >> (16 * q)) & 0xffffu;
+      const bool counts = kvalid && active[r] && (rowbits & ((1u << m) - 1u)) == 0u;
+      integ[r] += counts ? 0.5 * (gprev + g) * dr : 0.0;
+      active[r] = active[r] && rowbits == 0u;
+      gcarry[r] = __shfl(g, 16 * q + 15);
+      any_active = any_active || active[r];
+    }
+    if (!__any(any_active)) break;
+  }
+  // sum over the 16 chords a row holds; lane m = 0 of row q writes wavenumbers q + 4 r
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double s = integ[r];
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+    const int iw = i0 + q + 4 * r;
+    if (m == 0 && iw < W) p.spec[(size_t)w * W + iw] = (r_top * r_top - 2.0 * s) * p.inv_starrad2;
+  }
+}
+
+// Chord table from the radii prep_profiles wrote: one lane per entry the RT
+// kernels read (row tile kt uses steps s < 4 kt + 4), DS(k, j) = s_{j-1} - s_j.
+__global__ __launch_bounds__(256) void chord_table_fill(int L, const double *rtop, double *ds) {
+  const int w = blockIdx.y, kt = blockIdx.x;
+  const int nkt = (L + 15) / 16, ns = 4 * nkt;
+  const double *rt = rtop + (size_t)w * L;
+  double *tile = ds + (size_t)w * chord_table_size(L) + (size_t)kt * ns * 64;
+  for (int t = threadIdx.x; t < (4 * kt + 4) * 64; t += 256) {
+    const int lane = t & 63, k = 16 * kt + (lane & 15), j = 4 * (t >> 6) + (lane >> 4);
+    double v = 0.0;
+    if (k < L && j >= 1 && j <= k) {
+      const double rk = rt[k], r0 = rt[j - 1], r1 = rt[j];
+      const double s0 = sqrt((r0 - rk) * (r0 + rk));
+      const double s1 = (j == k) ? 0.0 : sqrt((r1 - rk) * (r1 + rk));
+      v = s0 - s1;
+    }
+    tile[t] = v;
+  }
+}
+
+hipError_t launch_chord_table(const PrepArgs &a, hipStream_t st) {
+  if (a.nwalkers <= 0 || !a.rtop || !a.ds) return hipSuccess;
+  hipLaunchKernelGGL(chord_table_fill, dim3((a.L + 15) / 16, a.nwalkers), dim3(256), 0, st, a.L,
+                     a.rtop, a.ds);
+  return hipGetLastError();
+}
+
+// dynamic LDS above the 64 kB default has to be opted into, once per kernel
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes, size_t &allowed) {
+  if (bytes <= allowed) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) allowed = bytes;
+  return e;
+}
+
 hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0 || a.W <= 0) return hipSuccess;
   const int ntiles8 = (a.ntiles + 7) / 8 * 8;
@@ -98,11 +279,30 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   const size_t sh = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
                                       (size_t)a.L * idx_stride(a.C) + (size_t)a.L * 64);
   if (sh > 160 * 1024) return hipErrorInvalidValue;
-  if (sh > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_transit),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return e;
+  static const bool generic_only = [] {
+    const char *e = std::getenv("BARTRT_KERNEL");
+    return e && std::string(e) == "generic";
+  }();
+  const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
+  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTiles) {
+    RtArgs b = a;
+    b.ntiles = (a.W + 63) / 64;
+    const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+    const size_t shm = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
+                                         (size_t)a.L * idx_stride(a.C) + (size_t)a.L);
+#define BARTRT_TRANSIT(MM, CC)                                                              \
+  if (a.M == MM && a.C == CC) {                                                             \
+    hipLaunchKernelGGL((rt_transit_mfma<MM, CC>), dim3(nb), dim3(256), shm, st, b);         \
+    return hipGetLastError();                                                               \
   }
+    BARTRT_TRANSIT(1, 0) BARTRT_TRANSIT(1, 1) BARTRT_TRANSIT(2, 0) BARTRT_TRANSIT(2, 1)
+    BARTRT_TRANSIT(3, 1) BARTRT_TRANSIT(4, 0) BARTRT_TRANSIT(4, 1) BARTRT_TRANSIT(5, 1)
+    BARTRT_TRANSIT(6, 1)
+#undef BARTRT_TRANSIT
+  }
+  static size_t allowed = 48 * 1024;
+  hipError_t e = allow_lds(rt_transit, sh, allowed);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(rt_transit, dim3(nblocks), dim3(64), sh, st, a);
   return hipGetLastError();
 }

@@ -104,6 +104,30 @@ def test_device_matches_oracle(tmp_path, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nlayers,nwave", [(16, 15), (17, 65), (100, 130), (128, 64), (129, 40)])
+def test_matrix_tiles_and_cloud_deck(tmp_path, nlayers, nwave):
+    """The batched transit kernel works in 16-chord x 16-wavenumber matrix tiles
+    (up to 128 layers; 129 falls through to the generic kernel): layer counts at
+    tile edges, fewer wavenumbers than a wave, and an opaque cloud deck moved
+    through the column so the stop layer lands in every row tile."""
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    from test_gpu_parity import walkers
+    c = _case(tmp_path, nlayers=nlayers, nwave=nwave)
+    engine.init(c.tcfg)
+    try:
+        o = orc.OracleEngine(c.tcfg)
+        profs = walkers(c, 2, seed=12)
+        np.testing.assert_allclose(engine.run_batch(profs), o.run_batch(profs), rtol=RTOL)
+        lp = np.log10(c.press_bar)
+        for ct in np.linspace(lp.min() - 0.3, lp.max() + 0.3, 9):
+            trm.set_cloudtop(float(ct)); o.set_cloudtop(float(ct))
+            np.testing.assert_allclose(engine.run_batch(profs), o.run_batch(profs), rtol=RTOL)
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
 def test_worker_transit_solution(tmp_path):
     """solution = transit: Rp is a fitted parameter fed through set_radius, the
     bands are plain filter averages of the modulation (BARTfunc.py:391-393)."""

@@ -1,0 +1,47 @@
+"""Transit (transmission) geometry on the bench grid: modulation spectra/s.
+usage: python tools/transit_bench.py [walkers ...]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from bart_amd import engine, synth, transit_module as trm  # noqa: E402
+
+
+def main():
+    batches = [int(a) for a in sys.argv[1:]] or [1, 10, 64, 256]
+    d = os.path.join(tempfile.gettempdir(), "bartrt_transitbench")
+    case = synth.make_case(d, nlayers=100, nwave=10000, reuse=True,
+                           extra_keys={"solution": "transit", "starrad": 1.145})
+    engine.init(case.tcfg)
+    for n in batches:
+        nsets = 8
+        profs = bench.make_profiles(case, n * nsets, seed=11).reshape(nsets, n, -1)
+        d_prof = torch.from_numpy(profs).cuda()
+        out = torch.empty((n, 10000), dtype=torch.float64, device="cuda")
+        steps = max(5, min(100, 1000 // n))
+        for i in range(3):
+            engine.run_batch_dev(d_prof[i % nsets], out)
+        torch.cuda.synchronize()
+        engine.timing_begin()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            engine.run_batch_dev(d_prof[i % nsets], out)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kms, nl = engine.timing_end()
+        print(json.dumps({"workload": "transit geometry, 100 layers x 1e4 wavenumbers", "walkers": n,
+                          "spectra_per_s": round(n * steps / dt), "ms_per_step": round(dt / steps * 1e3, 4),
+                          "rt_kernel_ms": round(kms / max(nl, 1), 4),
+                          "depth_min_max": [float(out.min()), float(out.max())]}), flush=True)
+    trm.free_memory()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,9 @@ int bartrt_get_pressure(double *out, int n) {
   return BARTRT_OK;
 }
 
+// host-buffer calls up to this size skip the staging copies (see below)
+static constexpr size_t kZeroCopyBytes = 512 * 1024;
+
 int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
                              double *spec, int nwave, unsigned char *ok) {
   NEED_ENGINE();
@@ -141,12 +144,26 @@ int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
     const size_t sb = sizeof(double) * (size_t)nwalkers * Wl;
     e->ensure_pin(pb + sb + nwalkers);
     std::memcpy(e->h_pin, prof, pb);
-    HIPCHK(hipMemcpyAsync(e->d_prof, e->h_pin, pb, hipMemcpyHostToDevice, e->stream));
-    e->run_dev(e->d_prof, nwalkers, e->d_spec, e->d_ok, e->stream, false);
     double *hs = e->h_pin + (size_t)nwalkers * nprof;
     unsigned char *hok = reinterpret_cast<unsigned char *>(hs + (size_t)nwalkers * Wl);
-    HIPCHK(hipMemcpyAsync(hs, e->d_spec, sb, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(hok, e->d_ok, nwalkers, hipMemcpyDeviceToHost, e->stream));
+    if (pb + sb <= kZeroCopyBytes) {
+      // a walker or a few: the kernels read the profiles from, and write the
+      // spectra to, the pinned host buffer themselves (three copy operations
+      // cost more than the kernels at this size)
+      void *dev = nullptr;
+      HIPCHK(hipHostGetDevicePointer(&dev, e->h_pin, 0));
+      double *dp = static_cast<double *>(dev);
+      e->run_dev(dp, nwalkers, dp + (size_t)nwalkers * nprof,
+                 reinterpret_cast<unsigned char *>(dp + (size_t)nwalkers * nprof + (size_t)nwalkers * Wl),
+                 e->stream, false);
+      e->last_prof = dp;   // stays valid until the next host-buffer call
+    } else {
+      e->last_prof = e->d_prof;
+      HIPCHK(hipMemcpyAsync(e->d_prof, e->h_pin, pb, hipMemcpyHostToDevice, e->stream));
+      e->run_dev(e->d_prof, nwalkers, e->d_spec, e->d_ok, e->stream, false);
+      HIPCHK(hipMemcpyAsync(hs, e->d_spec, sb, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(hok, e->d_ok, nwalkers, hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t off = nwave == Wl ? 0 : (size_t)e->lo;
     for (int w = 0; w < nwalkers; w++)
@@ -177,9 +194,10 @@ int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
   if (!tau || nwave != e->W() || nlayers != e->L)
     return fail(BARTRT_EINVAL, "get_tau: shape must be [local samples][nlayers]");
   return guarded([&] {
-    // re-run the most recent single profile (still in d_prof[0]) with the
+    // re-run the most recent profile of a host-buffer call with the
     // optical-depth output enabled
-    e->run_dev(e->d_prof, 1, e->d_spec, e->d_ok, e->stream, true);
+    if (!e->last_prof) throw IoError{"get_tau: no spectrum has been computed yet"};
+    e->run_dev(e->last_prof, 1, e->d_spec, e->d_ok, e->stream, true);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(tau, e->d_tau, sizeof(double) * (size_t)nwave * nlayers, hipMemcpyDeviceToHost));
     if (last) HIPCHK(hipMemcpy(last, e->d_last, sizeof(int) * (size_t)nwave, hipMemcpyDeviceToHost));
@@ -223,9 +241,10 @@ int bartrt_get_intensity(double *intens, int nangles, int nwave) {
   if (e->solution != 0) return fail(BARTRT_EINVAL, "get_intensity: eclipse geometry only");
   if (!intens || nangles != e->A || nwave != e->W()) return fail(BARTRT_EINVAL, "get_intensity: bad shape");
   return guarded([&] {
+    if (!e->last_prof) throw IoError{"get_intensity: no spectrum has been computed yet"};
     e->want_intens = true;
     try {
-      e->run_dev(e->d_prof, 1, e->d_spec, e->d_ok, e->stream, false);
+      e->run_dev(e->last_prof, 1, e->d_spec, e->d_ok, e->stream, false);
     } catch (...) { e->want_intens = false; throw; }
     e->want_intens = false;
     HIPCHK(hipStreamSynchronize(e->stream));

@@ -350,6 +350,7 @@ void Engine::ensure_walkers(int n) {
     p = nullptr;
     HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(*p)));
   };
+  if (last_prof == d_prof) last_prof = nullptr;
   re(d_prof, (size_t)cap * (S + 1) * L);
   re(d_coef, (size_t)cap * L * coef_stride(M, C));
   re(d_idx, (size_t)cap * L * idx_stride(C));
@@ -368,6 +369,7 @@ void Engine::ensure_pin(size_t bytes) {
   if (bytes <= h_pin_bytes) return;
   if (h_pin) HIPCHK(hipHostFree(h_pin));
   h_pin = nullptr;
+  last_prof = nullptr;
   HIPCHK(hipHostMalloc(&h_pin, bytes, hipHostMallocDefault));
   h_pin_bytes = bytes;
 }

@@ -43,6 +43,7 @@ struct Engine {
   // workspaces (grown on demand, never inside a timed launch sequence twice)
   int cap_walkers = 0;
   double *d_prof = nullptr, *d_coef = nullptr, *d_spec = nullptr;
+  const double *last_prof = nullptr;  // first profile of the latest host-buffer call (get_tau, get_intensity)
   idx_t *d_idx = nullptr;
   int *d_kstop = nullptr;
   double *d_rtop = nullptr, *d_ds = nullptr;  // transit geometry workspaces

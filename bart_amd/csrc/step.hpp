@@ -33,7 +33,7 @@ struct StepArgs {
   double *d_gwt = nullptr;
   // workspaces
   int cap = 0;
-  double *d_params = nullptr, *d_prof = nullptr, *d_spec = nullptr, *d_band = nullptr;
+  double *d_prof = nullptr, *d_spec = nullptr;
   int *d_status = nullptr;
   ~StepArgs();
 };
@@ -48,10 +48,11 @@ void step_ensure(Engine &e, int n);
 void step_profiles_dev(Engine &e, const double *d_params, int n, int npars, double *d_prof,
                        int *d_status, hipStream_t st);
 // full-grid spectra [n][Wfull] -> bandflux[n][F]; may flip status to 3 (energy)
+// status_out (optional, device-accessible): final status per walker
 void step_bandflux_dev(Engine &e, const double *d_spec_full, int n, int *d_status,
-                       double *d_bandflux, hipStream_t st);
+                       double *d_bandflux, hipStream_t st, int *status_out = nullptr);
 void step_run_dev(Engine &e, const double *d_params, int n, int npars, double *d_bandflux,
-                  int *d_status, double *d_spec, hipStream_t st);
+                  int *d_status, double *d_spec, hipStream_t st, int *status_out = nullptr);
 void step_run_host(Engine &e, const double *params, int n, int npars, double *bandflux,
                    int *status);
 

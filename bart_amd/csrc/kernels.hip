@@ -358,6 +358,7 @@ void rt_eclipse_fast(RtArgs p) {
   double tau = 0.0, eprev = 0.0, Bprev = 0.0;
   bool active = true;
   const int kend = p.kstop[w];
+  const double tcap = tau_cap(p, A);
 
   // One layer's arithmetic.  Straight-line: layer indices past the end are
   // clamped and masked instead of branched around, so that inside an unrolled
@@ -380,10 +381,11 @@ void rt_eclipse_fast(RtArgs p) {
     const double dtau = (eprev + e) * cf[0] * lv;
     tau += dtau;
     // Planck exponent and the A slant-path exponents in one interleaved batch
+    const double tc = fmin(tau, tcap);
     double xs[A + 1], es[A + 1];
     xs[A] = fmin(cf[1] * nu, 700.0);
 #pragma unroll
-    for (int a = 0; a < A; a++) xs[a] = fmax(-tau * p.invmu[a], -745.0);
+    for (int a = 0; a < A; a++) xs[a] = -tc * p.invmu[a];
     exp_core_n<A + 1>(xs, es);
     const double B = bnum * rcp_core(es[A] - 1.0);
     const double hb = (Bprev + B) * lv;
@@ -546,6 +548,7 @@ void rt_eclipse_split(RtArgs p) {
     double I[A], fprev[A];
 #pragma unroll
     for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }
+    const double tcap = tau_cap(p, A);
     for (int blk = 0; blk < nblk; blk++) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -554,10 +557,10 @@ void rt_eclipse_split(RtArgs p) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const double *slot = sX + ((blk & 1) * 4 + u) * 128;
-        const double tau = slot[lane], hb = slot[64 + lane];
+        const double tc = fmin(slot[lane], tcap), hb = slot[64 + lane];
         double xs[A], es[A];
 #pragma unroll
-        for (int a = 0; a < A; a++) xs[a] = fmax(-tau * p.invmu[a], -745.0);
+        for (int a = 0; a < A; a++) xs[a] = -tc * p.invmu[a];
         exp_core_n<A>(xs, es);
 #pragma unroll
         for (int a = 0; a < A; a++) {
@@ -696,6 +699,7 @@ void rt_eclipse_lp(RtArgs p) {
     }
     if (__any(!cut)) {
       const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+      const double tcap = tau_cap(p, A);
       double I[A], fprev[A], Bprev = 0.0;
 #pragma unroll
       for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }
@@ -703,7 +707,7 @@ void rt_eclipse_lp(RtArgs p) {
         double xs[A + 1], es[A + 1];
         xs[A] = fmin(sC[(k0 - 1) * NC + 1] * nu, 700.0);
 #pragma unroll
-        for (int a = 0; a < A; a++) xs[a] = fmax(-tup * p.invmu[a], -745.0);
+        for (int a = 0; a < A; a++) xs[a] = -fmin(tup, tcap) * p.invmu[a];
         exp_core_n<A + 1>(xs, es);
         Bprev = bnum * rcp_core(es[A] - 1.0);
 #pragma unroll
@@ -713,11 +717,11 @@ void rt_eclipse_lp(RtArgs p) {
       for (int j = 0; j < CH; j++) {
         const int k = k0 + j;
         const bool live = !cut && k <= kend;
-        const double tau = t0 + tl[j];
+        const double tau = t0 + tl[j], tc = fmin(tau, tcap);
         double xs[A + 1], es[A + 1];
         xs[A] = fmin(sC[clampk(k) * NC + 1] * nu, 700.0);
 #pragma unroll
-        for (int a = 0; a < A; a++) xs[a] = fmax(-tau * p.invmu[a], -745.0);
+        for (int a = 0; a < A; a++) xs[a] = -tc * p.invmu[a];
         exp_core_n<A + 1>(xs, es);
         const double B = bnum * rcp_core(es[A] - 1.0);
         const double hb = (Bprev + B) * (live ? 0.5 : 0.0);

@@ -138,12 +138,23 @@ struct RtArgs {
 };
 
 // ---------------------------------------------------------------------------
-// exp(x) for finite x <= ~700 without the special-case selects of the library
-// routine: Cody-Waite reduction by ln2, degree-11 interpolant on
-// [-ln2/2, ln2/2] (Chebyshev nodes, max relative error 1.7e-17 before
-// rounding), scaling by ldexp (underflows to 0 for very negative x).
+// exp(x) for -708 <= x <= 709 (callers clamp) without the special-case selects
+// of the library routine: the integer part n of x / ln2 comes out of one FMA
+// with the 1.5 * 2^52 shifter (its low dword is n), Cody-Waite reduction by ln2,
+// degree-11 interpolant on [-ln2/2, ln2/2] (Chebyshev nodes, max relative error
+// 1.7e-17 before rounding), and 2^n is applied by adding n to the exponent
+// field (the result stays normal on that range).  16 VALU operations.
+constexpr double kExpShift = 6755399441055744.0;  // 1.5 * 2^52
+constexpr double kExpMin = -708.0;
+
+__device__ __forceinline__ double exp_scale(double p, double shifted) {
+  const int hi = __double2hiint(p) + (__double2loint(shifted) << 20);
+  return __hiloint2double(hi, __double2loint(p));
+}
+
 __device__ __forceinline__ double exp_core(double x) {
-  const double n = __builtin_rint(x * 1.4426950408889634074);
+  const double t = fma(x, 1.4426950408889634074, kExpShift);
+  const double n = t - kExpShift;
   double r = fma(n, -6.93147180369123816490e-01, x);
   r = fma(n, -1.90821492927058770002e-10, r);
   double p = 2.5110037605963777e-08;
@@ -158,7 +169,7 @@ __device__ __forceinline__ double exp_core(double x) {
   p = fma(p, r, 0.5000000000000019);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)n);
+  return exp_scale(p, t);
 }
 
 // 1/d for normal, positive d: hardware estimate + two Newton steps.
@@ -175,14 +186,15 @@ __device__ __forceinline__ double rcp_core(double d) {
 // chains instead of paying the fp64 pipeline latency N x 12 times in a row.
 template <int N>
 __device__ __forceinline__ void exp_core_n(const double (&x)[N], double (&out)[N]) {
-  double n[N], r[N], q[N];
+  double t[N], r[N], q[N];
+#pragma unroll
+  for (int a = 0; a < N; a++) t[a] = fma(x[a], 1.4426950408889634074, kExpShift);
 #pragma unroll
   for (int a = 0; a < N; a++) {
-    n[a] = __builtin_rint(x[a] * 1.4426950408889634074);
-    r[a] = fma(n[a], -6.93147180369123816490e-01, x[a]);
+    const double n = t[a] - kExpShift;
+    r[a] = fma(n, -6.93147180369123816490e-01, x[a]);
+    r[a] = fma(n, -1.90821492927058770002e-10, r[a]);
   }
-#pragma unroll
-  for (int a = 0; a < N; a++) r[a] = fma(n[a], -1.90821492927058770002e-10, r[a]);
   constexpr double cf[11] = {2.763263963904103e-07, 2.755724091857897e-06, 2.4801485482328494e-05,
                              0.00019841269890047113, 0.0013888888952314775, 0.008333333333319601,
                              0.0416666666664881, 0.1666666666666668, 0.5000000000000019, 1.0, 1.0};
@@ -194,14 +206,18 @@ __device__ __forceinline__ void exp_core_n(const double (&x)[N], double (&out)[N
     for (int a = 0; a < N; a++) q[a] = fma(q[a], r[a], cf[j]);
   }
 #pragma unroll
-  for (int a = 0; a < N; a++) out[a] = __builtin_amdgcn_ldexp(q[a], (int)n[a]);
+  for (int a = 0; a < N; a++) out[a] = exp_scale(q[a], t[a]);
 }
 
-// The 2M+2C table values one lane needs for a layer, fetched with buffer loads:
-// one 128-bit descriptor over the opacity grid and one over the CIA block (built
-// from wave-uniform values), a loop-invariant 32-bit lane offset per value in a
-// VGPR, and the layer's plane offset (from the LDS offset record) as the scalar
-// operand -- a layer costs no vector address arithmetic at all.
+// Largest optical depth whose slant transmittances exp(-tau / mu_a) all stay in
+// exp_core's range; beyond it they are floored at e^-708 .. e^-(708 mu_min/mu_a)
+// instead of running on to zero (differences below 1e-50 of the top layers' terms).
+__device__ __forceinline__ double tau_cap(const RtArgs &p, int A) {
+  double m = p.invmu[0];
+  for (int a = 1; a < A; a++) m = p.invmu[a] > m ? p.invmu[a] : m;
+  return -kExpMin / m;
+}
+
 template <int M, int C>
 struct TableLoader {
   static constexpr int NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1, NI = 1 + C;

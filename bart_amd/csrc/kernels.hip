@@ -13,8 +13,10 @@
 // read back as wave-uniform broadcasts.  HBM-bound: no MFMA anywhere.
 #include "kernels.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <string>
+#include <utility>
 
 // upper bound on resident waves per SIMD the specialised kernels are compiled
 // for: lets the compiler spend registers on loads in flight (measured best: 3-4)
@@ -318,11 +320,15 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
 }
 
 // Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
-// bases (SGPR) + one 32-bit lane offset for every load, and a ring of PF layers
-// of 2M+2C loads kept in flight ahead of the arithmetic (the slot a layer has
-// just consumed is refilled with layer k+PF), so that the one or two waves a
-// SIMD holds at small batch sizes cover the HBM latency by themselves.
-template <int AT, int MT, int CT, int PF>
+// bases (SGPR) + one 32-bit lane offset for every load, and two pairs of
+// register slots of 2M+2C loads kept in flight ahead of the arithmetic, so that
+// the one or two waves a SIMD holds at small batch sizes cover the HBM latency
+// by themselves.
+// SQ: the last ray angle has exactly half the cosine of the first (launch_rt
+// orders them so; 0 and 60 degrees of the usual raygrid), so its transmittance
+// is the first one's square: exp(-2 tau / mu) = exp(-tau / mu)^2 -- one
+// multiplication instead of one of the six exponentials of a layer.
+template <int AT, int MT, int CT, bool SQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_fast(RtArgs p) {
   extern __shared__ double smem[];
@@ -382,12 +388,16 @@ void rt_eclipse_fast(RtArgs p) {
     tau += dtau;
     // Planck exponent and the A slant-path exponents in one interleaved batch
     const double tc = fmin(tau, tcap);
-    double xs[A + 1], es[A + 1];
-    xs[A] = fmin(cf[1] * nu, 700.0);
+    constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
+    double xs[AE + 1], ex[AE + 1], es[A];
+    xs[AE] = fmin(cf[1] * nu, 700.0);
 #pragma unroll
-    for (int a = 0; a < A; a++) xs[a] = -tc * p.invmu[a];
-    exp_core_n<A + 1>(xs, es);
-    const double B = bnum * rcp_core(es[A] - 1.0);
+    for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
+    exp_core_n<AE + 1>(xs, ex);
+#pragma unroll
+    for (int a = 0; a < AE; a++) es[a] = ex[a];
+    if (SQ) es[A - 1] = ex[0] * ex[0];
+    const double B = bnum * rcp_core(ex[AE] - 1.0);
     const double hb = (Bprev + B) * lv;
 #pragma unroll
     for (int a = 0; a < A; a++) {
@@ -400,38 +410,21 @@ void rt_eclipse_fast(RtArgs p) {
   };
   auto clampk = [&](int k) { return k < kend ? k : kend; };
 
-  if (PF <= 1) {
-    // one slot, refilled with the next layer right after it is consumed:
-    // fewest registers, most resident waves (large batches hide latency by
-    // occupancy and mostly hit in L2 anyway)
-    double s0[NR];
-    load_layer(0, s0);
-    for (int k = 0; k <= kend; k++) {
-      double cur[NR];
-#pragma unroll
-      for (int j = 0; j < NR; j++) cur[j] = s0[j];
-      load_layer(clampk(k + 1), s0);
-      layer(k, cur);
-      if (!__any(active)) break;
-    }
-  } else {
-    // two pairs of slots; each pair is reloaded two layers before it is used
-    // and the loads that cross the loop's back edge were issued two layers
-    // earlier, so a SIMD holding a single wave still covers the HBM latency
-    double a0[NR], a1[NR], b0[NR], b1[NR];
-    load_layer(clampk(0), a0);
-    load_layer(clampk(1), a1);
-    for (int k0 = 0; k0 <= kend; k0 += 4) {
-      load_layer(clampk(k0 + 2), b0);
-      load_layer(clampk(k0 + 3), b1);
-      layer(k0, a0);
-      layer(k0 + 1, a1);
-      load_layer(clampk(k0 + 4), a0);
-      load_layer(clampk(k0 + 5), a1);
-      layer(k0 + 2, b0);
-      layer(k0 + 3, b1);
-      if (!__any(active)) break;
-    }
+  // two pairs of slots; each pair is reloaded two layers before it is used and
+  // the loads that cross the loop's back edge were issued two layers earlier
+  double a0[NR], a1[NR], b0[NR], b1[NR];
+  load_layer(clampk(0), a0);
+  load_layer(clampk(1), a1);
+  for (int k0 = 0; k0 <= kend; k0 += 4) {
+    load_layer(clampk(k0 + 2), b0);
+    load_layer(clampk(k0 + 3), b1);
+    layer(k0, a0);
+    layer(k0 + 1, a1);
+    load_layer(clampk(k0 + 4), a0);
+    load_layer(clampk(k0 + 5), a1);
+    layer(k0 + 2, b0);
+    layer(k0 + 3, b1);
+    if (!__any(active)) break;
   }
   double F = 0.0;
   const bool surf = p.cloud_on && active;
@@ -450,7 +443,7 @@ void rt_eclipse_fast(RtArgs p) {
 // Hand-off: an LDS ring of two 4-layer halves [tau, (B_{k-1}+B_k)/2 * live]
 // per lane and ONE raw workgroup barrier per 4 layers (the consumer reads half
 // b while the producer fills half b+1).
-template <int AT, int MT, int CT>
+template <int AT, int MT, int CT, bool SQ>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_split(RtArgs p) {
   extern __shared__ double smem[];
@@ -558,10 +551,17 @@ void rt_eclipse_split(RtArgs p) {
       for (int u = 0; u < 4; u++) {
         const double *slot = sX + ((blk & 1) * 4 + u) * 128;
         const double tc = fmin(slot[lane], tcap), hb = slot[64 + lane];
-        double xs[A], es[A];
+        constexpr int AE = SQ ? A - 1 : A;
+        double xs[AE], es[A];
 #pragma unroll
-        for (int a = 0; a < A; a++) xs[a] = -tc * p.invmu[a];
-        exp_core_n<A>(xs, es);
+        for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
+        {
+          double ex[AE];
+          exp_core_n<AE>(xs, ex);
+#pragma unroll
+          for (int a = 0; a < AE; a++) es[a] = ex[a];
+          if (SQ) es[A - 1] = ex[0] * ex[0];
+        }
 #pragma unroll
         for (int a = 0; a < A; a++) {
           I[a] = fma(hb, fprev[a] - es[a], I[a]);
@@ -600,7 +600,7 @@ void rt_eclipse_split(RtArgs p) {
 // 12 560 waves that the dispatcher spreads evenly over the 1 024 SIMDs (1 570
 // long waves leave half of the SIMDs with two and half with one), and a lone
 // walker's latency drops by about the number of chunks.
-template <int AT, int MT, int CT, int CH>
+template <int AT, int MT, int CT, int CH, bool SQ>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_lp(RtArgs p) {
   extern __shared__ double smem[];
@@ -700,30 +700,35 @@ void rt_eclipse_lp(RtArgs p) {
     if (__any(!cut)) {
       const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
       const double tcap = tau_cap(p, A);
+      constexpr int AE = SQ ? A - 1 : A;
       double I[A], fprev[A], Bprev = 0.0;
 #pragma unroll
       for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }
       if (c > 0) {
-        double xs[A + 1], es[A + 1];
-        xs[A] = fmin(sC[(k0 - 1) * NC + 1] * nu, 700.0);
+        double xs[AE + 1], ex[AE + 1];
+        xs[AE] = fmin(sC[(k0 - 1) * NC + 1] * nu, 700.0);
 #pragma unroll
-        for (int a = 0; a < A; a++) xs[a] = -fmin(tup, tcap) * p.invmu[a];
-        exp_core_n<A + 1>(xs, es);
-        Bprev = bnum * rcp_core(es[A] - 1.0);
+        for (int a = 0; a < AE; a++) xs[a] = -fmin(tup, tcap) * p.invmu[a];
+        exp_core_n<AE + 1>(xs, ex);
+        Bprev = bnum * rcp_core(ex[AE] - 1.0);
 #pragma unroll
-        for (int a = 0; a < A; a++) fprev[a] = es[a];
+        for (int a = 0; a < AE; a++) fprev[a] = ex[a];
+        if (SQ) fprev[A - 1] = ex[0] * ex[0];
       }
 #pragma unroll
       for (int j = 0; j < CH; j++) {
         const int k = k0 + j;
         const bool live = !cut && k <= kend;
         const double tau = t0 + tl[j], tc = fmin(tau, tcap);
-        double xs[A + 1], es[A + 1];
-        xs[A] = fmin(sC[clampk(k) * NC + 1] * nu, 700.0);
+        double xs[AE + 1], ex[AE + 1], es[A];
+        xs[AE] = fmin(sC[clampk(k) * NC + 1] * nu, 700.0);
 #pragma unroll
-        for (int a = 0; a < A; a++) xs[a] = -tc * p.invmu[a];
-        exp_core_n<A + 1>(xs, es);
-        const double B = bnum * rcp_core(es[A] - 1.0);
+        for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
+        exp_core_n<AE + 1>(xs, ex);
+#pragma unroll
+        for (int a = 0; a < AE; a++) es[a] = ex[a];
+        if (SQ) es[A - 1] = ex[0] * ex[0];
+        const double B = bnum * rcp_core(ex[AE] - 1.0);
         const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
 #pragma unroll
         for (int a = 0; a < A; a++) {
@@ -767,6 +772,29 @@ static hipError_t launch_rt_t(const RtArgs &a, int block, int nblocks, size_t sh
   return hipGetLastError();
 }
 
+// (molecules, CIA pairs) the specialised kernels are instantiated for
+#define BARTRT_MC_LIST(X) \
+  X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(5, 1) X(6, 1)
+
+// If one ray angle has exactly half the cosine of another (0 and 60 degrees of
+// the usual raygrid 0 20 40 60 80), put that pair first and last: the SQ kernels
+// take the last transmittance as the square of the first.
+static bool order_angles_for_square(RtArgs &r) {
+  for (int i = 0; i < r.A; i++)
+    for (int j = 0; j < r.A; j++) {
+      if (i == j || std::fabs(r.invmu[j] - 2.0 * r.invmu[i]) > 8.9e-16 * r.invmu[j]) continue;
+      auto swap_angles = [&](int x, int y) {
+        std::swap(r.invmu[x], r.invmu[y]);
+        std::swap(r.wgt[x], r.wgt[y]);
+      };
+      swap_angles(0, i);
+      if (j == 0) j = i;  // the doubled angle sat in slot 0 and moved to i
+      swap_angles(r.A - 1, j);
+      return true;
+    }
+  return false;
+}
+
 // block: threads per workgroup (64 or 256); a.ntiles must be ceil(W/block).
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   if (a.nwalkers <= 0 || a.W <= 0) return hipSuccess;
@@ -778,18 +806,21 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split | lp (A/B runs)
     return std::string(e ? e : "");
   }();
-  static const int pf_env = [] {
-    const char *e = std::getenv("BARTRT_PF");
-    return e ? std::atoi(e) : 0;
+  static const bool allow_sq = [] {
+    const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
+    return !(e && e[0] == '0');
   }();
-  const int pf = pf_env > 0 ? pf_env : 2;  // measured: the paired ring wins at every batch size
   // the specialised kernels address the tables through 32-bit buffer offsets
   const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
   if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {
+    RtArgs b = a;
+    const bool sq = allow_sq && order_angles_for_square(b);
     // too few single-wave columns to load the 1 024 SIMDs evenly -> several
     // waves per 64 wavenumbers: one per chunk of layers (layer-parallel), or a
     // producer / consumer pair
     const long columns = (long)a.nwalkers * ((a.W + 63) / 64);
+    const int ntiles64 = (a.W + 63) / 64;
+    const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
     static const int lp_ch_env = [] {
       const char *e = std::getenv("BARTRT_LP_CH");
       return e ? std::atoi(e) : 0;
@@ -797,54 +828,42 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const int lp_ch = lp_ch_env > 0 ? lp_ch_env : kLpChunk;
     const int lp_waves = (a.L + lp_ch - 1) / lp_ch;
     if ((kmode == "lp" || (kmode.empty() && columns <= kLpMaxColumns)) && lp_waves <= 16) {
-      RtArgs b = a;
-      b.ntiles = (a.W + 63) / 64;
-      const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+      b.ntiles = ntiles64;
       const size_t shl = sh + sizeof(double) * (size_t)lp_waves * (256 + 64);
-#define BARTRT_LP(MM, CC, CHH)                                                                     \
-  if (a.M == MM && a.C == CC && lp_ch == CHH) {                                                    \
-    hipLaunchKernelGGL((rt_eclipse_lp<5, MM, CC, CHH>), dim3(nb), dim3(64 * lp_waves), shl, st, b);\
-    return hipGetLastError();                                                                      \
+#define BARTRT_LP_CH(MM, CC, CHH)                                                                          \
+  if (a.M == MM && a.C == CC && lp_ch == CHH) {                                                            \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_lp<5, MM, CC, CHH, true>), dim3(nb64), dim3(64 * lp_waves), shl, st, b);  \
+    else hipLaunchKernelGGL((rt_eclipse_lp<5, MM, CC, CHH, false>), dim3(nb64), dim3(64 * lp_waves), shl, st, b);    \
+    return hipGetLastError();                                                                              \
   }
-      BARTRT_LP(1, 0, 13) BARTRT_LP(1, 1, 13) BARTRT_LP(1, 2, 13)
-      BARTRT_LP(2, 0, 13) BARTRT_LP(2, 1, 13) BARTRT_LP(2, 2, 13)
-      BARTRT_LP(3, 0, 13) BARTRT_LP(3, 1, 13) BARTRT_LP(3, 2, 13)
-      BARTRT_LP(4, 0, 13) BARTRT_LP(4, 1, 13) BARTRT_LP(4, 2, 13)
-      BARTRT_LP(5, 1, 13) BARTRT_LP(6, 1, 13)
+#define BARTRT_LP(MM, CC) BARTRT_LP_CH(MM, CC, 13)
+      BARTRT_MC_LIST(BARTRT_LP)
 #ifdef BARTRT_LP_EXPERIMENT  // chunk-size A/B (BARTRT_LP_CH): 7, 10, 17 lose; 25 about equal
-      BARTRT_LP(4, 1, 7) BARTRT_LP(4, 1, 10) BARTRT_LP(4, 1, 17) BARTRT_LP(4, 1, 25)
+      BARTRT_LP_CH(4, 1, 7) BARTRT_LP_CH(4, 1, 10) BARTRT_LP_CH(4, 1, 17) BARTRT_LP_CH(4, 1, 25)
 #endif
 #undef BARTRT_LP
+#undef BARTRT_LP_CH
     }
-    const bool split = kmode == "split" || (kmode.empty() && columns <= kSplitMaxColumns);
-    if (split) {
-      RtArgs b = a;
-      b.ntiles = (a.W + 63) / 64;
-      const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+    if (kmode == "split" || (kmode.empty() && columns <= kSplitMaxColumns)) {
+      b.ntiles = ntiles64;
       const size_t shs = sh + sizeof(double) * (1024 + 2 + 64);
-#define BARTRT_SPLIT(MM, CC)                                                                     \
-  if (a.M == MM && a.C == CC) {                                                                  \
-    hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC>), dim3(nb), dim3(128), shs, st, b);          \
-    return hipGetLastError();                                                                    \
+#define BARTRT_SPLIT(MM, CC)                                                                               \
+  if (a.M == MM && a.C == CC) {                                                                            \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC, true>), dim3(nb64), dim3(128), shs, st, b);    \
+    else hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC, false>), dim3(nb64), dim3(128), shs, st, b);      \
+    return hipGetLastError();                                                                              \
   }
-      BARTRT_SPLIT(1, 0) BARTRT_SPLIT(1, 1) BARTRT_SPLIT(1, 2)
-      BARTRT_SPLIT(2, 0) BARTRT_SPLIT(2, 1) BARTRT_SPLIT(2, 2)
-      BARTRT_SPLIT(3, 0) BARTRT_SPLIT(3, 1) BARTRT_SPLIT(3, 2)
-      BARTRT_SPLIT(4, 0) BARTRT_SPLIT(4, 1) BARTRT_SPLIT(4, 2)
-      BARTRT_SPLIT(5, 1) BARTRT_SPLIT(6, 1)
+      BARTRT_MC_LIST(BARTRT_SPLIT)
 #undef BARTRT_SPLIT
     }
-#define BARTRT_FAST(MM, CC)                                                                      \
-  if (a.M == MM && a.C == CC) {                                                                  \
-    if (pf >= 2) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, 2>), dim3(nblocks), dim3(block), sh, st, a);      \
-    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, 1>), dim3(nblocks), dim3(block), sh, st, a);              \
-    return hipGetLastError();                                                                    \
+    b.ntiles = a.ntiles;
+#define BARTRT_FAST(MM, CC)                                                                                \
+  if (a.M == MM && a.C == CC) {                                                                            \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, true>), dim3(nblocks), dim3(block), sh, st, b); \
+    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, false>), dim3(nblocks), dim3(block), sh, st, b);   \
+    return hipGetLastError();                                                                              \
   }
-    BARTRT_FAST(1, 0) BARTRT_FAST(1, 1) BARTRT_FAST(1, 2)
-    BARTRT_FAST(2, 0) BARTRT_FAST(2, 1) BARTRT_FAST(2, 2)
-    BARTRT_FAST(3, 0) BARTRT_FAST(3, 1) BARTRT_FAST(3, 2)
-    BARTRT_FAST(4, 0) BARTRT_FAST(4, 1) BARTRT_FAST(4, 2)
-    BARTRT_FAST(5, 1) BARTRT_FAST(6, 1)
+    BARTRT_MC_LIST(BARTRT_FAST)
 #undef BARTRT_FAST
   }
   if (a.A == 5) return launch_rt_t<5, -1, -1>(a, block, nblocks, sh, st);

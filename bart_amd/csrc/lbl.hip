@@ -35,7 +35,7 @@ __device__ inline double voigt_k(double x, double y) {
     // far wings (almost every line-point pair of a pressure-broadened layer):
     // asymptotic series w = i/(sqrt(pi) z) (1 + 1/(2 z^2) + 3/(4 z^4) + ...),
     // 2 / 3 / 5 terms for |z| >= 100 / 30 / 15 (<= 1.3e-11 / 9e-11 / 1.7e-11)
-    const double inv = 1.0 / r2, inv2 = inv * inv;
+    const double inv = rcp_core(r2), inv2 = inv * inv;  // reciprocal + Newton: no IEEE divide per pair
     const double tr = (x * x - y * y) * inv2, ti = -2.0 * x * y * inv2;  // t = 1/z^2
     double hr, hi;
     if (r2 >= 1.0e4) { hr = 0.75; hi = 0.0; }
@@ -60,15 +60,15 @@ __device__ inline double voigt_k(double x, double y) {
     const int K = 8;
     double fr = x, fi = y;
     for (int k = K; k >= 1; k--) {
-      const double s = (0.5 * k) / (fr * fr + fi * fi);
+      const double s = (0.5 * k) * rcp_core(fr * fr + fi * fi);
       const double nr = x - s * fr, ni = y + s * fi;
       fr = nr; fi = ni;
     }
-    return kInvSqrtPi * fi / (fr * fr + fi * fi);
+    return kInvSqrtPi * fi * rcp_core(fr * fr + fi * fi);
   }
   // Weideman N = 40: Z = ((L - y) + i x) / ((L + y) - i x)
   const double ar = kWeidL - y, br = kWeidL + y;
-  const double den = 1.0 / (br * br + x * x);
+  const double den = rcp_core(br * br + x * x);
   const double Zr = (ar * br - x * x) * den, Zi = (x * br + ar * x) * den;
   double pr = kWeidA[0], pi = 0.0;
 #pragma unroll 8
@@ -156,8 +156,11 @@ __global__ void lbl_states(StateArgs a, LblDev d) {
   out[4 + 3 * i] = kSIGCTE * scale;
 }
 
-__device__ inline double line_strength(double gf, double elow, double nu0, double scale, double T) {
-  return gf * scale * exp(-kEXPCTE * elow / T) * (1.0 - exp(-kEXPCTE * nu0 / T));
+// invT = 1 / T.  exp_core: the arguments are <= 0; far below -708 the line is
+// negligible at any threshold
+__device__ inline double line_strength(double gf, double elow, double nu0, double scale, double invT) {
+  const double a = fmax(-kEXPCTE * elow * invT, kExpMin), b = fmax(-kEXPCTE * nu0 * invT, kExpMin);
+  return gf * scale * exp_core(a) * (1.0 - exp_core(b));
 }
 
 // max line strength per (state, group); positive doubles order like their bits
@@ -165,12 +168,12 @@ __global__ __launch_bounds__(256) void lbl_smax(LblDev d, const double *state, d
                                                 int nstate) {
   const int st = blockIdx.y, g = blockIdx.z;
   const double *sv = state + (size_t)st * (2 + 3 * d.niso);
-  const double T = sv[0];
+  const double invT = 1.0 / sv[0];
   double m = 0.0;
   for (long j = d.gstart[g] + blockIdx.x * blockDim.x + threadIdx.x; j < d.gend[g];
        j += (long)gridDim.x * blockDim.x) {
     const int i = d.liso[j];
-    m = fmax(m, line_strength(d.gf[j], d.elow[j], d.nu0[j], sv[4 + 3 * i], T));
+    m = fmax(m, line_strength(d.gf[j], d.elow[j], d.nu0[j], sv[4 + 3 * i], invT));
   }
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0 && m > 0.0)
@@ -185,57 +188,97 @@ struct AccArgs {
   double *out;
 };
 
+// ---------------------------------------------------------------------------
+// Window of group g's sorted line list for the points [nu_a, nu_b] of a state:
+// centres within the widest cut of the group's isotopes, rounded out to the
+// 1 cm-1 bucket index (every lane does the same two scalar loads; a single
+// lane's binary search over global memory would hold the others at a barrier
+// for ~40 dependent loads).  The exact per-line cut is applied by the callers.
+__device__ __forceinline__ void line_window(const LblDev &d, const double *sv, int g, double nu_a,
+                                            double nu_b, long &j0, long &j1, double &cmax) {
+  cmax = 0.0;
+  for (int k = 0; k < d.niso; k++)
+    if (d.iso_group[k] == g)
+      cmax = fmax(cmax, d.nwidth * fmax(sv[3 + 3 * k], (nu_b + 1.0) * sv[2 + 3 * k] * 1.001));
+  cmax *= 1.01;
+  int b0 = (int)floor((nu_a - cmax - d.bmin) / d.bstep), b1 = (int)floor((nu_b + cmax - d.bmin) / d.bstep) + 1;
+  b0 = b0 < 0 ? 0 : (b0 > d.nbucket ? d.nbucket : b0);
+  b1 = b1 < 0 ? 0 : (b1 > d.nbucket ? d.nbucket : b1);
+  j0 = d.bucket[d.boff[g] + b0];
+  j1 = d.bucket[d.boff[g] + b1];
+}
+
+// Widest cut of any isotope at this state / smallest point spacing of the tile:
+// how many points a line can reach on either side.  Decides which of the two
+// accumulation kernels owns the state (both are launched over all states).
+constexpr int kPairReach = 7;
+__device__ __forceinline__ bool narrow_state(const LblDev &d, const AccArgs &a, const double *sv, int tile0) {
+  const int ilast = min(tile0 + 255, a.W - 1);
+  if (ilast <= tile0) return false;
+  const double dnu = fmin(a.wn[tile0 + 1] - a.wn[tile0], a.wn[ilast] - a.wn[ilast - 1]);
+  double cany = 0.0;
+  for (int k = 0; k < d.niso; k++)
+    cany = fmax(cany, d.nwidth * fmax(sv[3 + 3 * k], (a.wn[ilast] + 1.0) * sv[2 + 3 * k] * 1.011));
+  return cany <= kPairReach * dnu;
+}
+
+// One line's staged record, or cut < 0 for a line below the strength threshold.
+struct LineRec { double nu0, amp, xs, y, cut; };
+__device__ __forceinline__ LineRec stage_line(const LblDev &d, const double *sv, double invT, double thresh, long j) {
+  LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
+  const int k = d.liso[j];
+  const double n0 = d.nu0[j];
+  const double Sj = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * k], invT);
+  if (Sj >= thresh && Sj > 0.0) {
+    const double aD = n0 * sv[2 + 3 * k], aL = sv[3 + 3 * k];
+    r.nu0 = n0;
+    r.cut = d.nwidth * fmax(aD, aL);
+    r.xs = kSqrtLn2 / aD;
+    r.amp = Sj * kSqrtLn2 * kInvSqrtPi / aD;
+    r.y = aL * r.xs;
+  }
+  return r;
+}
+
+// Broad states (pressure-broadened layers: a line reaches many points).  One
+// workgroup per (256-point tile, state); lane = point.  The window of the line
+// list is staged through LDS 256 lines at a time; lines below the strength
+// threshold (two thirds of a typical list at ethresh 1e-6) are dropped while
+// staging (ordered compaction: ballot + prefix), so no lane ever tests them.
 __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
   __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
-  __shared__ long s_j0, s_j1;
+  __shared__ int s_wcount[4];
   const int st = blockIdx.y;
   const int tile0 = blockIdx.x * 256;
-  const int i = tile0 + threadIdx.x;
-  const bool valid = i < a.W;
-  const double nu = a.wn[valid ? i : a.W - 1];
-  const double nu_a = a.wn[tile0], nu_b = a.wn[min(tile0 + 255, a.W - 1)];
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
-  const double T = sv[0];
+  if (narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate_pairs owns it
+  const double invT = 1.0 / sv[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tile0 + threadIdx.x;
+  const double nu = a.wn[min(i, a.W - 1)];
+  const double nu_a = a.wn[tile0], nu_b = a.wn[min(tile0 + 255, a.W - 1)];
   const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
   double acc = 0.0;
   for (int g = g_lo; g < g_hi; g++) {
-    if (threadIdx.x == 0) {
-      double cmax = 0.0;
-      for (int k = 0; k < d.niso; k++)
-        if (d.iso_group[k] == g)
-          cmax = fmax(cmax, d.nwidth * fmax(sv[3 + 3 * k], (nu_b + 1.0) * sv[2 + 3 * k] * 1.001));
-      // window of the sorted list: nu0 in [nu_a - cmax', nu_b + cmax'] (cmax' a little
-      // generous: the exact per-line cut is applied below)
-      const double lo = nu_a - cmax * 1.01, hi = nu_b + cmax * 1.01;
-      long a0 = d.gstart[g], a1 = d.gend[g];
-      while (a0 < a1) { long m = (a0 + a1) >> 1; if (d.nu0[m] < lo) a0 = m + 1; else a1 = m; }
-      s_j0 = a0;
-      a1 = d.gend[g];
-      while (a0 < a1) { long m = (a0 + a1) >> 1; if (d.nu0[m] <= hi) a0 = m + 1; else a1 = m; }
-      s_j1 = a0;
-    }
-    __syncthreads();
-    const long j0 = s_j0, j1 = s_j1;
+    long j0, j1;
+    double cmax;
+    line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
     const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
     for (long base = j0; base < j1; base += 256) {
       const long j = base + threadIdx.x;
-      double cut = -1.0, n0 = 0.0, amp = 0.0, xs = 0.0, yy = 1.0;
-      if (j < j1) {
-        const int k = d.liso[j];
-        n0 = d.nu0[j];
-        const double S = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * k], T);
-        if (S >= thresh && S > 0.0) {
-          const double aD = n0 * sv[2 + 3 * k], aL = sv[3 + 3 * k];
-          cut = d.nwidth * fmax(aD, aL);
-          xs = kSqrtLn2 / aD;
-          amp = S * kSqrtLn2 * kInvSqrtPi / aD;
-          yy = aL * xs;
-        }
-      }
-      s_nu0[threadIdx.x] = n0; s_amp[threadIdx.x] = amp; s_xs[threadIdx.x] = xs;
-      s_y[threadIdx.x] = yy; s_cut[threadIdx.x] = cut;
+      LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
+      if (j < j1) r = stage_line(d, sv, invT, thresh, j);
+      // ordered compaction of the kept lines
+      const unsigned long long keep = __ballot(r.cut >= 0.0);
+      if (lane == 0) s_wcount[wave] = __popcll(keep);
       __syncthreads();
-      const int cnt = (int)min((long)256, j1 - base);
+      int pos = __popcll(keep & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; w++) pos += s_wcount[w];
+      const int cnt = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+      if (r.cut >= 0.0) {
+        s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
+      }
+      __syncthreads();
       for (int t = 0; t < cnt; t++) {
         const double dv = fabs(nu - s_nu0[t]);
         if (dv <= s_cut[t]) acc += s_amp[t] * voigt_k(dv * s_xs[t], s_y[t]);
@@ -243,7 +286,110 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
       __syncthreads();
     }
   }
-  if (valid) {
+  if (i < a.W) {
+    if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + i] = acc;
+    else a.out[(size_t)st * a.W + i] = acc;
+  }
+}
+
+// Narrow states (Doppler cores: every cut reaches at most kPairReach points).
+// With lane = point a step would evaluate the Voigt function -- and the core of
+// a Doppler line is its costly branch, a 40-term rational -- with the few lanes
+// a line reaches and the rest of the wave idle, and a workgroup-wide staging
+// loop would leave three of four waves waiting at its barriers (a chunk of the
+// sorted list overlaps one wave's points).  Here every wave works alone on its 64
+// points, no workgroup barrier, 64 lines per round:
+//   A  lane = line: stage it, find its range of the wave's points (binary
+//      search), prefix sum of the range lengths -> pair offsets
+//   B  lane = (line, point) pair, 64 pairs per pass, all lanes busy: the pair's
+//      contribution goes to an LDS buffer in pair order
+//   C  lane = point: adds its pairs in line order (fixed summation order, no atomics)
+constexpr int kPairsPerLine = 2 * kPairReach + 3;   // incl. one point of slack either side
+
+struct PairScratch {                        // per wave
+  double wnu[64];                           // the wave's points
+  double nu0[64], amp[64], xs[64], y[64], cut[64];   // the round's lines
+  double val[64 * kPairsPerLine];           // pair contributions of the round
+  int off[65], first[64];                   // pair offset and first point of each line
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a) {
+  __shared__ PairScratch s_pairs[4];
+  const int st = blockIdx.y;
+  const int tile0 = blockIdx.x * 256;
+  const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
+  if (!narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate owns it
+  const double invT = 1.0 / sv[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int w0 = tile0 + wave * 64;
+  if (w0 >= a.W) return;
+  PairScratch &ws = s_pairs[wave];
+  const int i = w0 + lane;
+  // points beyond the grid's end are pushed out of every line's reach
+  ws.wnu[lane] = i < a.W ? a.wn[i] : 1e300;
+  wave_sync();
+  const double nu_a = a.wn[w0], nu_b = a.wn[min(w0 + 63, a.W - 1)];
+  const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
+  double acc = 0.0;
+  for (int g = g_lo; g < g_hi; g++) {
+    long j0, j1;
+    double cmax;
+    line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
+    const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
+    for (long base = j0; base < j1; base += 64) {
+      // ---- A
+      const long j = base + lane;
+      LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
+      if (j < j1) r = stage_line(d, sv, invT, thresh, j);
+      int first = 0, n = 0;
+      if (r.cut >= 0.0) {
+        const double lo = r.nu0 - r.cut, hi = r.nu0 + r.cut;
+        int b = 0, e = 64;  // b -> first point >= lo
+        while (b < e) { const int m = (b + e) >> 1; if (ws.wnu[m] < lo) b = m + 1; else e = m; }
+        int c = b;          // c -> first point > hi
+        e = 64;
+        while (c < e) { const int m = (c + e) >> 1; if (ws.wnu[m] <= hi) c = m + 1; else e = m; }
+        if (c > b) {
+          // one point of slack either side: the exact |nu - nu0| <= cut test is per pair
+          first = b > 0 ? b - 1 : 0;
+          n = min((c < 64 ? c + 1 : 64) - first, kPairsPerLine);
+        }
+      }
+      int incl = n;  // inclusive prefix sum over the lanes
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      const int total = __shfl(incl, 63);
+      if (total == 0) continue;
+      ws.nu0[lane] = r.nu0; ws.amp[lane] = r.amp; ws.xs[lane] = r.xs; ws.y[lane] = r.y; ws.cut[lane] = r.cut;
+      ws.off[lane] = incl - n;
+      ws.first[lane] = first;
+      if (lane == 63) ws.off[64] = total;
+      wave_sync();
+      // ---- B
+      for (int p = lane; p < total; p += 64) {
+        int x = 0, y = 64;  // line of pair p: last t with off[t] <= p
+        while (y - x > 1) { const int m = (x + y) >> 1; if (ws.off[m] <= p) x = m; else y = m; }
+        const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
+        ws.val[p] = dv <= ws.cut[x] ? ws.amp[x] * voigt_k(dv * ws.xs[x], ws.y[x]) : 0.0;
+      }
+      wave_sync();
+      // ---- C
+      for (int t = 0; t < 64; t++) {
+        const unsigned k = (unsigned)(lane - ws.first[t]);
+        if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc += ws.val[ws.off[t] + k];
+      }
+      wave_sync();
+    }
+  }
+  if (i < a.W) {
     if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + i] = acc;
     else a.out[(size_t)st * a.W + i] = acc;
   }
@@ -285,7 +431,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
     const int l = L - 1 - k;
     const int st = w * L + l;
     const double *sv = state + (size_t)st * (2 + 3 * d.niso);
-    const double T = sv[0];
+    const double invT = 1.0 / sv[0];
     double acc = 0.0;
     for (int g = 0; g < d.ngroup; g++) {
       double cmax = 0.0;
@@ -306,7 +452,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
         if (j < j1) {
           const int q = d.liso[j];
           n0 = d.nu0[j];
-          const double S = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * q], T);
+          const double S = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * q], invT);
           if (S >= thresh && S > 0.0) {
             const double aD = n0 * sv[2 + 3 * q], aL = sv[3 + 3 * q];
             cut = d.nwidth * fmax(aD, aL);
@@ -483,6 +629,8 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
   aa.W = e.W(); aa.nstate = sa.nstate; aa.wn = e.d_wn; aa.state = b->d_state; aa.smax = b->d_smax;
   const int ntile = (aa.W + 255) / 256;
   hipLaunchKernelGGL(lbl_accumulate, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
+                     0, st, d, aa);
+  hipLaunchKernelGGL(lbl_accumulate_pairs, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
                      0, st, d, aa);
   HIPCHK(hipGetLastError());
 }

@@ -18,13 +18,16 @@ ap.add_argument("--lines", type=int, default=250000, help="lines per molecule (4
 ap.add_argument("--nwave", type=int, default=100000)
 ap.add_argument("--nlayers", type=int, default=100)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--ptop", type=float, default=1e-5, help="top pressure, bar")
+ap.add_argument("--pbottom", type=float, default=100.0, help="bottom pressure, bar")
 a = ap.parse_args()
 
-d = os.path.join(tempfile.gettempdir(), "bartrt_lbl_bench")
+d = os.path.join(tempfile.gettempdir(), "bartrt_lbl_bench_%g_%g" % (a.ptop, a.pbottom))
 mols = ("H2O", "CO", "CO2", "CH4")
 t0 = time.perf_counter()
 case = synth_lbl.make_lbl_case(d, molecules=mols, nlines=a.lines, nwave=a.nwave, wnlow=1000.0,
-                               wndelt=0.1, nlayers=a.nlayers, cia=True)
+                               wndelt=0.1, nlayers=a.nlayers, cia=True, ptop=a.ptop,
+                               pbottom=a.pbottom)
 t_gen = time.perf_counter() - t0
 t0 = time.perf_counter()
 engine.init(case.tcfg)

@@ -77,6 +77,32 @@ def test_lbl_extinction_and_spectrum_match_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(ptop=1e-6, pbottom=1e-3, nwave=333),              # Doppler cores only: the pair kernel, ragged last wave
+    dict(ptop=1.0, pbottom=100.0, nwave=300),              # pressure-broadened only: the tile kernel
+    dict(ptop=1e-5, pbottom=100.0, nwave=70, wndelt=0.4),  # coarse grid: narrow = less than one point
+    dict(ptop=1e-4, pbottom=1.0, nwave=260, nlines=40),    # sparse list: empty windows
+])
+def test_narrow_and_broad_states(tmp_path, kw):
+    """Each layer state is summed by one of two kernels (lines a few points wide /
+    lines many points wide): atmospheres that are all one kind, grids that end
+    inside a wave, windows without lines."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle
+    kw = dict(kw)
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=kw.pop("nlines", 1200), nlayers=12, **kw)
+    engine.init(c.tcfg)
+    try:
+        prof = c.profiles()
+        ext = engine.lbl_extinction(prof)
+        ref = lbl_oracle.LblOracle(c.tcfg).extinction(prof)
+        assert ref.max() > 0
+        np.testing.assert_allclose(ext, ref, rtol=RTOL, atol=1e-30 + 1e-12 * ref.max())
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
 def test_ethresh_and_nwidth_are_applied(tmp_path):
     from bart_amd import engine, synth_lbl, transit_module as trm
     from oracle import lbl_oracle

@@ -102,15 +102,25 @@ def run(model, cfg: SamplerConfig, log=None):
     chis = np.zeros((nch, nsteps))
     naccept = 0
     gamma0 = 2.38 / np.sqrt(2 * max(nfree, 1))
+    idx = np.arange(nch)
+
+    def _other(rng, excluded):
+        """For every chain one chain index drawn uniformly from those not in its
+        row of `excluded` [nch, k] (distinct entries), all chains in one call."""
+        k = excluded.shape[1]
+        draw = rng.integers(0, nch - k, size=nch)
+        for col in np.sort(excluded, axis=1).T:   # skip over the excluded ones in ascending order
+            draw += draw >= col
+        return draw
+
     for t in range(nsteps):
         prop = x.copy()
-        r1 = np.array([rng.choice(np.delete(np.arange(nch), i)) for i in range(nch)])
-        r2 = np.array([rng.choice(np.delete(np.arange(nch), [i, r1[i]])) if nch > 2 else r1[i]
-                       for i in range(nch)])
+        r1 = _other(rng, idx[:, None])
+        r2 = _other(rng, np.stack([idx, r1], axis=1)) if nch > 2 else r1
         logjac = np.zeros(nch)
         if cfg.walk == "snooker" and nch > 3 and t % 10 != 0:
             # snooker update: move along the line through a third chain
-            z = np.array([rng.choice(np.delete(np.arange(nch), [i, r1[i], r2[i]])) for i in range(nch)])
+            z = _other(rng, np.stack([idx, r1, r2], axis=1))
             d = x[:, free] - x[z][:, free]
             nd = np.linalg.norm(d, axis=1, keepdims=True)
             nd[nd == 0] = 1.0

@@ -1,16 +1,23 @@
-// CDNA4 (gfx950) kernels of the forward radiative-transfer path.
+// CDNA4 (gfx950) kernels of the forward radiative-transfer path, eclipse geometry.
 //
-//  prep_profiles   one workgroup per walker: mean molecular mass, hydrostatic
-//                  radii (reference law code/makeatm.py:183-263), densities and
-//                  the per-layer interpolation weights -> coefficient records.
-//  rt_eclipse      one thread per (walker, wavenumber): streams the opacity
-//                  grid layer by layer from the top (coalesced along the
-//                  wavenumber axis, the grid's fastest index), accumulates the
-//                  optical depth and the emergent intensity per ray angle,
-//                  stops the wave once every lane passed `toomuch`.
+//  prep_profiles     one workgroup per walker: mean molecular mass, hydrostatic
+//                    radii (reference law code/makeatm.py:183-263), densities and
+//                    the per-layer interpolation weights -> coefficient records.
+//  rt_eclipse        generic: one lane per (walker, wavenumber) streams the
+//                    opacity grid layer by layer from the top (coalesced along
+//                    the wavenumber axis, the grid's fastest index), accumulates
+//                    the optical depth and the emergent intensity per ray angle,
+//                    stops the wave once every lane passed `toomuch`.  Runtime
+//                    angle / molecule / CIA counts; also carries the line-by-line
+//                    extinction and the tau / per-angle outputs.
+//  rt_eclipse_fast   the same walk specialised at compile time, buffer loads with
+//                    scalar plane offsets, two pairs of register slots in flight.
+//  rt_eclipse_split  5-9 walkers: producer / consumer wave pair per column.
+//  rt_eclipse_lp     1-4 walkers: one wave per chunk of layers per column.
 //
 // The walker's coefficient records are staged in LDS once per workgroup and
-// read back as wave-uniform broadcasts.  HBM-bound: no MFMA anywhere.
+// read back as wave-uniform broadcasts.  Interpolation + reduction, fp64 VALU;
+// the transit geometry (transit_geom.hip) is where MFMA fits.
 #include "kernels.hpp"
 
 #include <cmath>

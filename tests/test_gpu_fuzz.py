@@ -1,0 +1,55 @@
+"""Seeded random configurations against the oracle: layer / sample / walker
+counts around the kernel-selection thresholds, table molecules and CIA pairs the
+specialised kernels are and are not built for, ray grids with and without the
+0/60-degree pair, both geometries, cloud decks and `toomuch` values."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+MOLS = ("H2O", "CO", "CO2", "CH4")
+
+
+def _draw(rng):
+    kw = {}
+    kw["nlayers"] = int(rng.choice([5, 13, 26, 40, 100, 117, 209, 230]))
+    kw["nwave"] = int(rng.choice([2, 17, 64, 65, 200, 641, 1500, 4100]))
+    if kw["nwave"] >= 1500:   # keep the synthetic table small: few layers, 4 temperatures
+        kw["nlayers"] = int(rng.choice([13, 26, 40]))
+        kw.update(tlow=400.0, thigh=3100.0, tempdelt=900.0)
+    nm = int(rng.integers(0, 5))
+    kw["opmol"] = tuple(rng.choice(MOLS, size=nm, replace=False)) if nm else ()
+    kw["cia"] = bool(rng.integers(0, 2)) or nm == 0
+    kw["raygrid"] = [(0, 20, 40, 60, 80), (0, 30, 60), (10, 35, 50, 65, 85), (0, 15, 30, 45, 60, 75),
+                     (0, 20, 40, 60, 80)][int(rng.integers(0, 5))]
+    kw["toomuch"] = float(rng.choice([0.5, 10.0, 20.0, 1e30]))
+    geometry = "transit" if rng.random() < 0.4 else "eclipse"
+    if geometry == "transit":
+        kw["extra_keys"] = {"solution": "transit", "starrad": 1.145}
+    nwalk = int(rng.choice([1, 2, 4, 5, 9, 10, 23]))
+    cloud = float(rng.uniform(-4.0, 1.5)) if rng.random() < 0.4 else None
+    return kw, geometry, nwalk, cloud
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configuration(tmp_path, seed):
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    from test_gpu_parity import walkers
+    rng = np.random.default_rng(1000 + seed)
+    kw, geometry, nwalk, cloud = _draw(rng)
+    c = synth.make_case(str(tmp_path), **kw)
+    engine.init(c.tcfg)
+    try:
+        o = orc.OracleEngine(c.tcfg)
+        if cloud is not None:
+            trm.set_cloudtop(cloud); o.set_cloudtop(cloud)
+        profs = walkers(c, nwalk, seed=seed)
+        spec, ok = engine.run_batch(profs, want_ok=True)
+        assert ok.all()
+        ref = o.run_batch(profs)
+        np.testing.assert_allclose(spec, ref, rtol=RTOL, atol=1e-300,
+                                   err_msg="%s %s walkers=%d cloud=%s" % (geometry, kw, nwalk, cloud))
+    finally:
+        trm.free_memory()

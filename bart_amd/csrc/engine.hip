@@ -420,7 +420,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.rad_out = d_rad;
   pa.rtop = solution == 1 ? d_rtop : nullptr;
   pa.ds = solution == 1 ? d_ds : nullptr;
-  HIPCHK(launch_prep(pa, st));
+  if (prep_hook) HIPCHK(prep_hook(pa, st, prep_hook_ctx));
+  else HIPCHK(launch_prep(pa, st));
   if (solution == 1) HIPCHK(launch_chord_table(pa, st));
 
   RtArgs r = rt;

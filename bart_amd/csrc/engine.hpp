@@ -57,6 +57,10 @@ struct Engine {
   double *h_pin = nullptr;  // pinned staging
   size_t h_pin_bytes = 0;
   hipStream_t stream = nullptr;
+  // when set, run_chunk calls this instead of launch_prep (the per-step path
+  // fuses T(p) + abundances into the same launch, step.hip)
+  hipError_t (*prep_hook)(const PrepArgs &, hipStream_t, void *) = nullptr;
+  void *prep_hook_ctx = nullptr;
   // timing of RT launches
   bool timing = false;
   std::vector<hipEvent_t> ev;

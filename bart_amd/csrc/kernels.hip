@@ -19,6 +19,7 @@
 // read back as wave-uniform broadcasts.  Interpolation + reduction, fp64 VALU;
 // the transit geometry (transit_geom.hip) is where MFMA fits.
 #include "kernels.hpp"
+#include "prep.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -42,182 +43,17 @@ constexpr int kLpChunk = 13;  // layers per wave of the layer-parallel kernel
 
 namespace bartrt {
 
-// ---------------------------------------------------------------------------
-// Largest j with g[j] <= t, clamped to [0, n-2].  Starts from the uniform-grid
-// guess (tlow/thigh/tempdelt grids are uniform; ginv[0] = 1/(g[1]-g[0])) and
-// walks to the exact bracket.
-__device__ inline int bracket_dev(const double *g, const double *ginv, int n, double t) {
-  if (n <= 2) return 0;
-  double x = (t - g[0]) * ginv[0];
-  int j = x > 0.0 ? (x < (double)(n - 2) ? (int)x : n - 2) : 0;
-  while (j < n - 2 && g[j + 1] <= t) j++;
-  while (j > 0 && g[j] > t) j--;
-  return j;
-}
-
 __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   extern __shared__ double sm[];
-  const int L = p.L, S = p.S, M = p.M, C = p.C;
-  double *sT = sm;           // temperature, atm order
-  double *sMu = sm + L;      // mean molecular mass
-  double *sR = sm + 2 * L;   // radius
-  double *sH = sm + 3 * L;   // hydrostatic step terms
-  const int w = blockIdx.x;
+  const int L = p.L, S = p.S, w = blockIdx.x;
   // Everything this kernel reads from HBM (the walker's profile and the block of
   // per-engine constants) is pulled into LDS in ONE batch of independent loads;
-  // the phases below then run out of LDS.  The kernel is pure latency: each
-  // dependent trip to memory it avoids is worth most of a microsecond.
-  double *sProf = sm + 4 * L;                       // [(S+1)][L]
-  // from sPress on: the layout of p.consts
-  double *sPress = sProf + (size_t)(S + 1) * L;     // [L]
-  double *sDlnp = sPress + L;                       // [L]
-  double *sMass = sDlnp + L;                        // [S]
-  double *sTg = sMass + S;                          // [Nt]
-  double *sTgInv = sTg + p.Nt;                      // [Nt]
-  double *sCiaT = sTgInv + p.Nt;                    // [ncia_temps]
-  double *sCiaTInv = sCiaT + p.ncia_temps;          // [ncia_temps]
-  stage2_to_lds(sProf, p.prof + (size_t)w * (S + 1) * L, (S + 1) * L, sPress, p.consts,
-                2 * L + S + 2 * p.Nt + 2 * p.ncia_temps, threadIdx.x, blockDim.x);
-  const double *prof = sProf;
-  __shared__ int sBad;
-  if (threadIdx.x == 0) sBad = 0;
-  __syncthreads();
-  // Hydrostatic radii, makeatm.py:229-258 (layers bottom -> top).  The
-  // reference steps r_i = r_{i+-1} -+ H_i / g and rescales g by (r_old/r_new)^2,
-  // i.e. g r^2 stays g0 R0^2: the step is r -+ (H_i / (g0 R0^2)) r^2.  The
-  // layer terms H_i are formed in parallel (each lane also evaluates its upper
-  // neighbour's T/mu rather than wait for it); only the two-flop recurrence is
-  // serial (lane 0 walks down from the reference layer, lane 64 walks up).
-  const double rgas = kKB / kAMU;
-  {
-    const double invG = 1.0 / (p.gsurf * p.refradius * p.refradius);
-    for (int l = threadIdx.x; l < L; l += blockDim.x) {
-      const int lu = l + 1 < L ? l + 1 : l;
-      const double T = prof[l], Tu = prof[lu];
-      double mu = 0.0, muu = 0.0;
-      for (int s = 0; s < S; s++) {
-        mu += prof[(size_t)(s + 1) * L + l] * sMass[s];
-        muu += prof[(size_t)(s + 1) * L + lu] * sMass[s];
-      }
-      sT[l] = T;
-      sMu[l] = mu;
-      sH[l] = 0.5 * (T / mu + Tu / muu) * (rgas * sDlnp[l]) * invG;
-      if (!(T > 0.0) || !(T < 1e30) || !(mu > 0.0)) sBad = 1;
-    }
-  }
-  __syncthreads();
-  const bool bad = sBad != 0;
-  if (!bad && (threadIdx.x == 0 || threadIdx.x == 64)) {
-    const int ix = p.ref_idx;
-    double r = p.refradius;
-    if (!p.ref_exact) {
-      const int b = p.ref_ib;
-      const double t0 = sT[b] + p.ref_f * (sT[b + 1] - sT[b]);
-      const double m0 = sMu[b] + p.ref_f * (sMu[b + 1] - sMu[b]);
-      r += 0.5 * (sT[ix] / sMu[ix] + t0 / m0) * (rgas * p.ref_lnp / p.gsurf);
-    }
-    // blocks of 8 terms are fetched from LDS ahead of the dependent chain
-    if (threadIdx.x == 0) {
-      sR[ix] = r;
-      int i = ix - 1;
-      for (; i >= 7; i -= 8) {
-        double h[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) h[j] = sH[i - j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { r = fma(-h[j], r * r, r); sR[i - j] = r; }
-      }
-      for (; i >= 0; i--) { r = fma(-sH[i], r * r, r); sR[i] = r; }
-    } else {
-      int i = ix + 1;
-      for (; i + 7 < L; i += 8) {
-        double h[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) h[j] = sH[i + j - 1];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { r = fma(h[j], r * r, r); sR[i + j] = r; }
-      }
-      for (; i < L; i++) { r = fma(sH[i - 1], r * r, r); sR[i] = r; }
-    }
-  }
-  __syncthreads();
-  const int NC = coef_stride(M, C), NI = idx_stride(C);
-  double *coef = p.coef + (size_t)w * L * NC;
-  idx_t *idx = p.idx + (size_t)w * L * NI;
-  for (int k = threadIdx.x; k < L; k += blockDim.x) {
-    const int l = L - 1 - k;
-    double *c = coef + (size_t)k * NC;
-    idx_t *ix = idx + (size_t)k * NI;
-    if (bad) {
-      for (int j = 0; j < NC; j++) c[j] = 0.0;
-      for (int j = 0; j < NI; j++) ix[j] = 0;
-      c[1] = 1.0;
-      continue;
-    }
-    // one division per layer (1/T); grid spacings come as reciprocals
-    const double T = sT[l];
-    const double invT = 1.0 / T;
-    const double nd = sPress[l] * invT * (1.0 / kKB);
-    c[0] = (k == 0) ? 0.0 : (sR[l + 1] - sR[l]);
-    c[1] = (kH * kLS / kKB) * invT;
-    int j = 0;
-    double f = 0.0;
-    if (M > 0) {
-      j = bracket_dev(sTg, sTgInv, p.Nt, T);
-      f = (T - sTg[j]) * sTgInv[j];
-    }
-    ix[0] = (idx_t)(((size_t)l * p.Nt + j) * M * p.W) * 8;
-    for (int m = 0; m < M; m++) {
-      const int s = p.opmol[m];
-      const double rho = prof[(size_t)(s + 1) * L + l] * sMass[s] * kAMU * nd;
-      c[2 + 2 * m] = rho * (1.0 - f);
-      c[3 + 2 * m] = rho * f;
-    }
-    for (int cc = 0; cc < C; cc++) {
-      const int nt = p.cia_nt[cc];
-      const double *tg = sCiaT + p.cia_toff[cc], *tginv = sCiaTInv + p.cia_toff[cc];
-      const double Tc = T < tg[0] ? tg[0] : (T > tg[nt - 1] ? tg[nt - 1] : T);
-      const double n1 = prof[(size_t)(p.cia_s1[cc] + 1) * L + l] * nd * (1.0 / kAMAGAT);
-      const double n2 = prof[(size_t)(p.cia_s2[cc] + 1) * L + l] * nd * (1.0 / kAMAGAT);
-      int jc = 0;
-      double fc = 0.0;
-      if (nt > 1) {
-        jc = bracket_dev(tg, tginv, nt, Tc);
-        fc = (Tc - tg[jc]) * tginv[jc];
-      }
-      // a single-temperature table is stored twice so plane jc+1 exists
-      ix[1 + cc] = (idx_t)(p.cia_toff[cc] + cc + jc) * p.W * 8;
-      c[2 + 2 * M + 2 * cc] = n1 * n2 * (1.0 - fc);
-      c[3 + 2 * M + 2 * cc] = n1 * n2 * fc;
-    }
-    double ray = 0.0;
-    if (p.scat_flag == 1 && p.iH2 >= 0) {
-      const double l4 = (kRayLambda0 * kRayLambda0) * (kRayLambda0 * kRayLambda0);
-      ray = pow(10.0, p.scat_value) * kRaySigma0 * prof[(size_t)(p.iH2 + 1) * L + l] * nd * l4;
-    } else if (p.scat_flag == 2) {
-      const double k0 = 128.0 * (kPI * kPI * kPI * kPI * kPI) / 3.0;
-      if (p.iH2 >= 0) ray += kPolH2 * kPolH2 * prof[(size_t)(p.iH2 + 1) * L + l] * nd;
-      if (p.iHe >= 0) ray += kPolHe * kPolHe * prof[(size_t)(p.iHe + 1) * L + l] * nd;
-      ray *= k0;
-    }
-    c[2 + 2 * M + 2 * C] = ray;
-  }
-  if (p.rad_out)
-    for (int l = threadIdx.x; l < L; l += blockDim.x) p.rad_out[(size_t)w * L + l] = bad ? 0.0 : sR[l];
-  if (p.rtop && !bad) {
-    // the chord table itself is filled from these radii by chord_table_fill
-    double *rt = p.rtop + (size_t)w * L;
-    for (int k = threadIdx.x; k < L; k += blockDim.x) rt[k] = sR[L - 1 - k];
-  }
-  if (threadIdx.x == 0) {
-    int ks = L - 1;
-    if (p.has_cloud) {
-      for (int k = 0; k < L; k++)
-        if (sPress[L - 1 - k] >= p.cloudtop) { ks = k; break; }
-    }
-    p.kstop[w] = ks;
-    if (p.ok) p.ok[w] = bad ? 0 : 1;
-  }
+  // the phases of prep_body then run out of LDS.  The kernel is pure latency:
+  // each dependent trip to memory it avoids is worth most of a microsecond.
+  stage2_to_lds(prep_lds_profile(sm, L), p.prof + (size_t)w * (S + 1) * L, (S + 1) * L,
+                prep_lds_consts(sm, L, S), p.consts, 2 * L + S + 2 * p.Nt + 2 * p.ncia_temps,
+                threadIdx.x, blockDim.x);
+  prep_body(p, w, sm);
 }
 
 // ---------------------------------------------------------------------------
@@ -767,8 +603,7 @@ void rt_eclipse_lp(RtArgs p) {
 // ---------------------------------------------------------------------------
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
-  size_t sh = sizeof(double) * ((size_t)4 * a.L + (size_t)(a.S + 1) * a.L + 2 * a.L + a.S + 2 * a.Nt +
-                               2 * a.ncia_temps + 1);
+  const size_t sh = sizeof(double) * prep_lds_doubles(a.L, a.S, a.Nt, a.ncia_temps);
   hipLaunchKernelGGL(prep_profiles, dim3(a.nwalkers), dim3(128), sh, st, a);
   return hipGetLastError();
 }

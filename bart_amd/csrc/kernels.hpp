@@ -78,6 +78,34 @@ __device__ __forceinline__ void stage2_to_lds(TA *dstA, const TA *srcA, int nA, 
   }
 }
 
+// Three arrays in one batch (see stage2_to_lds).
+template <int U = 8, typename TA, typename TB, typename TC>
+__device__ __forceinline__ void stage3_to_lds(TA *dstA, const TA *srcA, int nA, TB *dstB, const TB *srcB,
+                                              int nB, TC *dstC, const TC *srcC, int nC, int tid,
+                                              int nthreads) {
+  static_assert(sizeof(TA) == 8 && sizeof(TB) == 8 && sizeof(TC) == 8, "8-byte words");
+  const int span = U * nthreads;
+  for (int base = 0; base < nA || base < nB || base < nC; base += span) {
+    TA a[U];
+    TB b[U];
+    TC c[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int t = base + j * nthreads + tid;
+      a[j] = t < nA ? srcA[t] : TA(0);
+      b[j] = t < nB ? srcB[t] : TB(0);
+      c[j] = t < nC ? srcC[t] : TC(0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int t = base + j * nthreads + tid;
+      if (t < nA) dstA[t] = a[j];
+      if (t < nB) dstB[t] = b[j];
+      if (t < nC) dstC[t] = c[j];
+    }
+  }
+}
+
 struct PrepArgs {
   int L, S, M, Nt, C, W, nwalkers;
   const double *prof;      // [nw][(S+1)][L]

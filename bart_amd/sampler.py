@@ -74,10 +74,13 @@ def run(model, cfg: SamplerConfig, log=None):
     nsteps = max(1, int(np.ceil(cfg.numit / nch)))
     npars = len(cfg.params)
 
+    inv_unc = 1.0 / np.asarray(cfg.uncert, float)
+
     def chisq_of(p):
         m = np.asarray(model(p))
-        bad = np.any(m < 0, axis=1) & np.all(m == -1.0, axis=1)
-        c = np.sum(((m - cfg.data) / cfg.uncert) ** 2, axis=1)
+        bad = (m == -1.0).all(axis=1)            # the worker's rejection sentinel
+        r = (m - cfg.data) * inv_unc
+        c = np.einsum("ij,ij->i", r, r)
         c[bad] = np.inf
         return c
 
@@ -103,51 +106,67 @@ def run(model, cfg: SamplerConfig, log=None):
     naccept = 0
     gamma0 = 2.38 / np.sqrt(2 * max(nfree, 1))
     idx = np.arange(nch)
+    snooker = cfg.walk == "snooker" and nch > 3
+    pmin, pmax, step_free = cfg.pmin, cfg.pmax, cfg.stepsize[free]
 
-    def _other(rng, excluded):
-        """For every chain one chain index drawn uniformly from those not in its
-        row of `excluded` [nch, k] (distinct entries), all chains in one call."""
-        k = excluded.shape[1]
-        draw = rng.integers(0, nch - k, size=nch)
-        for col in np.sort(excluded, axis=1).T:   # skip over the excluded ones in ascending order
-            draw += draw >= col
+    def others(excluded):
+        """[B, nch] chain indices drawn uniformly from the chains not listed in
+        `excluded` [B, nch, k] (distinct entries per chain), all at once."""
+        k = excluded.shape[-1]
+        draw = rng.integers(0, nch - k, size=excluded.shape[:-1])
+        ex = np.sort(excluded, axis=-1)
+        for j in range(k):                 # skip over the excluded ones in ascending order
+            draw += draw >= ex[..., j]
         return draw
 
-    for t in range(nsteps):
-        prop = x.copy()
-        r1 = _other(rng, idx[:, None])
-        r2 = _other(rng, np.stack([idx, r1], axis=1)) if nch > 2 else r1
-        logjac = np.zeros(nch)
-        if cfg.walk == "snooker" and nch > 3 and t % 10 != 0:
-            # snooker update: move along the line through a third chain
-            z = _other(rng, np.stack([idx, r1, r2], axis=1))
-            d = x[:, free] - x[z][:, free]
-            nd = np.linalg.norm(d, axis=1, keepdims=True)
-            nd[nd == 0] = 1.0
-            u = d / nd
-            proj = np.sum((x[r1][:, free] - x[r2][:, free]) * u, axis=1, keepdims=True)
-            g = rng.uniform(1.2, 2.2, size=(nch, 1))
-            prop[:, free] = x[:, free] + g * proj * u
-            nd_new = np.linalg.norm(prop[:, free] - x[z][:, free], axis=1)
-            logjac = (nfree - 1) * (np.log(np.maximum(nd_new, 1e-300)) - np.log(nd[:, 0]))
-        else:
-            gam = 1.0 if t % 10 == 0 else gamma0
-            jit = 1e-3 * cfg.stepsize[free] * rng.normal(size=(nch, nfree))
-            prop[:, free] = x[:, free] + gam * (x[r1][:, free] - x[r2][:, free]) + jit
-        inside = np.all((prop >= cfg.pmin) & (prop <= cfg.pmax), axis=1)
-        cp = np.full(nch, np.inf)
-        if inside.any():
-            cp[inside] = chisq_of(prop[inside])
-        with np.errstate(invalid="ignore", over="ignore"):
-            loga = -0.5 * (cp - c) + logjac
-        acc = np.log(rng.random(nch)) < loga
-        acc &= np.isfinite(cp)
-        x[acc], c[acc] = prop[acc], cp[acc]
-        naccept += int(acc.sum())
-        chain[:, t], chis[:, t] = x, c
-        if log is not None and (t + 1) % max(1, nsteps // 10) == 0:
-            log("step %d/%d  best chisq %.4f  acceptance %.2f" % (
-                t + 1, nsteps, float(np.min(chis[:, :t + 1])), naccept / ((t + 1) * nch)))
+    # random numbers for a block of iterations at a time: the per-iteration loop
+    # is then a dozen small array operations around one model call
+    B = 256
+    for t0 in range(0, nsteps, B):
+        nb = min(B, nsteps - t0)
+        me = np.broadcast_to(idx, (nb, nch))
+        r1 = others(me[..., None])
+        r2 = others(np.stack([me, r1], axis=-1)) if nch > 2 else r1
+        z = others(np.stack([me, r1, r2], axis=-1)) if snooker else None
+        jit = 1e-3 * step_free * rng.normal(size=(nb, nch, nfree))
+        gsn = rng.uniform(1.2, 2.2, size=(nb, nch, 1))
+        logu = np.log(rng.random((nb, nch)))
+        for b in range(nb):
+            t = t0 + b
+            xf = x[:, free]
+            prop = x.copy()
+            logjac = 0.0
+            if snooker and t % 10 != 0:
+                # snooker update: move along the line through a third chain
+                xz = xf[z[b]]
+                d = xf - xz
+                nd = np.sqrt(np.einsum("ij,ij->i", d, d))[:, None]
+                nd[nd == 0] = 1.0
+                u = d / nd
+                proj = np.einsum("ij,ij->i", xf[r1[b]] - xf[r2[b]], u)[:, None]
+                pf = xf + gsn[b] * proj * u
+                dn = pf - xz
+                nd_new = np.sqrt(np.einsum("ij,ij->i", dn, dn))
+                logjac = (nfree - 1) * (np.log(np.maximum(nd_new, 1e-300)) - np.log(nd[:, 0]))
+            else:
+                gam = 1.0 if t % 10 == 0 else gamma0
+                pf = xf + gam * (xf[r1[b]] - xf[r2[b]]) + jit[b]
+            prop[:, free] = pf
+            inside = ((prop >= pmin) & (prop <= pmax)).all(axis=1)
+            if inside.all():
+                cp = chisq_of(prop)
+            else:
+                cp = np.full(nch, np.inf)
+                if inside.any():
+                    cp[inside] = chisq_of(prop[inside])
+            with np.errstate(invalid="ignore", over="ignore"):
+                acc = (logu[b] < -0.5 * (cp - c) + logjac) & np.isfinite(cp)
+            x[acc], c[acc] = prop[acc], cp[acc]
+            naccept += int(acc.sum())
+            chain[:, t], chis[:, t] = x, c
+            if log is not None and (t + 1) % max(1, nsteps // 10) == 0:
+                log("step %d/%d  best chisq %.4f  acceptance %.2f" % (
+                    t + 1, nsteps, float(np.min(chis[:, :t + 1])), naccept / ((t + 1) * nch)))
     ib = np.unravel_index(np.argmin(chis), chis.shape)
     post = chain[:, min(cfg.burnin, nsteps - 1):]
     gr = gelman_rubin(post[:, :, free]) if cfg.grtest and post.shape[1] > 3 and nch > 1 else None

@@ -652,9 +652,10 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
     return !(e && e[0] == '0');
   }();
-  // the specialised kernels address the tables through 32-bit buffer offsets
-  const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
-  if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && fits32) {
+  // (the specialised kernels rebuild their buffer descriptor per layer, so the
+  // table may be of any size; one layer's pair of planes must stay below 4 GB)
+  const bool plane_ok = 2ull * a.M * a.W * 8ull < (1ull << 31);
+  if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && plane_ok) {
     RtArgs b = a;
     const bool sq = allow_sq && order_angles_for_square(b);
     // too few single-wave columns to load the 1 024 SIMDs evenly -> several

@@ -251,11 +251,13 @@ struct TableLoader {
   static constexpr int NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1, NI = 1 + C;
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   unsigned voff[NR];
-  decltype(__builtin_amdgcn_make_buffer_rsrc((void *)nullptr, (short)0, 0, 0)) rs_k, rs_c;
+  const char *kappa, *cia;
+  int span_k, span_c;   // bytes one layer reads from: two temperature planes
   const idx_t *sI;
 
   // ii: this lane's wavenumber index; sI: the walker's offset records in LDS
-  __device__ __forceinline__ TableLoader(const RtArgs &p, unsigned ii, const idx_t *sI_) : sI(sI_) {
+  __device__ __forceinline__ TableLoader(const RtArgs &p, unsigned ii, const idx_t *sI_)
+      : kappa(reinterpret_cast<const char *>(p.kappa)), cia(reinterpret_cast<const char *>(p.cia)), sI(sI_) {
     const unsigned off = ii * 8u;  // byte offset of this lane inside a table row
     const size_t rowB = (size_t)p.W * 8, planeB = (size_t)M * p.W * 8;
 #pragma unroll
@@ -268,26 +270,35 @@ struct TableLoader {
       voff[2 * M + 2 * cc] = off;
       voff[2 * M + 2 * cc + 1] = off + (unsigned)rowB;
     }
-    rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
-    rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
+    span_k = (int)(2 * planeB);
+    span_c = (int)(2 * rowB);
   }
 
-  // issue the loads of layer k into r (no wait)
+  // wave-uniform 64-bit byte offset out of a record read from LDS
+  static __device__ __forceinline__ long long uniform64(idx_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  }
+
+  // issue the loads of layer k into r (no wait).  The descriptor is rebuilt per
+  // layer around the layer's own pair of planes (a 64-bit scalar add), so the
+  // 32-bit offsets of the buffer instructions never limit the table size.
   __device__ __forceinline__ void load(int k, double (&r)[NR]) const {
     const idx_t *ix = sI + k * NI;
     if (M > 0) {
-      const int so = __builtin_amdgcn_readfirstlane((int)ix[0]);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kappa + uniform64(ix[0])), 0, span_k, 0x00020000);
 #pragma unroll
       for (int j = 0; j < 2 * M; j++)
-        r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)voff[j], so, 0));
+        r[j] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff[j], 0, 0));
     }
 #pragma unroll
     for (int cc = 0; cc < C; cc++) {
-      const int so = __builtin_amdgcn_readfirstlane((int)ix[1 + cc]);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(cia + uniform64(ix[1 + cc])), 0, span_c, 0x00020000);
 #pragma unroll
       for (int h = 0; h < 2; h++)
         r[2 * M + 2 * cc + h] = __builtin_bit_cast(
-            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)voff[2 * M + 2 * cc + h], so, 0));
+            double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff[2 * M + 2 * cc + h], 0, 0));
     }
   }
 };

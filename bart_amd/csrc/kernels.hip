@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     tau += dtau;
     // I_a += (B_{k-1} + B_k)/2 * (E_{a,k-1} - E_{a,k}), E = exp(-tau/mu):
     // trapezoid in the transmittance (exact for an isothermal column)
-    const double B = bnum / (exp(c[1] * nu) - 1.0);
+    const double B = bnum * rcp_core(exp_core(fmin(c[1] * nu, 700.0)) - 1.0);
     const double hb = active ? 0.5 * (Bprev + B) : 0.0;
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
       if (AT <= 0 && a >= A) break;
-      const double E = exp(-tau * p.invmu[a]);
+      const double E = exp_core(fmax(-tau * p.invmu[a], kExpMin));
       I[a] += hb * (fprev[a] - E);
       fprev[a] = E;
     }

@@ -614,10 +614,6 @@ static hipError_t launch_rt_t(const RtArgs &a, int block, int nblocks, size_t sh
   return hipGetLastError();
 }
 
-// (molecules, CIA pairs) the specialised kernels are instantiated for
-#define BARTRT_MC_LIST(X) \
-  X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(5, 1) X(6, 1)
-
 // If one ray angle has exactly half the cosine of another (0 and 60 degrees of
 // the usual raygrid 0 20 40 60 80), put that pair first and last: the SQ kernels
 // take the last transmittance as the square of the first.

@@ -2,6 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// (molecules, CIA pairs) the specialised kernels are instantiated for
+#define BARTRT_MC_LIST(X) \
+  X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(5, 1) X(6, 1)
+
 namespace bartrt {
 
 // Physical constants, cgs.  H, LS, KB: the values BART copies from transit

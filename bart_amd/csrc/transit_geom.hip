@@ -295,9 +295,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((rt_transit_mfma<MM, CC>), dim3(nb), dim3(256), shm, st, b);         \
     return hipGetLastError();                                                               \
   }
-    BARTRT_TRANSIT(1, 0) BARTRT_TRANSIT(1, 1) BARTRT_TRANSIT(2, 0) BARTRT_TRANSIT(2, 1)
-    BARTRT_TRANSIT(3, 1) BARTRT_TRANSIT(4, 0) BARTRT_TRANSIT(4, 1) BARTRT_TRANSIT(5, 1)
-    BARTRT_TRANSIT(6, 1)
+    BARTRT_MC_LIST(BARTRT_TRANSIT)
 #undef BARTRT_TRANSIT
   }
   static size_t allowed = 48 * 1024;

@@ -276,13 +276,14 @@ void rt_eclipse_fast(RtArgs p) {
   if (valid) p.spec[(size_t)w * W + i] = F;
 }
 
-// Few-walker variant (1-4 walkers at W = 1e4): the layer loop is split over TWO
-// waves per 64 wavenumbers.  Wave 0 (producer) streams the tables and advances
-// the optical depth and the Planck term; wave 1 (consumer) turns each tau into
-// the A transmittances and accumulates the intensities.  The halves are about
-// equal in issue slots, so the serial time per layer halves at unchanged total
-// work -- it pays only while most SIMDs hold no wave at all (1 walker: 40 vs
-// 53 us; from ~8 walkers on the single-wave kernel is as fast or faster).
+// Few-walker variant (5-9 walkers at W = 1e4; below that the layer-parallel
+// kernel is faster still): the layer loop is split over TWO waves per 64
+// wavenumbers.  Wave 0 (producer) streams the tables and advances the optical
+// depth and the Planck term; wave 1 (consumer) turns each tau into the A
+// transmittances and accumulates the intensities.  The halves are about equal
+// in issue slots, so the serial time per layer halves at unchanged total work
+// -- it pays while the single-wave columns cannot load the 1 024 SIMDs evenly
+// (9 walkers: 77 vs 88 us; from 10 walkers on the single-wave kernel wins).
 // Hand-off: an LDS ring of two 4-layer halves [tau, (B_{k-1}+B_k)/2 * live]
 // per lane and ONE raw workgroup barrier per 4 layers (the consumer reads half
 // b while the producer fills half b+1).

@@ -222,8 +222,16 @@ def comm_disconnect(comm):
     comm.Disconnect()
 
 
-def main(comm, argv=None):
-    """The reference's ``main(comm)`` (BARTfunc.py:33-412) on the GPU engine."""
+def main(comm, argv=None, group=None):
+    """The reference's ``main(comm)`` (BARTfunc.py:33-412) on the GPU engine.
+
+    ``comm`` is the intercommunicator to the MC3 master, one worker process per
+    chain as MC3 spawns them.  ``group`` is the workers' own communicator (their
+    ``MPI.COMM_WORLD``): when it holds more than one rank the chains' parameter
+    vectors are gathered to worker 0 every step, evaluated there as ONE batch on
+    the GPU, and the band fluxes scattered back before each worker answers the
+    master -- MC3 is unchanged, the engine is initialised once, and the forward
+    models of a step run batched instead of one engine call per process."""
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument("-c", "--config_file", required=True)
     args, _ = ap.parse_known_args(argv)
@@ -232,27 +240,44 @@ def main(comm, argv=None):
     array1 = np.zeros(2, int)
     comm_bcast(comm, array1)
     npars, niter = int(array1[0]), int(array1[1])
-    w = Worker(cfg)
-    if verb:
+    nworkers = group.Get_size() if group is not None else 1
+    wrank = group.Get_rank() if group is not None else 0
+    w = Worker(cfg) if wrank == 0 else None       # the GPU engine lives in worker 0
+    if verb and w is not None:
         print("There are {:d} layers and {:d} species.".format(w.nlayers, w.nspecies))
     params = np.zeros(npars, np.double)
+    nfilt = np.zeros(1, int)
+    if nworkers > 1:
+        if wrank == 0:
+            nfilt[0] = w.nfilters
+        group.Bcast(nfilt, root=0)
+    allp = np.zeros((nworkers, npars), np.double) if wrank == 0 else None
+    mine = np.zeros(int(nfilt[0]), np.double)
     while niter >= 0:
         niter -= 1
         comm_scatter(comm, params)
-        if params[0] == np.inf:
+        if params[0] == np.inf:       # MC3 ends the run with an all-inf vector to every worker
             break
-        comm_gather(comm, np.ascontiguousarray(w.step(params)[0]))
+        if nworkers == 1:
+            comm_gather(comm, np.ascontiguousarray(w.step(params)[0]))
+            continue
+        group.Gather(params, allp, root=0)
+        band = np.ascontiguousarray(w.step(allp)) if wrank == 0 else None
+        group.Scatter(band, mine, root=0)
+        comm_gather(comm, mine)
     comm_disconnect(comm)
-    w.close()
-    if verb:
-        print("Bad iterations of chain 0 due to:")
-        print("  Temperature: {}".format(w.nbad[1]))
-        print("  Abundance:   {}".format(w.nbad[2]))
+    nbad = w.nbad if w is not None else None
+    if w is not None:
+        w.close()
+    if verb and nbad is not None:
+        print("Bad iterations of {} due to:".format("chain 0" if nworkers == 1 else "all chains"))
+        print("  Temperature: {}".format(nbad[1]))
+        print("  Abundance:   {}".format(nbad[2]))
         if cfg.ebalance:
-            print("  Energy:      {}".format(w.nbad[3]))
-    return w.nbad
+            print("  Energy:      {}".format(nbad[3]))
+    return nbad
 
 
 if __name__ == "__main__":
     from mpi4py import MPI  # only needed when launched by MC3
-    main(MPI.Comm.Get_parent())
+    main(MPI.Comm.Get_parent(), group=MPI.COMM_WORLD)

@@ -106,3 +106,90 @@ def test_worker_batched_step_and_ebalance(tmp_path):
         assert np.all(band[band[:, 0] >= 0] > 0)
     finally:
         w.close()
+
+
+class FakeGroup:
+    """The workers' own communicator (MPI.COMM_WORLD of the processes MC3
+    spawns), shared-memory version for worker threads."""
+
+    def __init__(self, size):
+        import threading
+        self.size = size
+        self.barrier = threading.Barrier(size)
+        self.slots = [None] * size
+        self.root_buf = None
+
+    def view(self, rank):
+        g = self
+
+        class View:
+            def Get_size(self):
+                return g.size
+
+            def Get_rank(self):
+                return rank
+
+            def Bcast(self, array, root=0):
+                if rank == root:
+                    g.root_buf = np.array(array)
+                g.barrier.wait()
+                array[...] = g.root_buf
+                g.barrier.wait()
+
+            def Gather(self, send, recv, root=0):
+                g.slots[rank] = np.array(send, float)
+                g.barrier.wait()
+                if rank == root:
+                    recv[...] = np.array(g.slots)
+                g.barrier.wait()
+
+            def Scatter(self, send, recv, root=0):
+                if rank == root:
+                    g.root_buf = np.array(send, float)
+                g.barrier.wait()
+                recv[...] = g.root_buf[rank]
+                g.barrier.wait()
+
+        return View()
+
+
+@pytest.mark.gpu
+def test_worker_group_batches_the_chains(tmp_path):
+    """Four worker ranks as MC3 spawns them (one chain each): every step's four
+    parameter vectors are evaluated as one batch by worker 0; each master-side
+    communicator receives what a lone worker would have sent for its chain."""
+    import threading
+    from bart_amd import BARTfunc, synthcfg
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=600)
+    rng = np.random.default_rng(8)
+    base = np.array([-2.0, 0.0, 1.0, 0.0, 0.98, -0.5])
+    chains = [[base + 0.05 * rng.normal(size=6) for _ in range(3)] for _ in range(4)]
+    chains[2][1] = np.array([-1.0, -2.0, -2.0, 0.0, 1.2, -0.5])      # a rejected (too hot) proposal
+    # reference run: each chain through a lone worker
+    lone = []
+    for c in chains:
+        comm = FakeIntercomm(c)
+        BARTfunc.main(comm, ["-c", cfg])
+        lone.append(comm.received)
+    group = FakeGroup(4)
+    comms = [FakeIntercomm(c) for c in chains]
+    errors = []
+
+    def run(r):
+        try:
+            BARTfunc.main(comms[r], ["-c", cfg], group=group.view(r))
+        except Exception as e:                       # surface worker failures in the test thread
+            errors.append(e)
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for r in range(4):
+        assert comms[r].disconnected and len(comms[r].received) == 3
+        for got, want in zip(comms[r].received, lone[r]):
+            assert np.array_equal(got, want)
+    assert np.all(comms[2].received[1] == -1.0)

@@ -242,7 +242,24 @@ def main(comm, argv=None, group=None):
     npars, niter = int(array1[0]), int(array1[1])
     nworkers = group.Get_size() if group is not None else 1
     wrank = group.Get_rank() if group is not None else 0
-    w = Worker(cfg) if wrank == 0 else None       # the GPU engine lives in worker 0
+    # BARTRT_GPUS = G > 1: the first G workers each drive one GPU of the node and
+    # hold one wavenumber block of the tables; every step they all evaluate the
+    # whole batch on their block and reassemble the spectra with one RCCL
+    # all-gather (Worker.step's sharded path).  Needs G GPUs: not exercised by the
+    # single-GPU test suite.
+    ngpu = max(1, min(int(os.environ.get("BARTRT_GPUS", "1")), nworkers))
+    if ngpu > 1:
+        port = np.array([int(os.environ.get("BARTRT_PORT", "29533"))])
+        group.Bcast(port, root=0)
+        if wrank < ngpu:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(wrank)
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(port[0]),
+                                    rank=wrank, world_size=ngpu, device_id=torch.device("cuda", wrank))
+        w = Worker(cfg, shard=(wrank, ngpu), device=wrank) if wrank < ngpu else None
+    else:
+        w = Worker(cfg) if wrank == 0 else None   # the GPU engine lives in worker 0
     if verb and w is not None:
         print("There are {:d} layers and {:d} species.".format(w.nlayers, w.nspecies))
     params = np.zeros(npars, np.double)
@@ -251,7 +268,7 @@ def main(comm, argv=None, group=None):
         if wrank == 0:
             nfilt[0] = w.nfilters
         group.Bcast(nfilt, root=0)
-    allp = np.zeros((nworkers, npars), np.double) if wrank == 0 else None
+    allp = np.zeros((nworkers, npars), np.double) if (wrank == 0 or ngpu > 1) else None
     mine = np.zeros(int(nfilt[0]), np.double)
     while niter >= 0:
         niter -= 1
@@ -261,8 +278,11 @@ def main(comm, argv=None, group=None):
         if nworkers == 1:
             comm_gather(comm, np.ascontiguousarray(w.step(params)[0]))
             continue
-        group.Gather(params, allp, root=0)
-        band = np.ascontiguousarray(w.step(allp)) if wrank == 0 else None
+        if ngpu > 1:
+            group.Allgather(params, allp)      # every GPU-owning worker evaluates the whole batch
+        else:
+            group.Gather(params, allp, root=0)
+        band = np.ascontiguousarray(w.step(allp)) if w is not None else None
         group.Scatter(band, mine, root=0)
         comm_gather(comm, mine)
     comm_disconnect(comm)

@@ -438,8 +438,9 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     if (!d_intens) HIPCHK(hipMalloc(&d_intens, sizeof(double) * (size_t)A * W()));
     r.intens_out = d_intens;
   }
-  int block = 256;
-  if ((long)((r.W + 255) / 256) * n < 512 || solution == 1) block = 64;
+  // one wave per workgroup at every batch size (measured against 128 and 256 lanes:
+  // 2-5 % faster from 64 walkers up, finer turnover of the SIMDs' wave slots)
+  const int block = 64;
   r.ntiles = (r.W + block - 1) / block;
   r.rtop = d_rtop; r.ds = d_ds;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;

@@ -12,8 +12,8 @@
 //                    extinction and the tau / per-angle outputs.
 //  rt_eclipse_fast   the same walk specialised at compile time, buffer loads with
 //                    scalar plane offsets, two pairs of register slots in flight.
-//  rt_eclipse_split  5-9 walkers: producer / consumer wave pair per column.
-//  rt_eclipse_lp     1-4 walkers: one wave per chunk of layers per column.
+//  rt_eclipse_split  4-8 walkers: producer / consumer wave pair per column.
+//  rt_eclipse_lp     1-3 walkers: one wave per chunk of layers per column.
 //
 // The walker's coefficient records are staged in LDS once per workgroup and
 // read back as wave-uniform broadcasts.  Interpolation + reduction, fp64 VALU;
@@ -33,12 +33,12 @@
 #endif
 
 // Kernel choice by 64-wavenumber columns per launch (measured at W = 1e4, L = 100:
-// 157 columns per walker).  <= 4 walkers: layer-parallel (1 walker 27 us against
-// 39 split / 54 single-wave; 4 walkers 52 / 55 / 61); 5-9 walkers: producer/consumer
-// split (9 walkers 77 us against 89 layer-parallel / 88 single-wave); from 10
-// walkers on the single-wave kernel wins (90 / 95 / 98 us).
-constexpr long kLpMaxColumns = 640;
-constexpr long kSplitMaxColumns = 1440;
+// 157 columns per walker; microseconds per launch, layer-parallel / split / single-wave):
+//   1 walker 26 / 39 / 54     3 walkers 39 / 44 / 49     4 walkers 51 / 47 / 50
+//   6 walkers 65 / 54 / 55    8 walkers 79 / 68 / 75     9 walkers 91 / 80 / 80
+//   10 walkers 101 / 85 / 86  (single-wave from here on: same time, half the waves)
+constexpr long kLpMaxColumns = 500;
+constexpr long kSplitMaxColumns = 1300;
 constexpr int kLpChunk = 13;  // layers per wave of the layer-parallel kernel
 
 namespace bartrt {
@@ -276,14 +276,14 @@ void rt_eclipse_fast(RtArgs p) {
   if (valid) p.spec[(size_t)w * W + i] = F;
 }
 
-// Few-walker variant (5-9 walkers at W = 1e4; below that the layer-parallel
+// Few-walker variant (4-8 walkers at W = 1e4; below that the layer-parallel
 // kernel is faster still): the layer loop is split over TWO waves per 64
 // wavenumbers.  Wave 0 (producer) streams the tables and advances the optical
 // depth and the Planck term; wave 1 (consumer) turns each tau into the A
 // transmittances and accumulates the intensities.  The halves are about equal
 // in issue slots, so the serial time per layer halves at unchanged total work
 // -- it pays while the single-wave columns cannot load the 1 024 SIMDs evenly
-// (9 walkers: 77 vs 88 us; from 10 walkers on the single-wave kernel wins).
+// (8 walkers: 68 vs 75 us; from 9 walkers on the single-wave kernel is as fast).
 // Hand-off: an LDS ring of two 4-layer halves [tau, (B_{k-1}+B_k)/2 * live]
 // per lane and ONE raw workgroup barrier per 4 layers (the consumer reads half
 // b while the producer fills half b+1).

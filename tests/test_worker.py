@@ -102,7 +102,8 @@ def test_worker_batched_step_and_ebalance(tmp_path):
         band = w.step(p)
         assert band.shape == (33, 10)
         one = np.array([w.step(q)[0] for q in p[:4]])
-        assert np.array_equal(one, band[:4])          # batch == one-at-a-time, bit for bit
+        # batch == one at a time (to rounding: the two batch sizes run different RT kernels)
+        np.testing.assert_allclose(one, band[:4], rtol=1e-12)
         assert np.all(band[band[:, 0] >= 0] > 0)
     finally:
         w.close()

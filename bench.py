@@ -224,8 +224,8 @@ def main():
     sweep = {}
     if world == 1 and a.sweep:
         for b in [int(x) for x in a.sweep.split(",") if x]:
-            k = max(5, min(50, 2000 // b))
-            sdt, skm, snl, sok, _ = timed(b, k, 2, True)
+            k = max(16, min(50, 4000 // b))
+            sdt, skm, snl, sok, _ = timed(b, k, 8, True)
             sweep[str(b)] = {"spectra_per_s": b * k / sdt, "ms_per_step": sdt / k * 1e3,
                              "rt_kernel_ms": skm / max(snl, 1),
                              "algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}

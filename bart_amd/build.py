@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
-SOURCES = ["capi.hip", "engine.hip", "kernels.hip", "step.hip", "lbl.hip", "transit_geom.hip",
+SOURCES = ["capi.hip", "engine.hip", "kernels.hip", "step.hip", "mcmc.hip", "lbl.hip", "transit_geom.hip",
            "io.cpp"]
 HEADERS = ["engine.hpp", "kernels.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]

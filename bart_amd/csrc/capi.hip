@@ -372,4 +372,19 @@ int bartrt_step_batch(const double *params, int nwalkers, int npars,
   });
 }
 
+int bartrt_mcmc_run(int nchains, int npars, long nsteps, const double *params, const double *pmin,
+                    const double *pmax, const double *stepsize, int ndata, const double *data,
+                    const double *uncert, int snooker, unsigned long long seed, double *chain,
+                    double *chisq, long *naccept, long *nbad) {
+  NEED_ENGINE();
+  if (!g_eng->step) return fail(BARTRT_EINVAL, "mcmc_run: call bartrt_step_setup first");
+  if (!params || !pmin || !pmax || !stepsize || !data || !uncert || !chain || !chisq)
+    return fail(BARTRT_EINVAL, "mcmc_run: null buffer");
+  return guarded([&] {
+    mcmc_run(*g_eng, nchains, npars, nsteps, params, pmin, pmax, stepsize, ndata, data, uncert,
+             snooker, seed, chain, chisq, naccept, nbad);
+    return BARTRT_OK;
+  });
+}
+
 }  // extern "C"

@@ -55,5 +55,10 @@ void step_run_dev(Engine &e, const double *d_params, int n, int npars, double *d
                   int *d_status, double *d_spec, hipStream_t st, int *status_out = nullptr);
 void step_run_host(Engine &e, const double *params, int n, int npars, double *bandflux,
                    int *status);
+// DEMC / snooker over all chains, one step_run_host per iteration (mcmc.hip)
+void mcmc_run(Engine &e, int nchains, int npars, long nsteps, const double *params, const double *pmin,
+              const double *pmax, const double *stepsize, int ndata, const double *data,
+              const double *uncert, int snooker, unsigned long long seed, double *chain,
+              double *chisq, long *naccept, long *nbad);
 
 }  // namespace bartrt

@@ -26,6 +26,8 @@ def main(argv=None):
     ap.add_argument("-c", "--config_file", required=True)
     ap.add_argument("--out", default=None)
     ap.add_argument("--numit", type=int, default=None)
+    ap.add_argument("--python-loop", action="store_true",
+                    help="run the sampler loop in Python (sampler.run) instead of the native one")
     a = ap.parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -49,7 +51,8 @@ def main(argv=None):
             print(msg, flush=True)
 
     t0 = time.perf_counter()
-    res = sampler.run(w.step, scfg, log=log)
+    native = not a.python_loop and world == 1 and not (w.ncloud or w.nray or w.nradfit)
+    res = sampler.run_native(w, scfg, log=log) if native else sampler.run(w.step, scfg, log=log)
     dt = time.perf_counter() - t0
     nmodel = res["chain"].shape[0] * res["chain"].shape[1]
     log("%d models in %.2f s (%.0f models/s); acceptance %.3f; best chisq %.4f" % (

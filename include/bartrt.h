@@ -105,6 +105,21 @@ int bartrt_step_set_ebalance(int on, double e_in, double e_fac);
  * temperature, 2 bad abundance, 3 energy balance.  status may be NULL. */
 int bartrt_step_batch(const double *params, int nwalkers, int npars,
                       double *bandflux, int *status);
+/* The retrieval's driver loop, native: differential-evolution MCMC (snooker = 0,
+ * the reference's `walk = demc`) or its snooker variant (snooker = 1) over
+ * nchains chains, all of them evaluated by one batched model call per
+ * iteration, nsteps iterations.  Arguments are the keys of the reference's
+ * [MCMC] section (examples/demo/BART_eclipse.cfg:43-102): params (start),
+ * pmin, pmax, stepsize (0 = fixed) of length npars = nPT + nmolfit as in
+ * bartrt_step_batch; data, uncert of length ndata = nfilters.  Proposals
+ * outside [pmin, pmax] and models rejected by the worker are refused.
+ * chain[nchains][nsteps][npars], chisq[nchains][nsteps]; naccept (accepted
+ * proposals) and nbad[4] (models rejected with status 1, 2, 3 in nbad[1..3]) may
+ * be NULL. */
+int bartrt_mcmc_run(int nchains, int npars, long nsteps, const double *params, const double *pmin,
+                    const double *pmax, const double *stepsize, int ndata, const double *data,
+                    const double *uncert, int snooker, unsigned long long seed, double *chain,
+                    double *chisq, long *naccept, long *nbad);
 /* Device-resident form; d_status and d_spec ([nwalkers][nwave]) may be NULL. */
 int bartrt_step_batch_dev(const double *d_params, int nwalkers, int npars,
                           double *d_bandflux, int *d_status, double *d_spec,

@@ -26,12 +26,15 @@ for nch in (10, 32):
         pmax=np.array([-1, 1, 1, 1, 1.2, 1.5, 1.5, 1.5, 1.5]),
         stepsize=np.array([0.01, 0.01, 0.01, 0.01, 0.001, 0.05, 0.05, 0.05, 0.05]),
         data=data, uncert=data * 0.01, nchains=nch, numit=numit, burnin=50, walk="snooker", seed=1)
-    sampler.run(w.step, scfg)                      # warm-up
-    t0 = time.perf_counter()
-    res = sampler.run(w.step, scfg)
-    dt = time.perf_counter() - t0
-    print(json.dumps({"workload": "WASP-12b shape (100 layers x 2424 samples, 4 molecules, 4 filters), "
-                                  "snooker DEMC, %d chains" % nch,
-                      "iterations_per_s": round(numit / nch / dt, 1), "model_evaluations_per_s": round(numit / dt),
-                      "acceptance": round(res["accept_rate"], 3)}))
+    for name, fn in (("python loop", lambda: sampler.run(w.step, scfg)),
+                     ("native loop", lambda: sampler.run_native(w, scfg))):
+        fn()                                       # warm-up
+        t0 = time.perf_counter()
+        res = fn()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"workload": "WASP-12b shape (100 layers x 2424 samples, 4 molecules, 4 filters), "
+                                      "snooker DEMC, %d chains, %s" % (nch, name),
+                          "iterations_per_s": round(numit / nch / dt, 1),
+                          "model_evaluations_per_s": round(numit / dt),
+                          "acceptance": round(res["accept_rate"], 3)}))
 w.close()

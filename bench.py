@@ -141,7 +141,22 @@ def main():
     use_dist = world > 1 or (a.force_collective and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner through C stdio on stdout when the first
+        # communicator comes up; the contract is ONE JSON line there.  File
+        # descriptor 1 points at stderr until the communicator exists and the C
+        # buffers are flushed.
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from bart_amd import engine, synth
 

@@ -81,3 +81,41 @@ def test_full_grid_shards_concatenate(full_case):
         parts.append(engine.run_batch(np.tile(profs, (8, 1)))[:10])   # 80 walkers per step, as at N = 8
         trm.free_memory()
     assert np.array_equal(np.concatenate(parts, axis=1), full)
+
+
+def test_full_grid_transit_geometry(tmp_path_factory):
+    """Transit geometry at the headline shape: modulation bounded by the bottom
+    and top radii, walkers independent of batch order and size, blocks of the 8-GPU layout concatenate bit for bit, and the oracle
+    on slices."""
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = synth.make_case(str(tmp_path_factory.mktemp("case_full_transit")), nlayers=100, nwave=10000,
+                        extra_keys={"solution": "transit", "starrad": 1.145})
+    rstar = 1.145 * 6.95508e10
+    engine.init(c.tcfg)
+    try:
+        profs = _profiles(c, 6, seed=21)
+        spec = engine.run_batch(profs)
+        assert spec.shape == (6, 10000) and np.all(np.isfinite(spec))
+        import ctypes
+        rad = np.zeros(100)
+        for w in range(3):
+            one = trm.run_transit(profs[w], 10000)
+            np.testing.assert_allclose(one, spec[w], rtol=1e-13)      # one walker: the same kernel, other grid
+            assert trm.lib().bartrt_get_radius(rad.ctypes.data_as(ctypes.c_void_p), 100) == 0
+            assert np.all(one >= (rad.min() / rstar) ** 2 * (1 - 1e-12))
+            assert np.all(one <= (rad.max() / rstar) ** 2 * (1 + 1e-12))
+        perm = np.random.default_rng(2).permutation(6)
+        assert np.array_equal(engine.run_batch(profs[perm]), spec[perm])
+        assert np.array_equal(engine.run_batch(np.tile(profs, (20, 1)))[:6], spec)
+        for lo in (0, 5000, 9872):
+            o = orc.OracleEngine(c.tcfg, wn_lo=lo, wn_hi=lo + 128)
+            np.testing.assert_allclose(spec[2, lo:lo + 128], o.run(profs[2]), rtol=1e-10)
+    finally:
+        trm.free_memory()
+    parts = []
+    for r in range(8):
+        engine.init(c.tcfg, shard=(r, 8))
+        parts.append(engine.run_batch(profs))
+        trm.free_memory()
+    assert np.array_equal(np.concatenate(parts, axis=1), spec)

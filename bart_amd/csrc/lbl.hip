@@ -28,15 +28,19 @@ constexpr double kEXPCTE = kH * kLS / kKB;          // h c / k_B, cm K
 constexpr double kSqrtLn2 = 0.8325546111576977;
 constexpr double kInvSqrtPi = 0.5641895835477563;
 
-// Re w(x + i y), x >= 0, y > 0.
+// Re w(x + i y), x >= 0, y > 0.  Contraction is switched off inside and every
+// fused multiply-add is written out: the function is inlined into kernels with
+// different surroundings, and which products the compiler fuses must not depend
+// on them (a layer state can be summed by either accumulation kernel).
 __device__ inline double voigt_k(double x, double y) {
-  const double r2 = x * x + y * y;
+#pragma clang fp contract(off)
+  const double r2 = fma(x, x, y * y);
   if (r2 >= 225.0) {
     // far wings (almost every line-point pair of a pressure-broadened layer):
     // asymptotic series w = i/(sqrt(pi) z) (1 + 1/(2 z^2) + 3/(4 z^4) + ...),
     // 2 / 3 / 5 terms for |z| >= 100 / 30 / 15 (<= 1.3e-11 / 9e-11 / 1.7e-11)
     const double inv = rcp_core(r2), inv2 = inv * inv;  // reciprocal + Newton: no IEEE divide per pair
-    const double tr = (x * x - y * y) * inv2, ti = -2.0 * x * y * inv2;  // t = 1/z^2
+    const double tr = fma(x, x, -(y * y)) * inv2, ti = -2.0 * x * y * inv2;  // t = 1/z^2
     double hr, hi;
     if (r2 >= 1.0e4) { hr = 0.75; hi = 0.0; }
     else {
@@ -53,23 +57,23 @@ __device__ inline double voigt_k(double x, double y) {
     double ar = fma(hr, tr, -hi * ti) + 0.5, ai = fma(hr, ti, hi * tr);
     const double sr = fma(ar, tr, -ai * ti) + 1.0, si = fma(ar, ti, ai * tr);
     // Re[i s / z] = (y s_r - x s_i) / |z|^2
-    return kInvSqrtPi * (y * sr - x * si) * inv;
+    return kInvSqrtPi * fma(y, sr, -(x * si)) * inv;
   }
   if (r2 >= 64.0) {
     // Laplace continued fraction, 8 levels (8 <= |z| < 15, <= 1.7e-12)
     const int K = 8;
     double fr = x, fi = y;
     for (int k = K; k >= 1; k--) {
-      const double s = (0.5 * k) * rcp_core(fr * fr + fi * fi);
-      const double nr = x - s * fr, ni = y + s * fi;
+      const double s = (0.5 * k) * rcp_core(fma(fr, fr, fi * fi));
+      const double nr = fma(-s, fr, x), ni = fma(s, fi, y);
       fr = nr; fi = ni;
     }
-    return kInvSqrtPi * fi * rcp_core(fr * fr + fi * fi);
+    return kInvSqrtPi * fi * rcp_core(fma(fr, fr, fi * fi));
   }
   // Weideman N = 40: Z = ((L - y) + i x) / ((L + y) - i x)
   const double ar = kWeidL - y, br = kWeidL + y;
-  const double den = rcp_core(br * br + x * x);
-  const double Zr = (ar * br - x * x) * den, Zi = (x * br + ar * x) * den;
+  const double den = rcp_core(fma(br, br, x * x));
+  const double Zr = fma(ar, br, -(x * x)) * den, Zi = fma(x, br, ar * x) * den;
   double pr = kWeidA[0], pi = 0.0;
 #pragma unroll 8
   for (int k = 1; k < kWeidN; k++) {
@@ -79,8 +83,8 @@ __device__ inline double voigt_k(double x, double y) {
   }
   // 1/(L - iz) = (br + i x) den ; its square
   const double qr = br * den, qi = x * den;
-  const double q2r = qr * qr - qi * qi, q2i = 2.0 * qr * qi;
-  return 2.0 * (pr * q2r - pi * q2i) + kInvSqrtPi * qr;
+  const double q2r = fma(qr, qr, -(qi * qi)), q2i = 2.0 * qr * qi;
+  return fma(2.0, fma(pr, q2r, -(pi * q2i)), kInvSqrtPi * qr);
 }
 
 struct StateArgs {
@@ -159,6 +163,7 @@ __global__ void lbl_states(StateArgs a, LblDev d) {
 // invT = 1 / T.  exp_core: the arguments are <= 0; far below -708 the line is
 // negligible at any threshold
 __device__ inline double line_strength(double gf, double elow, double nu0, double scale, double invT) {
+#pragma clang fp contract(off)  // same bits in every kernel that inlines it (see voigt_k)
   const double a = fmax(-kEXPCTE * elow * invT, kExpMin), b = fmax(-kEXPCTE * nu0 * invT, kExpMin);
   return gf * scale * exp_core(a) * (1.0 - exp_core(b));
 }
@@ -225,6 +230,7 @@ __device__ __forceinline__ bool narrow_state(const LblDev &d, const AccArgs &a, 
 // One line's staged record, or cut < 0 for a line below the strength threshold.
 struct LineRec { double nu0, amp, xs, y, cut; };
 __device__ __forceinline__ LineRec stage_line(const LblDev &d, const double *sv, double invT, double thresh, long j) {
+#pragma clang fp contract(off)
   LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
   const int k = d.liso[j];
   const double n0 = d.nu0[j];
@@ -281,7 +287,10 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
       __syncthreads();
       for (int t = 0; t < cnt; t++) {
         const double dv = fabs(nu - s_nu0[t]);
-        if (dv <= s_cut[t]) acc += s_amp[t] * voigt_k(dv * s_xs[t], s_y[t]);
+        // product rounded on its own (no fma into the sum): the pair kernel stores
+        // the same product before adding it, and a state may change owner between
+        // two tilings of the grid -- the bits must not
+        if (dv <= s_cut[t]) acc = __dadd_rn(acc, __dmul_rn(s_amp[t], voigt_k(dv * s_xs[t], s_y[t])));
       }
       __syncthreads();
     }
@@ -378,13 +387,13 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
         int x = 0, y = 64;  // line of pair p: last t with off[t] <= p
         while (y - x > 1) { const int m = (x + y) >> 1; if (ws.off[m] <= p) x = m; else y = m; }
         const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
-        ws.val[p] = dv <= ws.cut[x] ? ws.amp[x] * voigt_k(dv * ws.xs[x], ws.y[x]) : 0.0;
+        ws.val[p] = dv <= ws.cut[x] ? __dmul_rn(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
       }
       wave_sync();
       // ---- C
       for (int t = 0; t < 64; t++) {
         const unsigned k = (unsigned)(lane - ws.first[t]);
-        if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc += ws.val[ws.off[t] + k];
+        if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc = __dadd_rn(acc, ws.val[ws.off[t] + k]);
       }
       wave_sync();
     }

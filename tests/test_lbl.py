@@ -166,3 +166,40 @@ def test_lazy_fused_kernel_matches_eager(tmp_path):
                               timeout=300)
         outs[mode] = np.load(out)
     np.testing.assert_allclose(outs["lazy"], outs["eager"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_config5_size_properties(tmp_path):
+    """BASELINE config 5's size (1e6 lines, 1e5 points, 100 layers), where the
+    oracle cannot follow: extinction is non-negative and exactly linear in a
+    molecule's abundance (a factor 2 is a bit-exact doubling: strengths and the
+    ethresh reference scale together, widths depend on H2 / He only), and the
+    wavenumber blocks of a sharded engine concatenate to the unsharded result
+    (to the last bit or two: which of the two accumulation kernels owns a layer
+    state depends on the tiling of the grid)."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    mols = ("H2O", "CO", "CO2", "CH4")
+    c = synth_lbl.make_lbl_case(str(tmp_path), molecules=mols, nlines=250000, nwave=100000,
+                                wnlow=1000.0, wndelt=0.1, nlayers=100, cia=False)
+    engine.init(c.tcfg)
+    try:
+        prof = c.profiles()
+        ext = engine.lbl_extinction(prof)
+        assert ext.shape == (100, 100000) and np.all(np.isfinite(ext)) and ext.min() >= 0 and ext.max() > 0
+        sp = engine.species()
+        twice = prof.copy()
+        for m in mols:
+            twice[1 + sp.index(m)] *= 2.0
+        assert np.array_equal(engine.lbl_extinction(twice), 2.0 * ext)
+        spec = trm.run_transit(prof.ravel(), 100000)
+        assert np.all(np.isfinite(spec)) and spec.min() > 0
+    finally:
+        trm.free_memory()
+    parts = []
+    for r in range(4):
+        engine.init(c.tcfg, shard=(r, 4))
+        parts.append(engine.lbl_extinction(prof))
+        trm.free_memory()
+    cat = np.concatenate(parts, axis=1)
+    np.testing.assert_allclose(cat, ext, rtol=1e-15, atol=0.0)
+    assert np.mean(cat != ext) < 1e-4

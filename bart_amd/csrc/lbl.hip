@@ -28,6 +28,17 @@ constexpr double kEXPCTE = kH * kLS / kKB;          // h c / k_B, cm K
 constexpr double kSqrtLn2 = 0.8325546111576977;
 constexpr double kInvSqrtPi = 0.5641895835477563;
 
+// a * b rounded, then added: never fused (the header's __dmul_rn / __dadd_rn are
+// plain operators the compiler may contract again after inlining)
+__device__ __forceinline__ double mul_rounded(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double add_rounded(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+
 // Re w(x + i y), x >= 0, y > 0.  Contraction is switched off inside and every
 // fused multiply-add is written out: the function is inlined into kernels with
 // different surroundings, and which products the compiler fuses must not depend
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
         // product rounded on its own (no fma into the sum): the pair kernel stores
         // the same product before adding it, and a state may change owner between
         // two tilings of the grid -- the bits must not
-        if (dv <= s_cut[t]) acc = __dadd_rn(acc, __dmul_rn(s_amp[t], voigt_k(dv * s_xs[t], s_y[t])));
+        if (dv <= s_cut[t]) acc = add_rounded(acc, mul_rounded(s_amp[t], voigt_k(dv * s_xs[t], s_y[t])));
       }
       __syncthreads();
     }
@@ -387,13 +398,13 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
         int x = 0, y = 64;  // line of pair p: last t with off[t] <= p
         while (y - x > 1) { const int m = (x + y) >> 1; if (ws.off[m] <= p) x = m; else y = m; }
         const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
-        ws.val[p] = dv <= ws.cut[x] ? __dmul_rn(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
+        ws.val[p] = dv <= ws.cut[x] ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
       }
       wave_sync();
       // ---- C
       for (int t = 0; t < 64; t++) {
         const unsigned k = (unsigned)(lane - ws.first[t]);
-        if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc = __dadd_rn(acc, ws.val[ws.off[t] + k]);
+        if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc = add_rounded(acc, ws.val[ws.off[t] + k]);
       }
       wave_sync();
     }

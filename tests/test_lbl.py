@@ -174,9 +174,9 @@ def test_config5_size_properties(tmp_path):
     oracle cannot follow: extinction is non-negative and exactly linear in a
     molecule's abundance (a factor 2 is a bit-exact doubling: strengths and the
     ethresh reference scale together, widths depend on H2 / He only), and the
-    wavenumber blocks of a sharded engine concatenate to the unsharded result
-    (to the last bit or two: which of the two accumulation kernels owns a layer
-    state depends on the tiling of the grid)."""
+    wavenumber blocks of a sharded engine concatenate to the unsharded result bit
+    for bit (which of the two accumulation kernels owns a layer state depends on
+    the tiling of the grid: they must agree to the last bit)."""
     from bart_amd import engine, synth_lbl, transit_module as trm
     mols = ("H2O", "CO", "CO2", "CH4")
     c = synth_lbl.make_lbl_case(str(tmp_path), molecules=mols, nlines=250000, nwave=100000,
@@ -200,6 +200,4 @@ def test_config5_size_properties(tmp_path):
         engine.init(c.tcfg, shard=(r, 4))
         parts.append(engine.lbl_extinction(prof))
         trm.free_memory()
-    cat = np.concatenate(parts, axis=1)
-    np.testing.assert_allclose(cat, ext, rtol=1e-15, atol=0.0)
-    assert np.mean(cat != ext) < 1e-4
+    assert np.array_equal(np.concatenate(parts, axis=1), ext)

@@ -82,8 +82,9 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
     }
     if (k > 0) {
       sP[(size_t)k * 64 + threadIdx.x] = eprev + e;
+      const double *dk = dsw + chord_table_index(L, k, 0);   // + (j / 4) * 64 + (j % 4) * 16 per layer j
       double t = 0.0;
-      for (int j = 1; j <= k; j++) t = fma(sP[(size_t)j * 64 + threadIdx.x], dsw[chord_table_index(L, k, j)], t);
+      for (int j = 1; j <= k; j++) t = fma(sP[(size_t)j * 64 + threadIdx.x], dk[(j >> 2) * 64 + (j & 3) * 16], t);
       if (active) {
         tau = t;
         const double g = exp(-t) * rt[k];

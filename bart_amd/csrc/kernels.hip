@@ -12,8 +12,8 @@
 //                    extinction and the tau / per-angle outputs.
 //  rt_eclipse_fast   the same walk specialised at compile time, buffer loads with
 //                    scalar plane offsets, two pairs of register slots in flight.
-//  rt_eclipse_split  4-8 walkers: producer / consumer wave pair per column.
-//  rt_eclipse_lp     1-3 walkers: one wave per chunk of layers per column.
+//  rt_eclipse_split  5-8 walkers: producer / consumer wave pair per column.
+//  rt_eclipse_quad   1-4 walkers: 16 wavenumbers x 4 layers per wave and step.
 //
 // The walker's coefficient records are staged in LDS once per workgroup and
 // read back as wave-uniform broadcasts.  Interpolation + reduction, fp64 VALU;
@@ -33,13 +33,12 @@
 #endif
 
 // Kernel choice by 64-wavenumber columns per launch (measured at W = 1e4, L = 100:
-// 157 columns per walker; microseconds per launch, layer-parallel / split / single-wave):
-//   1 walker 26 / 39 / 54     3 walkers 39 / 44 / 49     4 walkers 51 / 47 / 50
-//   6 walkers 65 / 54 / 55    8 walkers 79 / 68 / 75     9 walkers 91 / 80 / 80
-//   10 walkers 101 / 85 / 86  (single-wave from here on: same time, half the waves)
-constexpr long kLpMaxColumns = 500;
+// 157 columns per walker; microseconds per launch, quad-layer / split / single-wave):
+//   1 walker 26 / 39 / 54     2 walkers 33 / 38 / 48     4 walkers 45 / 47 / 50
+//   5 walkers 54 / 52 / 52    6 walkers 58 / 53 / 55     8 walkers 73 / 68 / 75
+//   9 walkers 81 / 80 / 80    10 walkers 90 / 85 / 84  (single-wave from here on)
+constexpr long kQuadMaxColumns = 640;
 constexpr long kSplitMaxColumns = 1300;
-constexpr int kLpChunk = 13;  // layers per wave of the layer-parallel kernel
 
 namespace bartrt {
 
@@ -276,7 +275,7 @@ void rt_eclipse_fast(RtArgs p) {
   if (valid) p.spec[(size_t)w * W + i] = F;
 }
 
-// Few-walker variant (4-8 walkers at W = 1e4; below that the layer-parallel
+// Few-walker variant (5-8 walkers at W = 1e4; below that the quad-layer
 // kernel is faster still): the layer loop is split over TWO waves per 64
 // wavenumbers.  Wave 0 (producer) streams the tables and advances the optical
 // depth and the Planck term; wave 1 (consumer) turns each tau into the A
@@ -426,179 +425,167 @@ void rt_eclipse_split(RtArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// Layer-parallel variant for small and medium batches.  Only the running sum
-// tau_k is serial along a column; the extinction of a layer, its Planck term
-// and its A transmittances are independent once tau_k is known.  A workgroup
-// therefore takes ONE 64-wavenumber column and gives every wave a chunk of CH
-// consecutive layers:
-//   phase A  table loads + extinction of the chunk's layers, optical depth
-//            relative to the chunk's first layer (kept in registers), and the
-//            chunk's first / last extinction, total and maximum -> LDS
-//   barrier
-//   phase B  every wave rebuilds the optical depth at its chunk's start from
-//            the published totals (same chain in every wave), finds out whether
-//            the column was cut (`toomuch`) above it, and sums its layers' terms
-//            of the transmittance trapezoid; per-wave partial fluxes meet in LDS.
-// Work per column is that of the single-wave kernel plus one boundary layer per
-// chunk, but it comes in L/CH short waves: 10 walkers x 157 columns become
-// 12 560 waves that the dispatcher spreads evenly over the 1 024 SIMDs (1 570
-// long waves leave half of the SIMDs with two and half with one), and a lone
-// walker's latency drops by about the number of chunks.
-template <int AT, int MT, int CT, int CH, bool SQ>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
-void rt_eclipse_lp(RtArgs p) {
+// Quad-layer variant: a wave takes 16 wavenumbers and FOUR layers at a time.
+// Lane (q = l / 16, m = l % 16) owns wavenumber m in the layers j = 4 s + q: per
+// step s the four lane rows load and evaluate four consecutive layers side by
+// side, the optical depth is a 4-lane prefix sum on top of the running value of
+// the previous step (the wavefront scan of the tau integral), and every lane
+// turns its own tau into its layer's Planck term and A transmittances.  The
+// previous layer's values a trapezoid step needs come from the lane row below
+// (row 3 of the previous step for row 0).  Same arithmetic per (layer,
+// wavenumber) as the single-wave kernel, but a column is 25 steps deep instead
+// of 100 layers, and a launch is made of four times as many, four times shorter
+// waves: ten walkers are 6 250 of them over 1 024 SIMDs instead of 1 570 that
+// leave half of the SIMDs with two and half with one.  The `toomuch` exit is
+// per 16 wavenumbers and per step of four layers.
+template <int AT, int MT, int CT, bool SQ>
+__global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
-  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
-  constexpr int NR = NLD > 0 ? NLD : 1;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
+  constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
   const int L = p.L, W = p.W;
   int tile, w;
   block_to_work(blockIdx.x, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
-  const int nwv = blockDim.x >> 6;  // waves = chunks
 
   double *sC = smem;
   idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
-  double *sPub = smem + (size_t)L * NC + (size_t)L * NI;  // [chunk][first, last, total, max][64]
-  double *sF = sPub + (size_t)nwv * 256;                  // [chunk][64] partial fluxes
+  stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
+                threadIdx.x, 256);
+  __syncthreads();
+
   const int lane = threadIdx.x & 63;
-  const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int k0 = c * CH;
-  const int i = tile * 64 + lane;
-  const bool valid = i < W;
-  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
-  const int kend = p.kstop[w];
+  const int q = lane >> 4, m = lane & 15;
+  const int i0 = tile * 64 + (threadIdx.x >> 6) * 16;  // this wave's first wavenumber
+  if (i0 >= W) return;
+  const unsigned ii = i0 + m < W ? (unsigned)(i0 + m) : (unsigned)(W - 1);
   const double nu = p.wn[ii];
+  const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+  const double nu4 = (nu * nu) * (nu * nu);
+  const int kend = p.kstop[w];
+  const double tcap = tau_cap(p, A);
+
+  // per-lane table addressing: plane offset of the lane's layer + row + lane
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
+  const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
+  auto load_layer = [&](int j, double (&r)[NR]) {
+    const idx_t *ix = sI + j * NI;
+    if (M > 0) {
+      const unsigned po = (unsigned)ix[0] + off;
+#pragma unroll
+      for (int mm = 0; mm < M; mm++) {
+        r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
+        r[2 * mm + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + planeB + mm * rowB), 0, 0));
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const unsigned po = (unsigned)ix[1 + cc] + off;
+      r[2 * M + 2 * cc] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)po, 0, 0));
+      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)(po + rowB), 0, 0));
+    }
+  };
   auto clampk = [&](int k) { return k < kend ? k : kend; };
-  {
-    // every wave stages the records of its own chunk and reads them back without
-    // a workgroup barrier; the other chunks' records are only needed after the
-    // barrier that ends phase A
-    const int n = (L - k0 < CH ? L - k0 : CH);
-    const double *gC = p.coef + ((size_t)w * L + k0) * NC;
-    const idx_t *gI = p.idx + ((size_t)w * L + k0) * NI;
-    stage2_to_lds(sC + k0 * NC, gC, n * NC, sI + k0 * NI, gI, n * NI, lane, 64);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
 
-  // ---------------- phase A ----------------
-  double tl[CH];  // tau_{k0+j} - tau_{k0}
+  // the lanes of one wavenumber: bits m, 16 + m, 32 + m, 48 + m of a ballot
+  const unsigned long long col_bits = 0x0001000100010001ull << m;
+  const unsigned long long below_bits = col_bits & ((1ull << (16 * q)) - 1ull);
+  const int from_below = (lane + 48) & 63;  // row q - 1 (row 3 for row 0)
+
+  double I[A];
 #pragma unroll
-  for (int j = 0; j < CH; j++) tl[j] = 0.0;
-  if (k0 <= kend) {
-    const double nu4 = (nu * nu) * (nu * nu);
-    const TableLoader<M, C> tab(p, ii, sI);
-    auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
-    // D layers of loads are requested ahead of the arithmetic (the loop is fully
-    // unrolled, and the compiler hoists further loads as registers allow:
-    // D = 2..6 measured the same)
-    constexpr int D = 2 < CH ? 2 : CH - 1;
-    double r[D + 1][NR];
+  for (int a = 0; a < A; a++) I[a] = 0.0;
+  // carries of row 0: extinction, Planck term, transmittances of the layer just
+  // above this step (row 3 of the previous step), and the optical depth there
+  double c_e = 0.0, c_B = 0.0, c_E[AE], c_tau = 0.0;
 #pragma unroll
-    for (int j = 0; j < D; j++) load_layer(clampk(k0 + j), r[j]);
-    double efirst = 0.0, eprev = 0.0, t = 0.0, tmax = 0.0;
+  for (int a = 0; a < AE; a++) c_E[a] = 1.0;
+  bool active = true;  // no layer above this step passed `toomuch` (per wavenumber, all rows agree)
+
+  auto step = [&](int s, const double (&rv)[NR]) {
+    const int j = 4 * s + q, jc = clampk(j);
+    const bool inrange = j <= kend;
+    const double *c = sC + jc * NC;
+    double cf[NC];
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-      const int k = k0 + j;
-      if (j + D < CH) load_layer(clampk(k + D), r[(j + D) % (D + 1)]);
-      const double *cr = sC + clampk(k) * NC;
-      double cf[NC];
+    for (int x = 0; x < NC; x++) cf[x] = c[x];
+    double e = cf[2 + 2 * M + 2 * C] * nu4;
 #pragma unroll
-      for (int q = 0; q < NC; q++) cf[q] = cr[q];
-      double e = cf[2 + 2 * M + 2 * C] * nu4;
+    for (int x = 0; x < NLD; x++) e = fma(cf[2 + x], rv[x], e);
+    // extinction of the layer above
+    const double e_below = __shfl(e, from_below);
+    const double eprev = q == 0 ? c_e : e_below;
+    c_e = e_below;
+    // optical depth: 4-lane prefix sum of the steps' increments + the running value
+    double v = (eprev + e) * cf[0] * ((inrange && active) ? 0.5 : 0.0);
+    const double v1 = __shfl(v, (lane + 48) & 63);
+    if (q >= 1) v += v1;
+    const double v2 = __shfl(v, (lane + 32) & 63);
+    if (q >= 2) v += v2;
+    const double tau = c_tau + v;
+    c_tau = __shfl(tau, 48 + m);
+    // which layers of this step are still above the cut
+    const unsigned long long over = __ballot(inrange && active && tau > p.toomuch);
+    const bool live = inrange && active && (over & below_bits) == 0ull;
+    active = active && (over & col_bits) == 0ull;
+    // Planck term and transmittances of this lane's layer
+    const double tc = fmin(tau, tcap);
+    double xs[AE + 1], ex[AE + 1];
+    xs[AE] = fmin(cf[1] * nu, 700.0);
 #pragma unroll
-      for (int q = 0; q < NLD; q++) e = fma(cf[2 + q], r[j % (D + 1)][q], e);
-      if (j == 0) {
-        efirst = e;
-      } else {
-        t += (eprev + e) * cf[0] * (k <= kend ? 0.5 : 0.0);
-        tmax = fmax(tmax, t);
-      }
-      tl[j] = t;
-      eprev = e;
+    for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
+    exp_core_n<AE + 1>(xs, ex);
+    const double B = bnum * rcp_core(ex[AE] - 1.0);
+    // the layer above: row q - 1, or the carry for row 0
+    const double B_below = __shfl(B, from_below);
+    const double Bprev = q == 0 ? c_B : B_below;
+    c_B = B_below;
+    const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
+    double Eprev[A], E[A];
+#pragma unroll
+    for (int a = 0; a < AE; a++) {
+      const double E_below = __shfl(ex[a], from_below);
+      Eprev[a] = q == 0 ? c_E[a] : E_below;
+      c_E[a] = E_below;
+      E[a] = ex[a];
     }
-    double *pb = sPub + c * 256 + lane;
-    pb[0] = efirst;
-    pb[64] = eprev;
-    pb[128] = t;
-    pb[192] = tmax;
-  }
-  __syncthreads();
+    if (SQ) {
+      Eprev[A - 1] = Eprev[0] * Eprev[0];
+      E[A - 1] = E[0] * E[0];
+    }
+#pragma unroll
+    for (int a = 0; a < A; a++) I[a] = fma(hb, Eprev[a] - E[a], I[a]);
+    if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) {  // deck reached below toomuch
+#pragma unroll
+      for (int a = 0; a < A; a++) I[a] = fma(B, E[a], I[a]);
+    }
+  };
 
-  // ---------------- phase B ----------------
+  double ra[NR], rb[NR];
+  load_layer(clampk(q), ra);
+  for (int s = 0; 4 * s <= kend; s += 2) {
+    load_layer(clampk(4 * (s + 1) + q), rb);
+    step(s, ra);
+    if (!__any(active)) break;
+    load_layer(clampk(4 * (s + 2) + q), ra);
+    if (4 * (s + 1) <= kend) {
+      step(s + 1, rb);
+      if (!__any(active)) break;
+    }
+  }
+  // the four rows of a wavenumber hold its layers' terms: sum them; row 0 writes
   double F = 0.0;
-  if (k0 <= kend) {
-    // optical depth at this chunk's first layer (t0) and at the layer above it
-    // (tup), and whether the column was cut before this chunk
-    double t0 = 0.0, tup = 0.0;
-    bool cut = false;
-    for (int cc = 0; cc < c; cc++) {
-      const double *pb = sPub + cc * 256 + lane;
-      cut = cut || (t0 + pb[192] > p.toomuch);
-      tup = t0 + pb[128];
-      const int kb = (cc + 1) * CH;  // <= k0 <= kend
-      t0 = tup + (pb[64] + pb[256]) * sC[kb * NC] * 0.5;
-    }
-    if (__any(!cut)) {
-      const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
-      const double tcap = tau_cap(p, A);
-      constexpr int AE = SQ ? A - 1 : A;
-      double I[A], fprev[A], Bprev = 0.0;
 #pragma unroll
-      for (int a = 0; a < A; a++) { I[a] = 0.0; fprev[a] = 1.0; }
-      if (c > 0) {
-        double xs[AE + 1], ex[AE + 1];
-        xs[AE] = fmin(sC[(k0 - 1) * NC + 1] * nu, 700.0);
-#pragma unroll
-        for (int a = 0; a < AE; a++) xs[a] = -fmin(tup, tcap) * p.invmu[a];
-        exp_core_n<AE + 1>(xs, ex);
-        Bprev = bnum * rcp_core(ex[AE] - 1.0);
-#pragma unroll
-        for (int a = 0; a < AE; a++) fprev[a] = ex[a];
-        if (SQ) fprev[A - 1] = ex[0] * ex[0];
-      }
-#pragma unroll
-      for (int j = 0; j < CH; j++) {
-        const int k = k0 + j;
-        const bool live = !cut && k <= kend;
-        const double tau = t0 + tl[j], tc = fmin(tau, tcap);
-        double xs[AE + 1], ex[AE + 1], es[A];
-        xs[AE] = fmin(sC[clampk(k) * NC + 1] * nu, 700.0);
-#pragma unroll
-        for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
-        exp_core_n<AE + 1>(xs, ex);
-#pragma unroll
-        for (int a = 0; a < AE; a++) es[a] = ex[a];
-        if (SQ) es[A - 1] = ex[0] * ex[0];
-        const double B = bnum * rcp_core(ex[AE] - 1.0);
-        const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
-#pragma unroll
-        for (int a = 0; a < A; a++) {
-          I[a] = fma(hb, fprev[a] - es[a], I[a]);
-          fprev[a] = es[a];
-        }
-        Bprev = B;
-        cut = cut || (live && tau > p.toomuch);
-        if (k == kend && p.cloud_on) {  // deck reached below toomuch: its surface emission
-          const double bs = cut ? 0.0 : B;
-#pragma unroll
-          for (int a = 0; a < A; a++) I[a] = fma(bs, es[a], I[a]);
-        }
-        if (!__any(!cut)) break;
-      }
-#pragma unroll
-      for (int a = 0; a < A; a++) F = fma(p.wgt[a], I[a], F);
-    }
+  for (int a = 0; a < A; a++) {
+    double t = I[a];
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    F = fma(p.wgt[a], t, F);
   }
-  sF[c * 64 + lane] = F;
-  __syncthreads();
-  if (c == 0) {
-    double s = 0.0;
-    for (int cc = 0; cc < nwv; cc++) s += sF[cc * 64 + lane];
-    if (valid) p.spec[(size_t)w * W + i] = s;
-  }
+  if (q == 0 && i0 + m < W) p.spec[(size_t)w * W + i0 + m] = F;
 }
 
 // ---------------------------------------------------------------------------
@@ -656,33 +643,23 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     RtArgs b = a;
     const bool sq = allow_sq && order_angles_for_square(b);
     // too few single-wave columns to load the 1 024 SIMDs evenly -> several
-    // waves per 64 wavenumbers: one per chunk of layers (layer-parallel), or a
-    // producer / consumer pair
+    // waves per 64 wavenumbers: four 16-wavenumber waves that take four layers at
+    // a time (quad-layer), or a producer / consumer pair
     const long columns = (long)a.nwalkers * ((a.W + 63) / 64);
     const int ntiles64 = (a.W + 63) / 64;
     const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
-    static const int lp_ch_env = [] {
-      const char *e = std::getenv("BARTRT_LP_CH");
-      return e ? std::atoi(e) : 0;
-    }();
-    const int lp_ch = lp_ch_env > 0 ? lp_ch_env : kLpChunk;
-    const int lp_waves = (a.L + lp_ch - 1) / lp_ch;
-    if ((kmode == "lp" || (kmode.empty() && columns <= kLpMaxColumns)) && lp_waves <= 16) {
+    // the quad-layer kernel addresses the tables with per-lane 32-bit offsets
+    const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
+    if ((kmode == "quad" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
       b.ntiles = ntiles64;
-      const size_t shl = sh + sizeof(double) * (size_t)lp_waves * (256 + 64);
-#define BARTRT_LP_CH(MM, CC, CHH)                                                                          \
-  if (a.M == MM && a.C == CC && lp_ch == CHH) {                                                            \
-    if (sq) hipLaunchKernelGGL((rt_eclipse_lp<5, MM, CC, CHH, true>), dim3(nb64), dim3(64 * lp_waves), shl, st, b);  \
-    else hipLaunchKernelGGL((rt_eclipse_lp<5, MM, CC, CHH, false>), dim3(nb64), dim3(64 * lp_waves), shl, st, b);    \
+#define BARTRT_QUAD(MM, CC)                                                                                \
+  if (a.M == MM && a.C == CC) {                                                                            \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, true>), dim3(nb64), dim3(256), sh, st, b);      \
+    else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false>), dim3(nb64), dim3(256), sh, st, b);        \
     return hipGetLastError();                                                                              \
   }
-#define BARTRT_LP(MM, CC) BARTRT_LP_CH(MM, CC, 13)
-      BARTRT_MC_LIST(BARTRT_LP)
-#ifdef BARTRT_LP_EXPERIMENT  // chunk-size A/B (BARTRT_LP_CH): 7, 10, 17 lose; 25 about equal
-      BARTRT_LP_CH(4, 1, 7) BARTRT_LP_CH(4, 1, 10) BARTRT_LP_CH(4, 1, 17) BARTRT_LP_CH(4, 1, 25)
-#endif
-#undef BARTRT_LP
-#undef BARTRT_LP_CH
+      BARTRT_MC_LIST(BARTRT_QUAD)
+#undef BARTRT_QUAD
     }
     if (kmode == "split" || (kmode.empty() && columns <= kSplitMaxColumns)) {
       b.ntiles = ntiles64;

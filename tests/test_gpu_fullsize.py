@@ -40,7 +40,7 @@ def test_full_grid_properties(full_case):
         # (2) walkers are independent: any order, any batch size, same bits
         perm = np.random.default_rng(1).permutation(12)
         assert np.array_equal(engine.run_batch(profs[perm]), spec[perm])
-        # one walker takes the producer/consumer kernel: same arithmetic, other schedule
+        # one walker takes the quad-layer kernel: same arithmetic, other schedule
         np.testing.assert_allclose(engine.run_batch(profs[3:4])[0], spec[3], rtol=1e-13)
         big = engine.run_batch(np.tile(profs[:4], (40, 1)))          # 160 walkers: other kernel path
         np.testing.assert_allclose(big[:4], spec[:4], rtol=1e-13)

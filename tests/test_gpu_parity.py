@@ -118,10 +118,10 @@ def test_kernel_variants_match_oracle(tmp_path, kw):
         trm.free_memory()
 
 
-@pytest.mark.parametrize("mode", ["generic", "mono", "split", "lp"])
+@pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad"])
 def test_every_kernel_variant_matches_oracle(small_case, mode):
     """The four RT kernels (generic fallback, single-wave specialised,
-    producer/consumer split, layer-parallel) on the same batch, without and with an opaque cloud
+    producer/consumer split, quad-layer) on the same batch, without and with an opaque cloud
     deck (its surface term takes a different route in each kernel).
     BARTRT_KERNEL is read once per process, so each variant runs in a child."""
     import subprocess, sys, os
@@ -148,12 +148,11 @@ def test_every_kernel_variant_matches_oracle(small_case, mode):
     assert not np.allclose(got[0], got[1])
 
 
-@pytest.mark.parametrize("nlayers", [13, 14, 100, 209])
-def test_cloud_deck_sweep_across_layer_chunks(tmp_path, nlayers):
-    """Small batches run the layer-parallel kernel (a wave per 13 layers; 209
-    layers exceed its 16 waves and fall through to the producer/consumer one):
-    move the cloud deck through the column so the stop layer lands in every
-    chunk, at chunk edges, and above the top."""
+@pytest.mark.parametrize("nlayers", [3, 4, 5, 13, 100, 209])
+def test_cloud_deck_sweep_across_layer_steps(tmp_path, nlayers):
+    """Small batches run the quad-layer kernel (four layers per step, one per lane
+    row): move the cloud deck through the column so the stop layer lands in every
+    row of a step, at step edges, and above the top."""
     from bart_amd import engine, synth, transit_module as trm
     from oracle import rt_oracle as orc
     c = synth.make_case(str(tmp_path), nlayers=nlayers, nwave=130)
@@ -162,8 +161,7 @@ def test_cloud_deck_sweep_across_layer_chunks(tmp_path, nlayers):
         o = orc.OracleEngine(c.tcfg)
         profs = walkers(c, 2, seed=6)
         lp = np.log10(c.press_bar)
-        tops = np.concatenate([np.linspace(lp.min() - 0.5, lp.max() + 0.5, 12), lp[[0, 12, 13]] if nlayers > 13
-                               else lp[[0, 6, 12]]])
+        tops = np.concatenate([np.linspace(lp.min() - 0.5, lp.max() + 0.5, 12), lp[[0, -1, nlayers // 2]]])
         for ct in tops:
             trm.set_cloudtop(float(ct)); o.set_cloudtop(float(ct))
             np.testing.assert_allclose(engine.run_batch(profs), o.run_batch(profs), rtol=RTOL, atol=1e-300)

@@ -13,11 +13,8 @@ VARIANTS = [
     ("default", {}),
     ("mono", {"BARTRT_KERNEL": "mono"}),
     ("split", {"BARTRT_KERNEL": "split"}),
-    ("lp13", {"BARTRT_KERNEL": "lp"}),
+    ("quad", {"BARTRT_KERNEL": "quad"}),
 ]
-for ch in os.environ.get("AB_LP_CH", "").split(","):
-    if ch:
-        VARIANTS.append(("lp%s" % ch, {"BARTRT_KERNEL": "lp", "BARTRT_LP_CH": ch}))
 
 
 only = [v for v in os.environ.get("AB_ONLY", "").split(",") if v]

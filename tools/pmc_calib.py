@@ -6,7 +6,7 @@ import os
 import sys
 import tempfile
 
-os.environ["BARTRT_KERNEL"] = "mono"  # the kernel the bench line times (one walker would pick the layer-parallel one)
+os.environ["BARTRT_KERNEL"] = "mono"  # the kernel the bench line times (one walker would pick the quad-layer one)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402

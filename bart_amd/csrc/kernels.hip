@@ -38,6 +38,7 @@
 //   5 walkers 54 / 52 / 52    6 walkers 58 / 53 / 55     8 walkers 73 / 68 / 75
 //   9 walkers 81 / 80 / 80    10 walkers 90 / 85 / 84  (single-wave from here on)
 constexpr long kQuadMaxColumns = 640;
+constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this: 1 walker 23 us, 2 walkers 30 us
 constexpr long kSplitMaxColumns = 1300;
 
 namespace bartrt {
@@ -438,12 +439,15 @@ void rt_eclipse_split(RtArgs p) {
 // waves: ten walkers are 6 250 of them over 1 024 SIMDs instead of 1 570 that
 // leave half of the SIMDs with two and half with one.  The `toomuch` exit is
 // per 16 wavenumbers and per step of four layers.
-template <int AT, int MT, int CT, bool SQ>
+// R = lane rows = layers per step (4, or 8 for the smallest launches: 8
+// wavenumbers x 8 layers per wave, twice the waves, half the depth).
+template <int AT, int MT, int CT, bool SQ, int R>
 __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
   constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
   constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
+  constexpr int WN = 64 / R;           // wavenumbers per wave
   const int L = p.L, W = p.W;
   int tile, w;
   block_to_work(blockIdx.x, p.nwalkers, tile, w);
@@ -456,8 +460,8 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int q = lane >> 4, m = lane & 15;
-  const int i0 = tile * 64 + (threadIdx.x >> 6) * 16;  // this wave's first wavenumber
+  const int q = lane / WN, m = lane % WN;
+  const int i0 = (tile * 4 + (threadIdx.x >> 6)) * WN;  // this wave's first wavenumber
   if (i0 >= W) return;
   const unsigned ii = i0 + m < W ? (unsigned)(i0 + m) : (unsigned)(W - 1);
   const double nu = p.wn[ii];
@@ -490,10 +494,10 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   };
   auto clampk = [&](int k) { return k < kend ? k : kend; };
 
-  // the lanes of one wavenumber: bits m, 16 + m, 32 + m, 48 + m of a ballot
-  const unsigned long long col_bits = 0x0001000100010001ull << m;
-  const unsigned long long below_bits = col_bits & ((1ull << (16 * q)) - 1ull);
-  const int from_below = (lane + 48) & 63;  // row q - 1 (row 3 for row 0)
+  // the lanes of one wavenumber: bits m, WN + m, 2 WN + m, ... of a ballot
+  const unsigned long long col_bits = (R == 4 ? 0x0001000100010001ull : 0x0101010101010101ull) << m;
+  const unsigned long long below_bits = col_bits & ((1ull << (WN * q)) - 1ull);
+  const int from_below = (lane + 64 - WN) & 63;  // row q - 1 (the last row for row 0)
 
   double I[A];
 #pragma unroll
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   bool active = true;  // no layer above this step passed `toomuch` (per wavenumber, all rows agree)
 
   auto step = [&](int s, const double (&rv)[NR]) {
-    const int j = 4 * s + q, jc = clampk(j);
+    const int j = R * s + q, jc = clampk(j);
     const bool inrange = j <= kend;
     const double *c = sC + jc * NC;
     double cf[NC];
@@ -519,14 +523,15 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
     const double e_below = __shfl(e, from_below);
     const double eprev = q == 0 ? c_e : e_below;
     c_e = e_below;
-    // optical depth: 4-lane prefix sum of the steps' increments + the running value
+    // optical depth: R-lane prefix sum of the step's increments + the running value
     double v = (eprev + e) * cf[0] * ((inrange && active) ? 0.5 : 0.0);
-    const double v1 = __shfl(v, (lane + 48) & 63);
-    if (q >= 1) v += v1;
-    const double v2 = __shfl(v, (lane + 32) & 63);
-    if (q >= 2) v += v2;
+#pragma unroll
+    for (int d = 1; d < R; d <<= 1) {
+      const double t = __shfl(v, (lane + 64 - d * WN) & 63);
+      if (q >= d) v += t;
+    }
     const double tau = c_tau + v;
-    c_tau = __shfl(tau, 48 + m);
+    c_tau = __shfl(tau, (R - 1) * WN + m);
     // which layers of this step are still above the cut
     const unsigned long long over = __ballot(inrange && active && tau > p.toomuch);
     const bool live = inrange && active && (over & below_bits) == 0ull;
@@ -566,23 +571,22 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 
   double ra[NR], rb[NR];
   load_layer(clampk(q), ra);
-  for (int s = 0; 4 * s <= kend; s += 2) {
-    load_layer(clampk(4 * (s + 1) + q), rb);
+  for (int s = 0; R * s <= kend; s += 2) {
+    load_layer(clampk(R * (s + 1) + q), rb);
     step(s, ra);
     if (!__any(active)) break;
-    load_layer(clampk(4 * (s + 2) + q), ra);
-    if (4 * (s + 1) <= kend) {
+    load_layer(clampk(R * (s + 2) + q), ra);
+    if (R * (s + 1) <= kend) {
       step(s + 1, rb);
       if (!__any(active)) break;
     }
   }
-  // the four rows of a wavenumber hold its layers' terms: sum them; row 0 writes
+  // the rows of a wavenumber hold its layers' terms: sum them; row 0 writes
   double F = 0.0;
 #pragma unroll
   for (int a = 0; a < A; a++) {
     double t = I[a];
-    t += __shfl_xor(t, 16);
-    t += __shfl_xor(t, 32);
+    for (int o = WN; o < 64; o <<= 1) t += __shfl_xor(t, o);
     F = fma(p.wgt[a], t, F);
   }
   if (q == 0 && i0 + m < W) p.spec[(size_t)w * W + i0 + m] = F;
@@ -650,13 +654,21 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
     // the quad-layer kernel addresses the tables with per-lane 32-bit offsets
     const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
-    if ((kmode == "quad" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
-      b.ntiles = ntiles64;
-#define BARTRT_QUAD(MM, CC)                                                                                \
-  if (a.M == MM && a.C == CC) {                                                                            \
-    if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, true>), dim3(nb64), dim3(256), sh, st, b);      \
-    else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false>), dim3(nb64), dim3(256), sh, st, b);        \
-    return hipGetLastError();                                                                              \
+    if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
+      // the smallest launches take eight layers per step (8 wavenumbers per wave)
+      const bool octo = kmode == "octo" || (kmode.empty() && columns <= kOctoMaxColumns);
+      b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;
+      const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+#define BARTRT_QUAD(MM, CC)                                                                                  \
+  if (a.M == MM && a.C == CC) {                                                                              \
+    if (octo) {                                                                                              \
+      if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, true, 8>), dim3(nbq), dim3(256), sh, st, b);    \
+      else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false, 8>), dim3(nbq), dim3(256), sh, st, b);      \
+    } else {                                                                                                 \
+      if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, true, 4>), dim3(nbq), dim3(256), sh, st, b);    \
+      else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false, 4>), dim3(nbq), dim3(256), sh, st, b);      \
+    }                                                                                                        \
+    return hipGetLastError();                                                                                \
   }
       BARTRT_MC_LIST(BARTRT_QUAD)
 #undef BARTRT_QUAD

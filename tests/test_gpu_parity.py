@@ -118,10 +118,10 @@ def test_kernel_variants_match_oracle(tmp_path, kw):
         trm.free_memory()
 
 
-@pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad"])
+@pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad", "octo"])
 def test_every_kernel_variant_matches_oracle(small_case, mode):
-    """The four RT kernels (generic fallback, single-wave specialised,
-    producer/consumer split, quad-layer) on the same batch, without and with an opaque cloud
+    """The RT kernels (generic fallback, single-wave specialised, producer/consumer
+    split, quad-layer with four and with eight lane rows) on the same batch, without and with an opaque cloud
     deck (its surface term takes a different route in each kernel).
     BARTRT_KERNEL is read once per process, so each variant runs in a child."""
     import subprocess, sys, os

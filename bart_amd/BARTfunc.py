@@ -155,6 +155,12 @@ class Worker:
                           self.rprs, solution=SOLUTION_CODE[cfg.solution],
                           pttype=PT_CODE[cfg.PTtype],
                           tint_thorngren=(cfg.tint_type == "thorngren"))
+        if self.nradfit or self.ncloud or self.nray:
+            # BARTfunc.py:350-360: the reference sets these through engine-wide setters,
+            # one walker per process; here they travel with each walker of the batch
+            engine.step_set_extras(self.nradfit, self.ncloud, self.nray)
+            if self.nray:
+                trm.set_scattering(2 if "polar" in cfg.scattering else 1, 0.0)
         if cfg.ebalance:
             # BARTfunc.py:375-377
             e_in = (hostio.sig * self.tstar ** 4 * self.rstar ** 2 * np.pi * self.rplanet ** 2
@@ -165,34 +171,18 @@ class Worker:
     def step(self, params: np.ndarray) -> np.ndarray:
         """params [nwalkers, npars] (or [npars]) -> bandflux [nwalkers, nfilters];
         rejected walkers carry -1 in every band."""
-        p = np.atleast_2d(np.asarray(params, np.double))
-        off = self.nPT + self.nradfit
-        if self.ncloud or self.nray or self.nradfit:
-            # engine-global setters, as in the reference (one walker per call)
-            if p.shape[0] != 1:
-                raise NotImplementedError("radius/cloud/scattering parameters are per-call "
-                                          "settings: batch size must be 1")
-            if self.nradfit:
-                trm.set_radius(p[0, self.nPT])          # BARTfunc.py:350-351, km
-            if self.ncloud:
-                trm.set_cloudtop(p[0, off])
-            if self.nray:
-                if "polar" in self.cfg.scattering:
-                    trm.set_scattering(2, 0.0)
-                else:
-                    trm.set_scattering(1, p[0, off + self.ncloud])
-        core = np.concatenate([p[:, :self.nPT], p[:, off + self.ncloud + self.nray:]], axis=1)
+        p = np.ascontiguousarray(np.atleast_2d(np.asarray(params, np.double)))
         lo, hi = engine.local_range()
         if hi - lo != self.nwave:
             # wavenumber-sharded node: profiles on every rank, RT on the local
             # block, RCCL all-gather of the spectra, band integration on the full grid
             import torch
-            d_par = torch.from_numpy(np.ascontiguousarray(core)).cuda()
+            d_par = torch.from_numpy(p).cuda()
             band_d, status_d, _ = engine.step_batch_sharded(d_par, self.nfilters)
             torch.cuda.synchronize()
             band, status = band_d.cpu().numpy(), status_d.cpu().numpy()
         else:
-            band, status = engine.step_batch(core, self.nfilters)
+            band, status = engine.step_batch(p, self.nfilters)
         for s in status[status > 0]:
             self.nbad[int(s)] += 1
         return band

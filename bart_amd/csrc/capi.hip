@@ -361,6 +361,14 @@ int bartrt_step_batch_dev(const double *d_params, int nwalkers, int npars,
   });
 }
 
+int bartrt_step_set_extras(int nrad, int ncloud, int nray) {
+  NEED_ENGINE();
+  return guarded([&] {
+    step_set_extras(*g_eng, nrad, ncloud, nray);
+    return BARTRT_OK;
+  });
+}
+
 int bartrt_step_batch(const double *params, int nwalkers, int npars,
                       double *bandflux, int *status) {
   NEED_ENGINE();

@@ -418,6 +418,9 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.coef = d_coef; pa.idx = d_idx; pa.kstop = d_kstop;
   pa.ok = d_okp ? d_okp : d_ok;
   pa.rad_out = d_rad;
+  pa.over = prep_over_once;
+  const bool over_cloud = prep_over_cloud && (prep_over_once || prep_hook);
+  prep_over_once = nullptr;
   pa.rtop = solution == 1 ? d_rtop : nullptr;
   pa.ds = solution == 1 ? d_ds : nullptr;
   if (prep_hook) HIPCHK(prep_hook(pa, st, prep_hook_ctx));
@@ -428,7 +431,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.nwalkers = n;
   r.coef = d_coef; r.idx = d_idx; r.kstop = d_kstop;
   r.ext = d_ext;
-  r.cloud_on = has_cloud;
+  r.cloud_on = has_cloud || over_cloud;
   r.toomuch = toomuch;
   r.spec = d_spec_out;
   r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;

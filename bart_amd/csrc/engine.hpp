@@ -61,6 +61,11 @@ struct Engine {
   // fuses T(p) + abundances into the same launch, step.hip)
   hipError_t (*prep_hook)(const PrepArgs &, hipStream_t, void *) = nullptr;
   void *prep_hook_ctx = nullptr;
+  // per-walker radius / cloud / scattering overrides for the NEXT prep launch only
+  // (set by step_profiles_dev, consumed by run_chunk); prep_over_cloud: a cloud-top
+  // parameter is among them, so the RT kernels add the deck's surface term
+  const double *prep_over_once = nullptr;
+  bool prep_over_cloud = false;
   // timing of RT launches
   bool timing = false;
   std::vector<hipEvent_t> ev;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   stage2_to_lds(prep_lds_profile(sm, L), p.prof + (size_t)w * (S + 1) * L, (S + 1) * L,
                 prep_lds_consts(sm, L, S), p.consts, 2 * L + S + 2 * p.Nt + 2 * p.ncia_temps,
                 threadIdx.x, blockDim.x);
-  prep_body(p, w, sm);
+  prep_body(p, w, sm, p.over ? p.over + (size_t)3 * w : nullptr);
 }
 
 // ---------------------------------------------------------------------------

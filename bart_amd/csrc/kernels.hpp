@@ -131,6 +131,9 @@ struct PrepArgs {
   // scattering / cloud
   int scat_flag, iH2, iHe, has_cloud;
   double scat_value, cloudtop;
+  // optional per-walker overrides [nw][3]: reference radius (cm), cloud-top pressure
+  // (barye), scattering value; NaN = the engine's setting (prep_body)
+  const double *over;
   // outputs
   double *coef;            // [nw][L][coef_stride]
   idx_t *idx;              // [nw][L][idx_stride]

@@ -30,8 +30,18 @@ __device__ inline double *prep_lds_consts(double *sm, int L, int S) { return sm 
 
 // Expects the walker's profile and the constants written to LDS by this workgroup
 // (the body's first barrier makes them visible); w = walker index; 128 lanes.
-__device__ inline void prep_body(const PrepArgs &p, int w, double *sm) {
+// over3 (optional; LDS or global): this walker's own reference radius (cm), cloud-top
+// pressure (barye) and scattering value, NaN = keep the engine's setting -- the
+// radius / cloud / scattering parameters of a retrieval step (BARTfunc.py:350-360).
+__device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const double *over3) {
   const int L = p.L, S = p.S, M = p.M, C = p.C;
+  double refradius = p.refradius, cloudtop = p.cloudtop, scat_value = p.scat_value;
+  int has_cloud = p.has_cloud;
+  if (over3) {
+    if (over3[0] == over3[0]) refradius = over3[0];
+    if (over3[1] == over3[1]) { cloudtop = over3[1]; has_cloud = 1; }
+    if (over3[2] == over3[2]) scat_value = over3[2];
+  }
   double *sT = sm;           // temperature, atm order
   double *sMu = sm + L;      // mean molecular mass
   double *sR = sm + 2 * L;   // radius
@@ -56,7 +66,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm) {
   // serial (lane 0 walks down from the reference layer, lane 64 walks up).
   const double rgas = kKB / kAMU;
   {
-    const double invG = 1.0 / (p.gsurf * p.refradius * p.refradius);
+    const double invG = 1.0 / (p.gsurf * refradius * refradius);
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
       const int lu = l + 1 < L ? l + 1 : l;
       const double T = prof[l], Tu = prof[lu];
@@ -75,7 +85,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm) {
   const bool bad = sBad != 0;
   if (!bad && (threadIdx.x == 0 || threadIdx.x == 64)) {
     const int ix = p.ref_idx;
-    double r = p.refradius;
+    double r = refradius;
     if (!p.ref_exact) {
       const int b = p.ref_ib;
       const double t0 = sT[b] + p.ref_f * (sT[b + 1] - sT[b]);
@@ -159,7 +169,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm) {
     double ray = 0.0;
     if (p.scat_flag == 1 && p.iH2 >= 0) {
       const double l4 = (kRayLambda0 * kRayLambda0) * (kRayLambda0 * kRayLambda0);
-      ray = pow(10.0, p.scat_value) * kRaySigma0 * prof[(size_t)(p.iH2 + 1) * L + l] * nd * l4;
+      ray = pow(10.0, scat_value) * kRaySigma0 * prof[(size_t)(p.iH2 + 1) * L + l] * nd * l4;
     } else if (p.scat_flag == 2) {
       const double k0 = 128.0 * (kPI * kPI * kPI * kPI * kPI) / 3.0;
       if (p.iH2 >= 0) ray += kPolH2 * kPolH2 * prof[(size_t)(p.iH2 + 1) * L + l] * nd;
@@ -177,9 +187,9 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm) {
   }
   if (threadIdx.x == 0) {
     int ks = L - 1;
-    if (p.has_cloud) {
+    if (has_cloud) {
       for (int k = 0; k < L; k++)
-        if (sPress[L - 1 - k] >= p.cloudtop) { ks = k; break; }
+        if (sPress[L - 1 - k] >= cloudtop) { ks = k; break; }
     }
     p.kstop[w] = ks;
     if (p.ok) p.ok[w] = bad ? 0 : 1;

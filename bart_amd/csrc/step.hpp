@@ -13,6 +13,7 @@ struct StepArgs {
   int tint_thorngren = 0;
   double tmin = 400, tmax = 3000;
   int nmolfit = 0, nfilters = 0, solution = 0;
+  int nrad = 0, ncloud = 0, nray = 0;   // radius / cloud-top / scattering parameters after the T(p) ones
   double rprs = 0;
   int ebalance = 0;
   double e_in = 0, e_fac = 0;  // reject when trapz(spec) * e_fac > e_in
@@ -34,6 +35,7 @@ struct StepArgs {
   // workspaces
   int cap = 0;
   double *d_prof = nullptr, *d_spec = nullptr;
+  double *d_over = nullptr;             // [cap][3] per-walker overrides for prep (unfused path)
   int *d_status = nullptr;
   ~StepArgs();
 };
@@ -43,6 +45,7 @@ void step_setup(Engine &e, const double *ptargs5, int tint_thorngren, int pttype
                 const int *imol, int nfilters, const int *idx0, const int *npts,
                 const double *nifilter, const double *istarfl, double rprs, int solution);
 void step_set_ebalance(Engine &e, int on, double e_in, double e_fac);
+void step_set_extras(Engine &e, int nrad, int ncloud, int nray);
 void step_ensure(Engine &e, int n);
 // params[n][npars] -> prof[n][(S+1)][L], status[n]
 void step_profiles_dev(Engine &e, const double *d_params, int n, int npars, double *d_prof,

@@ -185,6 +185,12 @@ def step_setup(ptargs5, tmin, tmax, abund, imol, idx0, npts, nifilter, istarfl,
         _ptr(star) if star is not None else None, float(rprs), int(solution)))
 
 
+def step_set_extras(nrad: int, ncloud: int, nray: int) -> None:
+    """Radius / cloud-top / scattering parameters (0 or 1 each) sit between the T(p)
+    parameters and the abundance factors of every walker (BARTfunc.py:350-360)."""
+    _check(trm.lib().bartrt_step_set_extras(int(nrad), int(ncloud), int(nray)))
+
+
 def step_set_ebalance(on, e_in, e_fac):
     _check(trm.lib().bartrt_step_set_ebalance(int(bool(on)), float(e_in), float(e_fac)))
 

@@ -51,7 +51,7 @@ def main(argv=None):
             print(msg, flush=True)
 
     t0 = time.perf_counter()
-    native = not a.python_loop and world == 1 and not (w.ncloud or w.nray or w.nradfit)
+    native = not a.python_loop and world == 1
     res = sampler.run_native(w, scfg, log=log) if native else sampler.run(w.step, scfg, log=log)
     dt = time.perf_counter() - t0
     nmodel = res["chain"].shape[0] * res["chain"].shape[1]

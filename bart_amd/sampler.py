@@ -178,13 +178,9 @@ def run_native(worker, cfg: SamplerConfig, log=None):
     """The same sampler through ``bartrt_mcmc_run`` (csrc/mcmc.hip): the loop,
     its random draws and the chi-square in C++, one batched model call per
     iteration -- about twice the iterations per second of :func:`run` at ten
-    chains.  Needs a worker whose parameters are all batched ones (T(p) and
-    abundances: no per-call radius / cloud / scattering setters) on an unsharded
-    engine; same result dictionary as :func:`run`."""
+    chains.  Needs an unsharded engine; same result dictionary as :func:`run`."""
     import ctypes as C
     from . import engine, transit_module as trm
-    if worker.ncloud or worker.nray or worker.nradfit:
-        raise ValueError("run_native: radius / cloud / scattering parameters are per-call settings; use run()")
     lo, hi = engine.local_range()
     if hi - lo != worker.nwave:
         raise ValueError("run_native: the engine is sharded; use run()")

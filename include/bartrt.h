@@ -99,7 +99,16 @@ int bartrt_step_setup(const double *ptargs5, int tint_thorngren, int pttype,
  * trapz(spectrum, wn) * e_fac > e_in  (e_fac = 4 (Rp*100)^2). */
 int bartrt_step_set_ebalance(int on, double e_in, double e_fac);
 
-/* params[nwalkers][npars] (npars = nPT + nmolfit; nPT = 5 for "line", 1 for
+/* Declares the per-walker parameters BARTfunc places between the T(p) parameters
+ * and the abundance factors (BARTfunc.py:350-360), each 0 or 1, in this order:
+ * planet radius at the reference pressure (km; what trm.set_radius takes), log10
+ * of the cloud-top pressure (bar; trm.set_cloudtop), Rayleigh scattering value
+ * (trm.set_scattering(1, value); present but unused with the polarisability
+ * flavour, flag 2, which is set once with bartrt_set_scattering).  They then act
+ * per walker inside the batch instead of through the engine-wide setters. */
+int bartrt_step_set_extras(int nrad, int ncloud, int nray);
+
+/* params[nwalkers][npars] (npars = nPT + extras + nmolfit; nPT = 5 for "line", 1 for
  * "iso") -> bandflux[nwalkers][nfilters]; rejected walkers get -1 in every
  * band (BARTfunc.py:327-330,339-344,378-383).  status[w]: 0 ok, 1 bad
  * temperature, 2 bad abundance, 3 energy balance.  status may be NULL. */

@@ -143,3 +143,54 @@ def test_worker_transit_solution(tmp_path):
         assert np.all(b > a) and 0.012 < a.min() < a.max() < 0.03
     finally:
         w.close()
+
+
+@pytest.mark.gpu
+def test_radius_cloud_scattering_parameters_in_a_batch(tmp_path):
+    """A transit retrieval's radius, cloud-top and scattering parameters travel with
+    each walker of a batch (the reference sets them through engine-wide setters,
+    one walker per process, BARTfunc.py:350-360): a batch of six equals six
+    single-walker engines configured through the setters, and the oracle."""
+    from bart_amd import BARTfunc, engine, hostio, synthcfg, transit_module as trm
+    from oracle import pyhalf, rt_oracle as orc
+    p0 = (-2.0, 0.0, 1.0, 0.0, 0.98, 97000.0, -1.0, 1.5, -0.5)   # PT(5), radius km, log10 cloudtop bar, scattering, CH4
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=900, solution="transit", params=p0,
+                                          extra_keys=dict(TKEYS))
+    with open(cfg, "a") as f:
+        f.write("cloudtop = -1.0\nscattering = 1.5\n")
+    wc = BARTfunc.WorkerConfig.from_cfg(cfg)
+    w = BARTfunc.Worker(wc)
+    try:
+        assert (w.nradfit, w.ncloud, w.nray, w.nPT) == (1, 1, 1, 5)
+        rng = np.random.default_rng(3)
+        pars = np.array(p0) + rng.normal(0, [0.1, 0.1, 0.1, 0.02, 0.01, 800.0, 0.5, 0.3, 0.3], (6, 9))
+        pars[:, 3] = np.clip(pars[:, 3], 0, 1)
+        band = w.step(pars)
+        assert band.shape == (6, 10) and np.all(band > 0)
+        one = np.array([w.step(q)[0] for q in pars])
+        np.testing.assert_allclose(one, band, rtol=1e-12)
+        assert np.ptp(band[:, 0]) > 1e-5            # the parameters matter
+        # oracle: setters per walker
+        tep = hostio.TepFile(wc.tep_name)
+        rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+        rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+        mp = float(tep.getvalue("Mp")[0]) * hostio.Mjup
+        ptargs = [rstar, float(tep.getvalue("Ts")[0]), wc.tint, float(tep.getvalue("a")[0]) * hostio.AU,
+                  100.0 * hostio.G_NEWTON * mp / rp ** 2]
+        species, press, _, abund = hostio.readatm(wc.atmfile)
+        o = orc.OracleEngine(wc.tconfig)
+        idx0, npts, nif = [], [], []
+        for f in wc.filters:
+            fwn, ftr = hostio.readfilter(f)
+            a, _, ind = hostio.resample(o.wn, fwn, ftr, fwn, ftr)
+            idx0.append(ind[0][0]); npts.append(len(ind[0])); nif.append(a)
+        for k in (0, 3):
+            core = np.concatenate([pars[k, :5], pars[k, 8:]])
+            prof, st = pyhalf.step_profiles(core, press, abund, species, wc.molfit, ptargs, wc.Tmin, wc.Tmax)
+            assert st == 0
+            o.set_radius(pars[k, 5]); o.set_cloudtop(pars[k, 6]); o.set_scattering(1, pars[k, 7])
+            ref = pyhalf.bandflux(o.run(prof), o.wn, idx0, npts, np.concatenate(nif), np.concatenate(nif),
+                                  rp / rstar, "transit")
+            np.testing.assert_allclose(band[k], ref, rtol=1e-9)
+    finally:
+        w.close()

@@ -224,3 +224,34 @@ def test_bad_profile_flagged(small_case):
         assert np.all(np.isfinite(spec[[0, 2]]))
     finally:
         trm.free_memory()
+
+
+def test_wavelength_keys_of_the_demo_configuration(demo_case, tmp_path):
+    """The reference's demo transit configuration gives the spectral range in
+    microns (`wllow 2.0`, `wlhigh 4.0`, `wlfct 1e-4`, examples/demo/
+    transit_demo.cfg:17-24): same 2501-point grid, same spectrum as the
+    wavenumber keys."""
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = demo_case
+    keep = [l for l in open(c.tcfg).read().splitlines() if not l.startswith(("wnlow", "wnhigh"))]
+    cfg2 = str(tmp_path / "transit_wl.cfg")
+    with open(cfg2, "w") as f:
+        f.write("\n".join(keep) + "\nwllow 2.0\nwlhigh 4.0\nwlfct 1e-4\n")
+    prof = c.profiles().ravel()
+    engine.init(c.tcfg)
+    a = trm.run_transit(prof, trm.get_no_samples())
+    wn_a = trm.get_waveno_arr(trm.get_no_samples())
+    trm.free_memory()
+    engine.init(cfg2)
+    try:
+        n = trm.get_no_samples()
+        assert n == 2501
+        wn_b = trm.get_waveno_arr(n)
+        assert np.array_equal(wn_a, wn_b) and wn_b[0] == 2500.0 and wn_b[-1] == 5000.0
+        assert np.array_equal(trm.run_transit(prof, n), a)
+        o = orc.OracleEngine(cfg2)
+        assert np.array_equal(o.wn, wn_b)
+        np.testing.assert_allclose(a, o.run(prof), rtol=RTOL)
+    finally:
+        trm.free_memory()

@@ -71,6 +71,15 @@ static bool file_exists(const std::string &p) {
 
 void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   cfg = cfg_in;
+  // Keys of the reference's whitelist (code/makecfg.py:36-52) that would change
+  // the physics and are not implemented are refused, not ignored.  (Accepted
+  // without effect: verb, wnosamp, allowq, rad*, orbpars*, tauiso, outtau,
+  // taulevel, modlevel -- sampling and diagnostic controls of the CPU engine.)
+  if (cfg_has(cfg, "cloudext") && cfg_num(cfg, "cloudext", 0.0) != 0.0)
+    throw IoError{"transit cfg: the radius-ramp cloud (cloudrad / cloudfct / cloudext) is not implemented; "
+                  "use cloudtop (opaque deck at a pressure)"};
+  if (cfg_has(cfg, "transparent") && cfg["transparent"] != "0" && cfg["transparent"] != "no")
+    throw IoError{"transit cfg: 'transparent' is not implemented"};
   // An opacity file that does not exist yet is generated from the line list
   // first (what `transit --justOpacity` does, BART.py:561-565), by a
   // temporary line-by-line engine on the same configuration.

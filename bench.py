@@ -276,7 +276,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
                          "kernel": "rt_eclipse", "launches": nlaunch,
                          "avg_launch_ms": per_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg},
+                         "algorithmic_bytes_per_launch": alg,
+                         # the same launch against the bytes the PMC pass saw leave L2
+                         "traffic_GBps": traffic / per_launch_s / 1e9 if traffic else None,
+                         "traffic_frac": traffic / per_launch_s / 1e9 / PEAK_HBM_GBS if traffic else None},
         }
         if sweep:
             res["batch_sweep"] = sweep

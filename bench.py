@@ -274,7 +274,9 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
-                         "kernel": "rt_eclipse_fast<5 angles, 4 molecules, 1 CIA pair, squared 60-degree transmittance> (single-wave columns; rocprof: bartrt::rt_eclipse_fast<5, 4, 1, true>)", "launches": nlaunch,
+                         "kernel": "bartrt::rt_eclipse_fast<5, 4, 1, true> at the default 10 walkers per GPU "
+                                   "(launch_rt picks rt_eclipse_quad / _split below 9 walkers)",
+                         "launches": nlaunch,
                          "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg,
                          # the same launch against the bytes the PMC pass saw leave L2

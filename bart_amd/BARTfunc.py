@@ -279,6 +279,9 @@ def main(comm, argv=None, group=None):
     nbad = w.nbad if w is not None else None
     if w is not None:
         w.close()
+        if ngpu > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
     if verb and nbad is not None:
         print("Bad iterations of {} due to:".format("chain 0" if nworkers == 1 else "all chains"))
         print("  Temperature: {}".format(nbad[1]))

@@ -169,7 +169,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     if (!(d > 0) || !(hi_wn > lo_wn)) throw IoError{"transit cfg: bad spectral sampling"};
     long n = (long)std::floor((hi_wn - lo_wn) / d + 1e-9) + 1;
     wn_full.resize(n);
-    for (long i = 0; i < n; i++) wn_full[i] = lo_wn + d * i;
+    for (long i = 0; i < n; i++) wn_full[i] = lo_wn + d * (double)i;
     M = 0; Nt = 2; tgrid = {0.0, 1.0};
   }
   Wfull = (int)wn_full.size();

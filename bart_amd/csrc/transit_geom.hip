@@ -110,9 +110,10 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
 }
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int kMfmaTiles = 8;  // row tiles of 16 chords: L <= 128
+constexpr int kMfmaTiles = 8;      // row tiles of 16 chords: L <= 128
+constexpr int kMfmaTilesDeep = 16;  // L <= 256: twice the pair-sum registers, half the waves per SIMD
 
-template <int MT, int CT>
+template <int MT, int CT, int KT>
 __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int M = MT, C = CT;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
     }
   };
 
-  double P[4 * kMfmaTiles];  // pair sums e_{j-1} + e_j of this lane's layers j = 4 s + q
+  double P[4 * KT];  // pair sums e_{j-1} + e_j of this lane's layers j = 4 s + q
   double ecarry = 0.0;       // lanes q = 0: extinction of layer j - 1, from row q = 3 one step back
   double integ[4] = {0.0, 0.0, 0.0, 0.0};
   double gcarry[4];          // exp(-tau) r of the last chord of the previous tile
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   for (int r = 0; r < 4; r++) gcarry[r] = r_top;
 
 #pragma unroll
-  for (int kt = 0; kt < kMfmaTiles; kt++) {
+  for (int kt = 0; kt < KT; kt++) {
     const int k0 = 16 * kt;
     if (k0 > kend) break;
     // ---- extinction of the tile's 16 layers: 4 per lane row
@@ -285,7 +286,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
     return e && std::string(e) == "generic";
   }();
   const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
-  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTiles) {
+  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesDeep) {
     RtArgs b = a;
     b.ntiles = (a.W + 63) / 64;
     const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
@@ -293,7 +294,10 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
                                          (size_t)a.L * idx_stride(a.C) + (size_t)a.L);
 #define BARTRT_TRANSIT(MM, CC)                                                              \
   if (a.M == MM && a.C == CC) {                                                             \
-    hipLaunchKernelGGL((rt_transit_mfma<MM, CC>), dim3(nb), dim3(256), shm, st, b);         \
+    if (a.L <= 16 * kMfmaTiles)                                                             \
+      hipLaunchKernelGGL((rt_transit_mfma<MM, CC, kMfmaTiles>), dim3(nb), dim3(256), shm, st, b); \
+    else                                                                                    \
+      hipLaunchKernelGGL((rt_transit_mfma<MM, CC, kMfmaTilesDeep>), dim3(nb), dim3(256), shm, st, b); \
     return hipGetLastError();                                                               \
   }
     BARTRT_MC_LIST(BARTRT_TRANSIT)

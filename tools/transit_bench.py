@@ -1,5 +1,5 @@
 """Transit (transmission) geometry on the bench grid: modulation spectra/s.
-usage: python tools/transit_bench.py [walkers ...]"""
+usage: python tools/transit_bench.py [walkers ...]   (TRANSIT_LAYERS=200 for a deeper column)"""
 import json
 import os
 import sys
@@ -16,8 +16,9 @@ from bart_amd import engine, synth, transit_module as trm  # noqa: E402
 
 def main():
     batches = [int(a) for a in sys.argv[1:]] or [1, 10, 64, 256]
-    d = os.path.join(tempfile.gettempdir(), "bartrt_transitbench")
-    case = synth.make_case(d, nlayers=100, nwave=10000, reuse=True,
+    nlay = int(os.environ.get("TRANSIT_LAYERS", "100"))
+    d = os.path.join(tempfile.gettempdir(), "bartrt_transitbench%d" % nlay)
+    case = synth.make_case(d, nlayers=nlay, nwave=10000, reuse=True,
                            extra_keys={"solution": "transit", "starrad": 1.145})
     engine.init(case.tcfg)
     for n in batches:
@@ -36,7 +37,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kms, nl = engine.timing_end()
-        print(json.dumps({"workload": "transit geometry, 100 layers x 1e4 wavenumbers", "walkers": n,
+        print(json.dumps({"workload": "transit geometry, %d layers x 1e4 wavenumbers" % nlay, "walkers": n,
                           "spectra_per_s": round(n * steps / dt), "ms_per_step": round(dt / steps * 1e3, 4),
                           "rt_kernel_ms": round(kms / max(nl, 1), 4),
                           "depth_min_max": [float(out.min()), float(out.max())]}), flush=True)

@@ -4,6 +4,7 @@ from __future__ import annotations
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -32,16 +33,19 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", 
              "-Wall", "-Wno-unused-result", *os.environ.get("BARTRT_CXXFLAGS", "").split()]
-    for src in SOURCES:
+    def compile_one(src: str) -> str:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        objs.append(obj)
+        return obj
+
+    # translation units are independent: a few compilers side by side
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
     subprocess.check_call(cmd)
     # the standalone `transit` executable (C ABI only), found next to the library

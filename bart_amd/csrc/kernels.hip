@@ -602,6 +602,15 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
 
 template <int AT, int MT, int CT>
 static hipError_t launch_rt_t(const RtArgs &a, int block, int nblocks, size_t sh, hipStream_t st) {
+  // layer records above the 64 kB default (deep columns, many molecules): opt in once
+  static size_t allowed = 64 * 1024;
+  if (sh > allowed) {
+    if (sh > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_eclipse<AT, MT, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return e;
+    allowed = sh;
+  }
   hipLaunchKernelGGL((rt_eclipse<AT, MT, CT>), dim3(nblocks), dim3(block), sh, st, a);
   return hipGetLastError();
 }
@@ -643,7 +652,8 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
   // (the specialised kernels rebuild their buffer descriptor per layer, so the
   // table may be of any size; one layer's pair of planes must stay below 4 GB)
   const bool plane_ok = 2ull * a.M * a.W * 8ull < (1ull << 31);
-  if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && plane_ok) {
+  if (kmode != "generic" && a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && plane_ok &&
+      sh <= 55 * 1024) {  // (the producer/consumer kernel adds 9 kB of its own)
     RtArgs b = a;
     const bool sq = allow_sq && order_angles_for_square(b);
     // too few single-wave columns to load the 1 024 SIMDs evenly -> several

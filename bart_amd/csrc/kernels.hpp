@@ -4,7 +4,8 @@
 
 // (molecules, CIA pairs) the specialised kernels are instantiated for
 #define BARTRT_MC_LIST(X) \
-  X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(5, 1) X(6, 1)
+  X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) \
+  X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2) X(7, 1) X(7, 2) X(8, 1) X(8, 2)
 
 namespace bartrt {
 

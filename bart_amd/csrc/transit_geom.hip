@@ -33,6 +33,10 @@
 
 namespace bartrt {
 
+// STAGE: the walker's layer records are copied to LDS in front of the pair sums;
+// without it (deep columns with many molecules, where both do not fit) they are
+// read from global memory where they lie.
+template <bool STAGE>
 __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   extern __shared__ double smem[];
   const int M = p.M, C = p.C, L = p.L, W = p.W;
@@ -43,16 +47,20 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   const int tile = (jb / p.nwalkers) * 8 + xcd;
   if (tile >= p.ntiles) return;
 
-  double *sC = smem;
-  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
-  // pair sums, [L][64], after the offset records
-  double *sP = smem + (size_t)L * NC + (size_t)L * NI;
-  {
-    const double *gC = p.coef + (size_t)w * L * NC;
-    const idx_t *gI = p.idx + (size_t)w * L * NI;
-    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, 64);
+  const double *gC = p.coef + (size_t)w * L * NC;
+  const idx_t *gI = p.idx + (size_t)w * L * NI;
+  const size_t nrec = STAGE ? (size_t)L * NC + (size_t)L * NI : 0;
+  double *sP = smem + nrec;  // pair sums, [L][64], after the records
+  const double *sC = gC;
+  const idx_t *sI = gI;
+  if constexpr (STAGE) {
+    double *lC = smem;
+    idx_t *lI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+    stage2_to_lds(lC, gC, L * NC, lI, gI, L * NI, threadIdx.x, 64);
+    __syncthreads();
+    sC = lC;
+    sI = lI;
   }
-  __syncthreads();
 
   const int i = tile * 64 + threadIdx.x;
   const bool valid = i < W;
@@ -280,7 +288,8 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
                                       (size_t)a.L * idx_stride(a.C) + (size_t)a.L * 64);
-  if (sh > 160 * 1024) return hipErrorInvalidValue;
+  const size_t sh_pairs = sizeof(double) * (size_t)a.L * 64;
+  if (sh_pairs > 160 * 1024) return hipErrorInvalidValue;  // more than 320 layers
   static const bool generic_only = [] {
     const char *e = std::getenv("BARTRT_KERNEL");
     return e && std::string(e) == "generic";
@@ -303,10 +312,16 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
     BARTRT_MC_LIST(BARTRT_TRANSIT)
 #undef BARTRT_TRANSIT
   }
-  static size_t allowed = 48 * 1024;
-  hipError_t e = allow_lds(rt_transit, sh, allowed);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(rt_transit, dim3(nblocks), dim3(64), sh, st, a);
+  static size_t allowed = 48 * 1024, allowed_pairs = 48 * 1024;
+  if (sh <= 160 * 1024) {
+    hipError_t e = allow_lds(rt_transit<true>, sh, allowed);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rt_transit<true>, dim3(nblocks), dim3(64), sh, st, a);
+  } else {
+    hipError_t e = allow_lds(rt_transit<false>, sh_pairs, allowed_pairs);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rt_transit<false>, dim3(nblocks), dim3(64), sh_pairs, st, a);
+  }
   return hipGetLastError();
 }
 

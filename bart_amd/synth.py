@@ -241,17 +241,21 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
     if len(opmol) and write:
         write_opacity(p("opacity.dat"), ids, tgrid, press * 1e6, wn,
                       plane_fn=lambda l: kappa_layer(seed, l, L, tgrid, len(opmol), wn, press[l]))
+    # cia: False / True (H2-H2) / number of pairs (H2-H2, H2-He, H2-CH4), each file
+    # with its own temperature and wavenumber sampling
     cia_files = []
-    if cia:
-        rng = np.random.default_rng(seed + 1)
-        ct = np.arange(400.0, 3000.1, 200.0)
-        cw = np.arange(wn[0] - 20.0, wn[-1] + 20.1, 10.0)
-        base = 1e-7 * np.exp(-((cw - 0.4 * (wn[0] + wn[-1])) / (0.6 * (wn[-1] - wn[0]))) ** 2)
+    pairs = (("H2", "H2"), ("H2", "He"), ("H2", "CH4"))[:int(cia)]
+    rng = np.random.default_rng(seed + 1)
+    for n, (s1, s2) in enumerate(pairs):
+        ct = np.arange(400.0, 3000.1, 200.0 + 150.0 * n)
+        cw = np.arange(wn[0] - 20.0, wn[-1] + 20.1 + 3.0 * n, 10.0 + 3.0 * n)
+        base = 1e-7 / (1 + 2 * n) * np.exp(-((cw - (0.4 + 0.15 * n) * (wn[0] + wn[-1]))
+                                             / (0.6 * (wn[-1] - wn[0]))) ** 2)
         al = base[None, :] * (1.0 + 0.3 * (ct[:, None] - 400.0) / 2600.0) \
             * np.exp(0.2 * rng.normal(size=(1, len(cw))))
         if write:
-            write_cia(p("CIA_H2H2.dat"), "H2", "H2", ct, cw, al)
-        cia_files.append(p("CIA_H2H2.dat"))
+            write_cia(p("CIA_%s%s.dat" % (s1, s2)), s1, s2, ct, cw, al)
+        cia_files.append(p("CIA_%s%s.dat" % (s1, s2)))
     keys = {
         "atm": p("synth.atm"),
         "molfile": p("molecules.dat"),

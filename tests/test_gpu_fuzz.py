@@ -11,7 +11,7 @@ RTOL = 1e-10
 MOLS = ("H2O", "CO", "CO2", "CH4")
 
 
-def _draw(rng):
+def _draw(rng, wide=False):
     kw = {}
     kw["nlayers"] = int(rng.choice([5, 13, 26, 40, 100, 117, 209, 230]))
     kw["nwave"] = int(rng.choice([2, 17, 64, 65, 200, 641, 1500, 4100]))
@@ -21,6 +21,12 @@ def _draw(rng):
     nm = int(rng.integers(0, 5))
     kw["opmol"] = tuple(rng.choice(MOLS, size=nm, replace=False)) if nm else ()
     kw["cia"] = bool(rng.integers(0, 2)) or nm == 0
+    if wide:                      # up to nine table molecules, up to three CIA pairs
+        from test_gpu_parity import many_molecules
+        nm = int(rng.integers(1, 10))
+        kw.update(many_molecules(nm), cia=int(rng.integers(0, 4 if nm >= 4 else 3)))   # the third pair is H2-CH4
+        if kw["nwave"] < 1500:
+            kw.update(tlow=400.0, thigh=3000.0, tempdelt=650.0)
     kw["raygrid"] = [(0, 20, 40, 60, 80), (0, 30, 60), (10, 35, 50, 65, 85), (0, 15, 30, 45, 60, 75),
                      (0, 20, 40, 60, 80)][int(rng.integers(0, 5))]
     kw["toomuch"] = float(rng.choice([0.5, 10.0, 20.0, 1e30]))
@@ -32,13 +38,13 @@ def _draw(rng):
     return kw, geometry, nwalk, cloud
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(72))
 def test_random_configuration(tmp_path, seed):
     from bart_amd import engine, synth, transit_module as trm
     from oracle import rt_oracle as orc
     from test_gpu_parity import walkers
     rng = np.random.default_rng(1000 + seed)
-    kw, geometry, nwalk, cloud = _draw(rng)
+    kw, geometry, nwalk, cloud = _draw(rng, wide=seed >= 48)   # seeds 0-47 keep their draws
     c = synth.make_case(str(tmp_path), **kw)
     engine.init(c.tcfg)
     try:

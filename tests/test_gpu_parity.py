@@ -94,6 +94,12 @@ def test_demo_shape_one_molecule(demo_case):
         trm.free_memory()
 
 
+def many_molecules(nm):
+    """Keyword arguments of synth.make_case for nm table molecules."""
+    mols = ("H2O", "CO", "CO2", "CH4", "NH3", "HCN", "C2H2", "TiO", "VO")[:nm]
+    return dict(opmol=mols, species=("He", "H2") + mols, abund=(0.15, 0.85) + (1e-4,) * nm)
+
+
 @pytest.mark.parametrize("kw", [
     dict(opmol=("H2O", "CO"), cia=False),                       # specialised kernel, no CIA
     dict(opmol=("H2O", "CO", "CH4"), raygrid=(0, 30, 60)),      # generic kernel, 3 angles
@@ -101,12 +107,23 @@ def test_demo_shape_one_molecule(demo_case):
     dict(opmol=("H2O",), raygrid=(0, 10, 20, 30, 40, 50, 60, 70, 80)),
     dict(nlayers=37, nwave=100, toomuch=1e30),                  # ragged sizes, no early exit
     dict(nlayers=150, nwave=65),
+    dict(cia=2),                                                # H2-H2 + H2-He, BART's usual pair
+    dict(cia=3),                                                # three pairs: generic kernel
+    dict(opmol=("H2O",), cia=2),
+    dict(many=5, cia=2), dict(many=6, cia=0), dict(many=7, cia=1), dict(many=8, cia=2),
+    dict(many=9, cia=2),                                        # nine table molecules: generic kernel
+    dict(many=9, cia=3, nlayers=300, nwave=90),                 # layer records above 64 kB of LDS
+    dict(many=8, cia=2, nlayers=300, nwave=90),                 # ... where a specialised kernel exists
+    dict(many=9, cia=3, nlayers=300, nwave=90, extra_keys={"solution": "transit", "starrad": 1.145}),
+    dict(many=2, cia=1, nlayers=320, nwave=70, extra_keys={"solution": "transit", "starrad": 1.145}),
 ])
 def test_kernel_variants_match_oracle(tmp_path, kw):
     from bart_amd import engine, synth, transit_module as trm
     from oracle import rt_oracle as orc
     kw = dict(kw)
     kw.setdefault("nwave", 333)
+    if "many" in kw:
+        kw.update(many_molecules(kw.pop("many")), tlow=400.0, thigh=3000.0, tempdelt=650.0)
     c = synth.make_case(str(tmp_path), **kw)
     engine.init(c.tcfg)
     try:
@@ -118,15 +135,25 @@ def test_kernel_variants_match_oracle(tmp_path, kw):
         trm.free_memory()
 
 
+@pytest.fixture(scope="module")
+def wide_cases(tmp_path_factory):
+    """Six table molecules with BART's usual two CIA pairs, eight with two."""
+    from bart_amd import synth
+    return {nm: synth.make_case(str(tmp_path_factory.mktemp("case_wide%d" % nm)), nlayers=61, nwave=300,
+                                cia=2, tlow=400.0, thigh=3000.0, tempdelt=650.0, **many_molecules(nm))
+            for nm in (6, 8)}
+
+
+@pytest.mark.parametrize("shape", ["4mol_1cia", "6mol_2cia", "8mol_2cia"])
 @pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad", "octo"])
-def test_every_kernel_variant_matches_oracle(small_case, mode):
+def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode, shape):
     """The RT kernels (generic fallback, single-wave specialised, producer/consumer
     split, quad-layer with four and with eight lane rows) on the same batch, without and with an opaque cloud
     deck (its surface term takes a different route in each kernel).
     BARTRT_KERNEL is read once per process, so each variant runs in a child."""
     import subprocess, sys, os
     from oracle import rt_oracle as orc
-    c = small_case
+    c = small_case if shape == "4mol_1cia" else wide_cases[int(shape[0])]
     profs = walkers(c, 5, seed=8)
     np.save(os.path.join(c.dir, "p.npy"), profs)
     out = os.path.join(c.dir, "s_%s.npy" % mode)

@@ -109,6 +109,41 @@ def test_worker_batched_step_and_ebalance(tmp_path):
         w.close()
 
 
+@pytest.mark.gpu
+def test_worker_six_fitted_molecules_two_cia_pairs(tmp_path):
+    """The shape of a fuller retrieval: six table molecules, all fitted, H2-H2 and
+    H2-He CIA; a batch through Worker.step against the independent chain."""
+    from bart_amd import BARTfunc, synthcfg, hostio
+    from oracle import rt_oracle as orc, pyhalf
+    from test_gpu_parity import many_molecules
+    kw = many_molecules(6)
+    base = (-2.0, 0.0, 1.0, 0.0, 0.98) + (0.0,) * 6
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=900, molfit=kw["opmol"], params=base,
+                                          cia=2, tlow=400.0, thigh=3000.0, tempdelt=650.0, **kw)
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        rng = np.random.default_rng(5)
+        p = np.array(base) + np.concatenate([0.05 * rng.normal(size=(7, 5)),
+                                             rng.uniform(-1.5, 1.0, size=(7, 6))], axis=1)
+        band = w.step(p)
+        wc = w.cfg
+        tep = hostio.TepFile(wc.tep_name)
+        rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+        mp = float(tep.getvalue("Mp")[0]) * hostio.Mjup
+        ptargs = [w.rstar, w.tstar, 100.0, w.sma, 100.0 * hostio.G_NEWTON * mp / rp ** 2]
+        species, press, _, abund = hostio.readatm(wc.atmfile)
+        o = orc.OracleEngine(wc.tconfig)
+        idx0, npts, nif, ist = w.windows
+        for par, got in zip(p, band):
+            prof, st = pyhalf.step_profiles(par, press, abund, species, list(kw["opmol"]), ptargs,
+                                            400.0, 3000.0)
+            assert st == 0
+            ref = pyhalf.bandflux(o.run(prof), o.wn, idx0, npts, nif, ist, rp / w.rstar)
+            np.testing.assert_allclose(got, ref, rtol=1e-9)
+    finally:
+        w.close()
+
+
 class FakeGroup:
     """The workers' own communicator (MPI.COMM_WORLD of the processes MC3
     spawns), shared-memory version for worker threads."""

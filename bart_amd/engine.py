@@ -168,6 +168,67 @@ def allgather_blocks(local, group=None, total=None, async_op=False, out=None):
     return (work, finish) if async_op else finish()
 
 
+class GatherPipeline:
+    """Bucketed, double-buffered all-gather of per-step wavenumber blocks.
+
+    Each step writes its local block spec[nwalkers, W_r] into ``slot(i)``; every
+    ``group`` steps one collective carries the whole bucket (fewer, larger
+    transfers over xGMI, and one cross-stream wait per bucket instead of one per
+    step on the compute stream), issued asynchronously on RCCL's stream while the
+    next bucket's kernels run.  ``submit(i)`` returns the reassembled spectra
+    [steps, nwalkers, W] of the bucket whose buffers step i+1 is about to reuse (or
+    None); ``drain()`` flushes what is still in flight."""
+
+    def __init__(self, nwalkers, wlocal, total, steps_per_bucket, device, pg=None, dtype=None):
+        import torch
+        import torch.distributed as dist
+        self.n, self.wl, self.total, self.G, self.pg = nwalkers, wlocal, total, max(1, steps_per_bucket), pg
+        world = dist.get_world_size(pg)
+        wmax = max(total * (r + 1) // world - total * r // world for r in range(world))
+        dtype = dtype or torch.float64
+        self.local = [torch.empty((self.G, nwalkers, wlocal), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.empty((world * self.G * nwalkers, wmax), dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [None, None]      # per buffer: (finish, steps it holds)
+        self.filled = 0                  # steps written into the open bucket
+
+    def slot(self, i):
+        """Where step i's kernels write; first finishes the bucket that used these buffers."""
+        b, k = (i // self.G) & 1, i % self.G
+        done = None
+        if k == 0:
+            done = self._finish(b)
+        self._done = done
+        return self.local[b][k]
+
+    def submit(self, i):
+        b, k = (i // self.G) & 1, i % self.G
+        self.filled = k + 1
+        if k == self.G - 1:
+            self._issue(b)
+        return self._done
+
+    def _issue(self, b):
+        _, fin = allgather_blocks(self.local[b].view(self.G * self.n, self.wl), self.pg, total=self.total,
+                                  async_op=True, out=self.recv[b])
+        self.pending[b] = (fin, self.filled)
+        self.filled = 0
+
+    def _finish(self, b):
+        if self.pending[b] is None:
+            return None
+        fin, k = self.pending[b]
+        self.pending[b] = None
+        return fin().view(self.G, self.n, self.total)[:k]
+
+    def drain(self, last_step):
+        """After the last submit(last_step): returns the remaining buckets in step order."""
+        b = (last_step // self.G) & 1
+        if self.filled:
+            self._issue(b)               # a partly filled bucket travels whole; only its filled steps are returned
+        outs = [self._finish(1 - b), self._finish(b)]
+        return [o for o in outs if o is not None]
+
+
 # ---- per-step converters --------------------------------------------------
 def step_setup(ptargs5, tmin, tmax, abund, imol, idx0, npts, nifilter, istarfl,
                rprs, solution=0, pttype=0, tint_thorngren=False):

@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--sweep", default="64,256,1024",
                     help="extra batch sizes reported under batch_sweep (N=1 only; '' = none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--gather-steps", type=int, default=8,
+                    help="N > 1: steps per all-gather bucket (fewer, larger collectives)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)
@@ -177,37 +179,29 @@ def main():
         nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
         profs_h = make_profiles(case, nwalk * nsets, seed=20260103).reshape(nsets, nwalk, -1)
         d_prof = torch.from_numpy(profs_h).to(dev)
-        # two sets of buffers: on N > 1 the all-gather of step i runs on RCCL's
-        # stream while the kernels of step i+1 run on the compute stream
+        # N > 1: the steps' local blocks go into bucket slots; one all-gather per
+        # bucket runs on RCCL's stream while the next bucket's kernels run on the
+        # compute stream (engine.GatherPipeline)
         d_local = [torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev) for _ in range(2)]
-        wmax = -(-a.nwave // world)           # largest block of the integer split
-        recv = [torch.empty((world * nwalk, wmax), dtype=torch.float64, device=dev)
-                for _ in range(2)] if use_dist else None
-        pending = [None, None]
+        pipe = engine.GatherPipeline(nwalk, hi - lo, a.nwave, a.gather_steps, dev) if use_dist else None
 
         def step(i):
-            b = i & 1
-            out_prev = None
-            if use_dist and pending[b] is not None:
-                out_prev = pending[b]()              # spectra of step i-2, reassembled
-                pending[b] = None
-            engine.run_batch_dev(d_prof[i % nsets], d_local[b])
-            if use_dist:
-                _, pending[b] = engine.allgather_blocks(d_local[b], total=a.nwave, async_op=True,
-                                                        out=recv[b])
-                return out_prev
-            return d_local[b]
+            if not use_dist:
+                engine.run_batch_dev(d_prof[i % nsets], d_local[i & 1])
+                return d_local[i & 1]
+            engine.run_batch_dev(d_prof[i % nsets], pipe.slot(i))
+            done = pipe.submit(i)            # reassembled spectra of an earlier bucket, or None
+            return done[-1] if done is not None else None
 
-        def drain():
-            outs = [f() for f in pending if f is not None]
-            pending[0] = pending[1] = None
-            return outs
+        def drain(last):
+            outs = pipe.drain(last)
+            return [outs[-1][-1]] if outs else []
 
         out = None
         for i in range(warmup):
             out = step(i)
-        if use_dist:
-            out = (drain() or [out])[-1]
+        if use_dist and warmup:
+            out = (drain(warmup - 1) or [out])[-1]
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -219,7 +213,7 @@ def main():
             o = step(i)
             out = o if o is not None else out
         if use_dist:
-            out = (drain() or [out])[-1]
+            out = (drain(steps - 1) or [out])[-1]
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

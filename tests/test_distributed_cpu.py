@@ -38,22 +38,22 @@ WORKER = textwrap.dedent("""
     assert torch.equal(out, full)
     out2 = engine.allgather_blocks(local, total=W)      # static sizes: one collective
     assert torch.equal(out2, full)
-    # bench.py's N > 1 step loop: asynchronous gathers into two receive buffers,
-    # each finished two steps later
-    wmax = -(-W // world)
-    recv = [torch.empty((world * n, wmax), dtype=torch.float64) for _ in range(2)]
-    pending, done = [None, None], []
-    for i in range(6):
-        b = i & 1
-        if pending[b] is not None:
-            done.append(pending[b]())
-            pending[b] = None
-        local_i = (full * (i + 1))[:, lo:hi].contiguous()
-        _, pending[b] = engine.allgather_blocks(local_i, total=W, async_op=True, out=recv[b])
-    done += [f() for f in pending if f is not None]
-    assert len(done) == 6
-    for i, o in enumerate(done):
-        assert torch.equal(o, full * (i + 1)), i
+    # bench.py's N > 1 step loop: steps write into bucket slots, one asynchronous
+    # gather per bucket into one of two receive buffers, finished when the buffers
+    # come round again; 7 steps leave a partly filled bucket for drain()
+    for G in (1, 3, 4):
+        pipe = engine.GatherPipeline(n, hi - lo, W, G, "cpu")
+        done = []
+        for i in range(7):
+            pipe.slot(i).copy_((full * (i + 1))[:, lo:hi])
+            o = pipe.submit(i)
+            if o is not None:
+                done += [x.clone() for x in o]
+        for o in pipe.drain(6):
+            done += list(o)
+        assert len(done) == 7, (G, len(done))
+        for i, o in enumerate(done):
+            assert torch.equal(o, full * (i + 1)), (G, i)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert abs(t.item() - 0.1 * world) < 1e-12

@@ -472,13 +472,18 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 
   // per-lane table addressing: plane offset of the lane's layer + row + lane
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
   const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
   const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
   auto load_layer = [&](int j, double (&r)[NR]) {
     const idx_t *ix = sI + j * NI;
     if (M > 0) {
-      const unsigned po = (unsigned)ix[0] + off;
+      const idx_t mine = ix[0];
+      const long long base = p.window ? row_window_base<R>(mine) : 0ll;
+      const unsigned long long left = p.kappa_bytes - (unsigned long long)base;
+      const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.kappa) + base), 0,
+          (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+      const unsigned po = (unsigned)(mine - base) + off;
 #pragma unroll
       for (int mm = 0; mm < M; mm++) {
         r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
@@ -645,6 +650,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split | lp (A/B runs)
     return std::string(e ? e : "");
   }();
+  static const bool force_window = std::getenv("BARTRT_WINDOW") != nullptr;  // windowed addressing on any grid (tests)
   static const bool allow_sq = [] {
     const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
     return !(e && e[0] == '0');
@@ -663,10 +669,12 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st) {
     const int ntiles64 = (a.W + 63) / 64;
     const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
     // the quad-layer kernel addresses the tables with per-lane 32-bit offsets
-    const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
+    // (a grid of 4 GB or more through a window that moves with the step's layers)
+    const bool octo = kmode == "octo" || (kmode.empty() && columns <= kOctoMaxColumns);
+    b.window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
+    const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, octo ? 8 : 4));
     if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
       // the smallest launches take eight layers per step (8 wavenumbers per wave)
-      const bool octo = kmode == "octo" || (kmode.empty() && columns <= kOctoMaxColumns);
       b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;
       const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
 #define BARTRT_QUAD(MM, CC)                                                                                  \

@@ -155,6 +155,7 @@ struct RtArgs {
   const double *kappa;     // [L][Nt][M][W]
   const double *cia;       // [planes][W]
   unsigned long long kappa_bytes, cia_bytes;  // extents of the two tables
+  int window;              // table of 4 GB or more: row-per-layer kernels address it through a moving window
   const double *ext;       // optional line-by-line extinction [nw][L][W] (atm layer order)
   const double *wn;        // [W]
   const double *coef;
@@ -310,5 +311,31 @@ struct TableLoader {
     }
   }
 };
+
+// Kernels whose lane rows work on different layers (ROWS rows of 64 / ROWS lanes)
+// address the opacity grid with per-lane 32-bit offsets.  For a grid of 4 GB or
+// more the descriptor is rebuilt per step around the smallest plane offset among
+// the rows' layers (the layers of a step are adjacent, so the window spans a few
+// layer slabs; launch_* checks that it stays below 4 GB) and the lane offsets are
+// taken relative to it.  `mine`: the plane offset of this lane's layer.
+template <int ROWS>
+__device__ __forceinline__ long long row_window_base(idx_t mine) {
+  const int lo = (int)(unsigned)mine, hi = (int)(unsigned)((unsigned long long)mine >> 32);
+  long long best = 0;
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, r * (64 / ROWS));
+    const unsigned h = (unsigned)__builtin_amdgcn_readlane(hi, r * (64 / ROWS));
+    const long long v = (long long)(((unsigned long long)h << 32) | l);
+    best = (r == 0 || v < best) ? v : best;
+  }
+  return best;
+}
+
+// can the rows of a step (ROWS adjacent layers) be reached from one window?
+inline bool window_fits(const RtArgs &a, int rows) {
+  const unsigned long long slab = (unsigned long long)a.Nt * a.M * a.W * 8ull;
+  return (rows + 1) * slab < (1ull << 32);
+}
 
 }  // namespace bartrt

@@ -154,13 +154,18 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
 
   // table loads: per-lane byte offset = plane offset of the lane's layer + row + lane
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.kappa), 0, (int)p.kappa_bytes, 0x00020000);
   const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
   const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
   auto load_layer = [&](int j, double (&r)[NR]) {
     const idx_t *ix = sI + j * NI;
     if (M > 0) {
-      const unsigned po = (unsigned)ix[0] + off;
+      const idx_t mine = ix[0];
+      const long long base = p.window ? row_window_base<4>(mine) : 0ll;
+      const unsigned long long left = p.kappa_bytes - (unsigned long long)base;
+      const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.kappa) + base), 0,
+          (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+      const unsigned po = (unsigned)(mine - base) + off;
 #pragma unroll
       for (int mm = 0; mm < M; mm++) {
         r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
@@ -294,9 +299,12 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
     const char *e = std::getenv("BARTRT_KERNEL");
     return e && std::string(e) == "generic";
   }();
-  const bool fits32 = a.kappa_bytes < (1ull << 32) - 4096 && a.cia_bytes < (1ull << 32) - 4096;
+  static const bool force_window = std::getenv("BARTRT_WINDOW") != nullptr;  // (tests)
+  const bool window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
+  const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!window || window_fits(a, 4));
   if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesDeep) {
     RtArgs b = a;
+    b.window = window;
     b.ntiles = (a.W + 63) / 64;
     const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
     const size_t shm = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +

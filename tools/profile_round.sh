@@ -16,7 +16,12 @@ rocprofv3 --kernel-trace --stats -d "$out/stats_w256" --output-format csv -- pyt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_calib" --output-format csv -- python3 "$root/tools/pmc_calib.py" > "$out/pmc_calib.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_transit" --output-format csv -- python3 "$root/tools/transit_bench.py" 10 256 > "$out/stats_transit.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_6mol2cia" --output-format csv -- python3 "$root/tools/shape_bench.py" 1 10 256 > "$out/stats_6mol2cia.log" 2>&1
 cd "$root"
+python3 tools/collect_profiles.py "${tag}_transit" "$out/stats_transit"
+python3 tools/collect_profiles.py "${tag}_6mol2cia" "$out/stats_6mol2cia"
+cp "$out/stats_transit.log" "profiles/${tag}_transit_bench.jsonl"; cp "$out/stats_6mol2cia.log" "profiles/${tag}_6mol2cia_bench.jsonl"
 python3 tools/collect_profiles.py "${tag}_w10" "$out/stats_w10" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_calib"
 python3 tools/collect_profiles.py "${tag}_w1" "$out/stats_w1"
 python3 tools/collect_profiles.py "${tag}_w256" "$out/stats_w256"

@@ -1,5 +1,6 @@
 // extern "C" boundary of libbartrt.so (include/bartrt.h).
 #include <cstring>
+#include <stdexcept>
 #include <string>
 
 #include "../../include/bartrt.h"
@@ -168,7 +169,13 @@ int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
     const size_t off = nwave == Wl ? 0 : (size_t)e->lo;
     for (int w = 0; w < nwalkers; w++)
       std::memcpy(spec + (size_t)w * nwave + off, hs + (size_t)w * Wl, sizeof(double) * Wl);
-    if (ok) std::memcpy(ok, hok, nwalkers);
+    if (ok) {
+      std::memcpy(ok, hok, nwalkers);
+    } else {
+      // no flag array to report through (the reference-shaped single call): refuse loudly
+      for (int w = 0; w < nwalkers; w++)
+        if (!hok[w]) throw std::invalid_argument("run_transit: the profile holds a non-finite or non-positive temperature");
+    }
     return BARTRT_OK;
   });
 }

@@ -64,8 +64,9 @@ int bartrt_free_memory(void);
 /* ---- batched / device-resident variants (same arithmetic) ------------- */
 
 /* nwalkers profiles -> nwalkers spectra; ok[w] = 0 marks a profile the
- * engine cannot evaluate (non-finite or non-positive temperature).  ok may
- * be NULL.  spec is [nwalkers][nwave_local]. */
+ * engine cannot evaluate (non-finite or non-positive temperature).  With
+ * ok == NULL (and through bartrt_run_transit) such a profile is an error
+ * (BARTRT_EINVAL) instead.  spec is [nwalkers][nwave_local]. */
 int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
                              double *spec, int nwave, unsigned char *ok);
 

@@ -144,35 +144,37 @@ def wide_cases(tmp_path_factory):
             for nm in (6, 8)}
 
 
-@pytest.mark.parametrize("shape", ["4mol_1cia", "6mol_2cia", "8mol_2cia"])
 @pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad", "octo"])
-def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode, shape):
+def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode):
     """The RT kernels (generic fallback, single-wave specialised, producer/consumer
-    split, quad-layer with four and with eight lane rows) on the same batch, without and with an opaque cloud
-    deck (its surface term takes a different route in each kernel).
+    split, quad-layer with four and with eight lane rows) on the same batches --
+    four molecules + one CIA pair, six + two, eight + two -- without and with an
+    opaque cloud deck (its surface term takes a different route in each kernel).
     BARTRT_KERNEL is read once per process, so each variant runs in a child."""
     import subprocess, sys, os
     from oracle import rt_oracle as orc
-    c = small_case if shape == "4mol_1cia" else wide_cases[int(shape[0])]
-    profs = walkers(c, 5, seed=8)
-    np.save(os.path.join(c.dir, "p.npy"), profs)
-    out = os.path.join(c.dir, "s_%s.npy" % mode)
+    cases = [small_case, wide_cases[6], wide_cases[8]]
+    jobs = []
+    for c in cases:
+        profs = walkers(c, 5, seed=8)
+        np.save(os.path.join(c.dir, "p.npy"), profs)
+        jobs.append((os.path.join(c.dir, "p.npy"), c.tcfg, os.path.join(c.dir, "s_%s.npy" % mode)))
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
             "from bart_amd import engine, transit_module as trm\n"
-            "p = np.load(%r); engine.init(%r); a = engine.run_batch(p)\n"
-            "trm.set_cloudtop(-1.0); b = engine.run_batch(p)\n"
-            "np.save(%r, np.array([a, b])); trm.free_memory()\n"
-            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-               os.path.join(c.dir, "p.npy"), c.tcfg, out))
+            "for pfile, tcfg, out in %r:\n"
+            "    p = np.load(pfile); engine.init(tcfg); a = engine.run_batch(p)\n"
+            "    trm.set_cloudtop(-1.0); b = engine.run_batch(p)\n"
+            "    np.save(out, np.array([a, b])); trm.free_memory()\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), jobs))
     subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_KERNEL=mode),
                           timeout=600)
-    got = np.load(out)
-    o = orc.OracleEngine(c.tcfg)
-    np.testing.assert_allclose(got[0], o.run_batch(profs), rtol=RTOL)
-    o.set_cloudtop(-1.0)
-    ref = o.run_batch(profs)
-    np.testing.assert_allclose(got[1], ref, rtol=RTOL)
-    assert not np.allclose(got[0], got[1])
+    for c, (pfile, _, out) in zip(cases, jobs):
+        profs, got = np.load(pfile), np.load(out)
+        o = orc.OracleEngine(c.tcfg)
+        np.testing.assert_allclose(got[0], o.run_batch(profs), rtol=RTOL)
+        o.set_cloudtop(-1.0)
+        np.testing.assert_allclose(got[1], o.run_batch(profs), rtol=RTOL)
+        assert not np.allclose(got[0], got[1])
 
 
 @pytest.mark.parametrize("nlayers", [3, 4, 5, 13, 100, 209])

@@ -164,6 +164,53 @@ def test_full_step_against_oracle_chain(demo_case, wg, ptg):
         trm.free_memory()
 
 
+def test_sharded_step_equals_unsharded(demo_case, wg, ptg):
+    """engine.step_batch_sharded minus the collective, on one GPU: each of three
+    wavenumber-block engines in turn builds the profiles and evaluates its block;
+    the concatenated blocks go through the band integration of a sharded engine
+    and give the unsharded step's band fluxes."""
+    import torch
+    import ctypes as C
+    from bart_amd import engine, transit_module as trm
+    c = demo_case
+    params = np.array([[-2.0, 0.0, 1.0, 0.0, 0.98, -0.5],
+                       [-2.3, -0.4, 0.6, 0.3, 0.9, 0.4],
+                       [-1.8, 0.2, 0.1, 0.7, 5.0, -1.7],      # rejected: T(p) above Tmax
+                       [-1.8, 0.2, 0.1, 0.7, 1.0, -1.7]])
+    _setup_demo(c, wg, ptg)
+    try:
+        band0, status0 = engine.step_batch(params, 10)
+        assert list(status0) == [0, 0, 1, 0]
+    finally:
+        trm.free_memory()
+    d_par = torch.from_numpy(params).cuda()
+    n, world, blocks = len(params), 3, []
+    for r in range(world):
+        engine.init(c.tcfg, shard=(r, world))
+        try:
+            imol = [c.species.index("CH4")]
+            engine.step_setup(ptg["line_args"], 400.0, 3000.0, c.abund0, imol, wg["demo_idx0"],
+                              wg["demo_npts"], wg["demo_nifilter"], wg["demo_istarfl"], float(wg["rprs"]))
+            prof = torch.empty((n, engine.nprof()), dtype=torch.float64, device="cuda")
+            status = torch.empty(n, dtype=torch.int32, device="cuda")
+            trm.check(trm.lib().bartrt_step_profiles_dev(
+                C.c_void_p(d_par.data_ptr()), n, params.shape[1], C.c_void_p(prof.data_ptr()),
+                C.c_void_p(status.data_ptr()), None))
+            blocks.append(engine.run_batch_dev(prof).clone())
+            if r == world - 1:
+                spec = torch.cat(blocks, dim=1).contiguous()
+                assert spec.shape == (n, trm.get_no_samples())
+                band = torch.empty((n, 10), dtype=torch.float64, device="cuda")
+                trm.check(trm.lib().bartrt_step_bandflux_dev(
+                    C.c_void_p(spec.data_ptr()), n, C.c_void_p(status.data_ptr()),
+                    C.c_void_p(band.data_ptr()), None))
+                torch.cuda.synchronize()
+                assert np.array_equal(status.cpu().numpy(), status0)
+                np.testing.assert_allclose(band.cpu().numpy(), band0, rtol=1e-13)
+        finally:
+            trm.free_memory()
+
+
 def test_energy_balance_rejection(demo_case, wg, ptg):
     from bart_amd import engine, transit_module as trm
     _setup_demo(demo_case, wg, ptg)

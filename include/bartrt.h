@@ -12,6 +12,9 @@
  *
  * Engine state is a process-global singleton, like the reference module's
  * (created by transit_init, destroyed by free_memory; BARTfunc.py:230,406).
+ * Calls are not re-entrant: drive the engine from one host thread at a time
+ * (the reference runs one engine per MPI process); the `_dev` entry points
+ * are asynchronous on the stream they are given.
  */
 #ifndef BARTRT_H
 #define BARTRT_H

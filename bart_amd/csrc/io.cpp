@@ -147,6 +147,16 @@ OpacityHeader read_opacity_header(const std::string &path) {
          h.nmol < 4096 && h.ntemp < 100000 && h.nlayer < 100000;
   }
   if (ok) {
+    // the counts must fit the file before anything is sized by them
+    const long here = std::ftell(fp);
+    std::fseek(fp, 0, SEEK_END);
+    const long fsize = std::ftell(fp);
+    std::fseek(fp, here, SEEK_SET);
+    const long double need = 32.0L + 4.0L * h.nmol + 8.0L * (h.ntemp + h.nlayer + h.nwave) +
+                             8.0L * h.nlayer * h.ntemp * h.nmol * (long double)h.nwave;
+    ok = need <= (long double)fsize;
+  }
+  if (ok) {
     h.molid.resize(h.nmol); h.temp.resize(h.ntemp);
     h.press.resize(h.nlayer); h.wn.resize(h.nwave);
     ok = std::fread(h.molid.data(), sizeof(int), h.nmol, fp) == (size_t)h.nmol &&
@@ -224,6 +234,17 @@ namespace {
 struct BinReader {
   FILE *fp;
   const std::string &path;
+  long fsize = -1;
+  // bytes between the read position and the end of the file
+  long left() {
+    if (fsize < 0) {
+      const long here = std::ftell(fp);
+      std::fseek(fp, 0, SEEK_END);
+      fsize = std::ftell(fp);
+      std::fseek(fp, here, SEEK_SET);
+    }
+    return fsize - std::ftell(fp);
+  }
   template <class T>
   T get() {
     T v;
@@ -238,6 +259,8 @@ struct BinReader {
   }
   template <class T>
   void arr(std::vector<T> &v, size_t n) {
+    // a count the file cannot hold is a corrupt header, not an allocation request
+    if (n > (size_t)left() / sizeof(T)) throw IoError{"TLI file '" + path + "' is truncated"};
     v.resize(n);
     if (n && std::fread(v.data(), sizeof(T), n, fp) != n)
       throw IoError{"TLI file '" + path + "' is truncated"};

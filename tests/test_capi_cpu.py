@@ -80,6 +80,22 @@ def test_missing_and_malformed_inputs(lib, tmp_path):
         trm.transit_init(3, ["transit", "-c", case.tcfg])
 
 
+def test_corrupt_sample_count_is_refused_before_it_sizes_a_buffer(lib, tmp_path):
+    """A sample count in the opacity header that the file cannot hold is an input
+    error at once -- not a 70 GB allocation (the TLI's transition counts: tests/test_lbl.py)."""
+    import struct
+    import time
+    from bart_amd import synth, transit_module as trm
+    case = synth.make_case(str(tmp_path / "o"), nwave=16, nlayers=10)
+    with open(case.opacity, "r+b") as f:
+        f.seek(24)
+        f.write(struct.pack("=q", 1 << 33))             # Nwave
+    t0 = time.time()
+    with pytest.raises(trm.TransitError, match="truncated|not an opacity grid"):
+        trm.transit_init(3, ["transit", "-c", case.tcfg])
+    assert time.time() - t0 < 20
+
+
 def test_no_gpu_means_error_not_fallback(lib, tmp_path):
     """On a box without a GPU a valid configuration must fail with ENODEV."""
     import torch

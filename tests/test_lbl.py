@@ -103,6 +103,25 @@ def test_narrow_and_broad_states(tmp_path, kw):
 
 
 @pytest.mark.gpu
+def test_corrupt_transition_count_is_refused(tmp_path):
+    """A transition count the TLI file cannot hold is an input error at once, not an
+    allocation of that many records."""
+    import struct
+    import time
+    from bart_amd import synth_lbl, transit_module as trm
+    lc = synth_lbl.make_lbl_case(str(tmp_path), nlines=50, nwave=20, nlayers=4)
+    data = bytearray(open(lc.tli, "rb").read())
+    first = struct.pack("=q", len(lc.linedbs[0]["wn"]))
+    at = data.index(first, 32)                           # the first database's transition count
+    data[at:at + 8] = struct.pack("=q", 1 << 33)
+    open(lc.tli, "wb").write(bytes(data))
+    t0 = time.time()
+    with pytest.raises(trm.TransitError, match="truncated|transition count"):
+        trm.transit_init(3, ["transit", "-c", lc.tcfg])
+    assert time.time() - t0 < 20
+
+
+@pytest.mark.gpu
 def test_ethresh_and_nwidth_are_applied(tmp_path):
     from bart_amd import engine, synth_lbl, transit_module as trm
     from oracle import lbl_oracle

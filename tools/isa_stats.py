@@ -1,0 +1,68 @@
+"""Instruction mix of an RT kernel's layer loop from the gfx950 assembly (no GPU needed).
+usage: python tools/isa_stats.py [mangled-kernel-substring] > profiles/<tag>_isa_<kernel>.txt
+Compiles csrc/kernels.hip to assembly with the build's flags, takes the largest
+basic block of the kernel (the straight-line block of four layers) and counts
+instructions by class."""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FP64 = ("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_min_f64", "v_max_f64", "v_rcp_f64")
+
+
+def main():
+    want = sys.argv[1] if len(sys.argv) > 1 else "rt_eclipse_fastILi5ELi4ELi1ELb1E"
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+                               "--cuda-device-only", "-S", "-x", "hip",
+                               os.path.join(ROOT, "bart_amd", "csrc", "kernels.hip"), "-o", out],
+                              stderr=subprocess.DEVNULL)
+        s = open(out).read()
+    name = re.search(r"^(_ZN6bartrt\w*%s\w*):" % re.escape(want), s, re.M).group(1)
+    body = s[s.index(name + ":"):]
+    body = body[:body.index(".Lfunc_end")].splitlines()
+    blocks, cur = [], []
+    for line in body:
+        t = line.strip()
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            blocks.append(cur)
+            cur = []
+        elif t and not t.startswith((";", ".", "//")):
+            cur.append(t.split()[0])
+    blocks.append(cur)
+    big = max(blocks, key=len)
+    cls = collections.Counter()
+    for m in big:
+        if m.startswith(FP64):
+            cls["fp64 VALU"] += 1
+        elif m.startswith("v_"):
+            cls["other VALU"] += 1
+        elif m.startswith("s_waitcnt"):
+            cls["s_waitcnt"] += 1
+        elif m.startswith("s_"):
+            cls["SALU"] += 1
+        elif m.startswith("buffer_load"):
+            cls["buffer_load"] += 1
+        elif m.startswith("ds_"):
+            cls["LDS"] += 1
+        else:
+            cls[m] += 1
+    print("kernel:", name)
+    print("instructions in the kernel: %d; layer loop body (four layers): %d = %.1f per layer"
+          % (sum(len(b) for b in blocks), len(big), len(big) / 4))
+    for k, v in cls.most_common():
+        print("  %-12s %4d  %6.1f per layer" % (k, v, v / 4))
+    print("by mnemonic:")
+    for k, v in collections.Counter(big).most_common():
+        print("  %-26s %4d" % (k, v))
+    vm = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(l.strip() for l in body))
+    print("counted vmcnt waits in the kernel:", dict(collections.Counter(int(x) for x in vm)))
+
+
+if __name__ == "__main__":
+    main()

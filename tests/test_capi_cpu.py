@@ -30,6 +30,27 @@ def test_every_declared_symbol_is_exported(lib):
     assert not missing, missing
 
 
+def test_header_is_plain_c_and_the_c_host_links(lib, tmp_path):
+    """include/bartrt.h through a strict C99 compiler with every declared entry point
+    referenced, and examples/c_host.c linked against the library."""
+    import subprocess
+    names = _declared()
+    tu = tmp_path / "all.c"
+    tu.write_text('#include "bartrt.h"\n'
+                  "void *table[] = {%s};\nint main(void) { return table[0] == 0; }\n"
+                  % ", ".join("(void *)%s" % n for n in names))
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "bart_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I" + inc, str(tu),
+                           "-L" + libdir, "-lbartrt", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "all")])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + inc,
+                           os.path.join(ROOT, "examples", "c_host.c"), "-L" + libdir, "-lbartrt",
+                           "-Wl,-rpath," + libdir, "-o", str(tmp_path / "c_host")])
+    r = subprocess.run([str(tmp_path / "c_host"), str(tmp_path / "none.cfg"), str(tmp_path / "o.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
 def test_reference_module_names_present():
     from bart_amd import transit_module as trm
     for n in ("transit_init", "get_no_samples", "get_waveno_arr", "set_radius", "set_cloudtop",

@@ -76,3 +76,37 @@ def test_cli_just_opacity(tmp_path):
     r = subprocess.run([CLI, "-c", c.tcfg, "--justOpacity"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.getsize(c.keys["opacityfile"]) > 5 * 2 * 2 * 60 * 8
+
+
+@pytest.mark.gpu
+def test_c_host_on_the_c_abi(tmp_path):
+    """examples/c_host.c, compiled as C99 against include/bartrt.h: init, sizes, the
+    atmosphere file's profile through run_transit, a batch of three -- against the
+    oracle and the Python shim."""
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = synth.make_case(str(tmp_path / "case"), nwave=500, nlayers=60)
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.join(ROOT, "bart_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host.c"), "-L" + libdir, "-lbartrt",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = str(tmp_path / "spec.txt")
+    r = subprocess.run([exe, c.tcfg, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "500 samples, ok flags 1 1 1" in r.stdout
+    got = np.loadtxt(out)
+    o = orc.OracleEngine(c.tcfg)
+    assert np.array_equal(got[:, 0], o.wn)
+    prof = c.profiles()
+    np.testing.assert_allclose(got[:, 1], o.run(prof.ravel()), rtol=1e-10)
+    for col, f in ((3, 1.05), (4, 0.95)):
+        p = prof.copy()
+        p[0] *= f
+        np.testing.assert_allclose(got[:, col], o.run(p.ravel()), rtol=1e-10)
+    np.testing.assert_allclose(got[:, 2], got[:, 1], rtol=1e-12)      # first row of the batch
+    engine.init(c.tcfg)
+    try:
+        assert np.array_equal(trm.run_transit(prof.ravel(), 500), got[:, 1])
+    finally:
+        trm.free_memory()

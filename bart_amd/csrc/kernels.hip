@@ -213,16 +213,18 @@ void rt_eclipse_fast(RtArgs p) {
   // clamped and masked instead of branched around, so that inside an unrolled
   // block the compiler waits (counted vmcnt) on exactly the loads a layer
   // needs and leaves the younger ones in flight.
-  auto layer = [&](int k, const double (&r)[NR]) {
-    const int kc = k < kend ? k : kend;
-    const bool live = active && k <= kend;
-    // the layer record is read from LDS in one batch (all reads issued
-    // together, one wait); masking by multiplication keeps the reads of the
-    // path length and of c2/T out of conditional blocks
-    const double *c = sC + kc * NC;
-    double cf[NC];
+  // The record of a layer is read from LDS one layer ahead (cf / cfn alternate
+  // between two register sets), so its latency is not waited out at the head of
+  // the layer that uses it; masking by multiplication keeps the reads of the
+  // path length and of c2/T out of conditional blocks.
+  auto read_rec = [&](int k, double (&cf)[NC]) {
+    const double *c = sC + (k < kend ? k : kend) * NC;
 #pragma unroll
     for (int j = 0; j < NC; j++) cf[j] = c[j];
+  };
+  auto layer = [&](int k, const double (&r)[NR], const double (&cf)[NC], double (&cfn)[NC]) {
+    const bool live = active && k <= kend;
+    read_rec(k + 1, cfn);
     const double lv = live ? 0.5 : 0.0;
     double e = cf[2 + 2 * M + 2 * C] * nu4;
 #pragma unroll
@@ -258,15 +260,17 @@ void rt_eclipse_fast(RtArgs p) {
   double a0[NR], a1[NR], b0[NR], b1[NR];
   load_layer(clampk(0), a0);
   load_layer(clampk(1), a1);
+  double cfE[NC], cfO[NC];
+  read_rec(0, cfE);
   for (int k0 = 0; k0 <= kend; k0 += 4) {
     load_layer(clampk(k0 + 2), b0);
     load_layer(clampk(k0 + 3), b1);
-    layer(k0, a0);
-    layer(k0 + 1, a1);
+    layer(k0, a0, cfE, cfO);
+    layer(k0 + 1, a1, cfO, cfE);
     load_layer(clampk(k0 + 4), a0);
     load_layer(clampk(k0 + 5), a1);
-    layer(k0 + 2, b0);
-    layer(k0 + 3, b1);
+    layer(k0 + 2, b0, cfE, cfO);
+    layer(k0 + 3, b1, cfO, cfE);
     if (!__any(active)) break;
   }
   double F = 0.0;

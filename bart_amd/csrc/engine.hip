@@ -397,16 +397,23 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
   }
   if (lbl) {
     // eager path (optical-depth / intensity outputs, transit geometry):
-    // [walkers][L][W] extinction first, in bounded chunks
+    // [walkers][L][W] extinction first, in bounded chunks.  The walkers' one-shot
+    // radius / cloud / scattering overrides are [n][3]: every chunk gets its own
+    // rows (run_chunk consumes the pointer it is given, so it is re-armed per chunk).
     const size_t per = (size_t)L * W() * sizeof(double);
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)2 << 30) / per));
+    size_t cap_bytes = (size_t)2 << 30;
+    if (const char *c = std::getenv("BARTRT_LBL_CHUNK_BYTES")) cap_bytes = std::max<size_t>(1, std::strtoull(c, nullptr, 10));
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap_bytes / per));
     const int nprof = (S + 1) * L;
+    const double *over = prep_over_once;
     for (int off = 0; off < n; off += chunk) {
       const int m = std::min(chunk, n - off);
       lbl_extinction(*this, d_prof_in + (size_t)off * nprof, m, st);
+      prep_over_once = over ? over + (size_t)3 * off : nullptr;
       run_chunk(d_prof_in + (size_t)off * nprof, m, d_spec_out + (size_t)off * W(),
                 (d_okp ? d_okp : d_ok) + off, st, want_tau, lbl->d_ext);
     }
+    prep_over_once = nullptr;
     return;
   }
   run_chunk(d_prof_in, n, d_spec_out, d_okp, st, want_tau, nullptr);

@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     tau += dtau;
     // I_a += (B_{k-1} + B_k)/2 * (E_{a,k-1} - E_{a,k}), E = exp(-tau/mu):
     // trapezoid in the transmittance (exact for an isothermal column)
-    const double B = bnum * rcp_core(exp_core(fmin(c[1] * nu, 700.0)) - 1.0);
+    const double B = bnum * rcp_core(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
     const double hb = active ? 0.5 * (Bprev + B) : 0.0;
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
       if (AT <= 0 && a >= A) break;
-      const double E = exp_core(fmax(-tau * p.invmu[a], kExpMin));
+      const double E = exp_rt(fmax(-tau * p.invmu[a], kExpMin));
       I[a] += hb * (fprev[a] - E);
       fprev[a] = E;
     }
@@ -238,7 +238,7 @@ void rt_eclipse_fast(RtArgs p) {
     xs[AE] = fmin(cf[1] * nu, 700.0);
 #pragma unroll
     for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
-    exp_core_n<AE + 1>(xs, ex);
+    exp_rt_n<AE + 1>(xs, ex);
 #pragma unroll
     for (int a = 0; a < AE; a++) es[a] = ex[a];
     if (SQ) es[A - 1] = ex[0] * ex[0];
@@ -345,7 +345,7 @@ void rt_eclipse_split(RtArgs p) {
 #pragma unroll
       for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
       tau += (eprev + e) * cf[0] * lv;
-      const double B = bnum * rcp_core(exp_core(fmin(cf[1] * nu, 700.0)) - 1.0);
+      const double B = bnum * rcp_core(exp_rt(fmin(cf[1] * nu, 700.0)) - 1.0);
       double *slot = sX + (k & 7) * 128;   // half (k/4)&1, layer k&3
       slot[lane] = tau;
       slot[64 + lane] = (Bprev + B) * lv;
@@ -405,7 +405,7 @@ void rt_eclipse_split(RtArgs p) {
         for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
         {
           double ex[AE];
-          exp_core_n<AE>(xs, ex);
+          exp_rt_n<AE>(xs, ex);
 #pragma unroll
           for (int a = 0; a < AE; a++) es[a] = ex[a];
           if (SQ) es[A - 1] = ex[0] * ex[0];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
     xs[AE] = fmin(cf[1] * nu, 700.0);
 #pragma unroll
     for (int a = 0; a < AE; a++) xs[a] = -tc * p.invmu[a];
-    exp_core_n<AE + 1>(xs, ex);
+    exp_rt_n<AE + 1>(xs, ex);
     const double B = bnum * rcp_core(ex[AE] - 1.0);
     // the layer above: row q - 1, or the carry for row 0
     const double B_below = __shfl(B, from_below);

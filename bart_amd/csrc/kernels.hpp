@@ -218,32 +218,48 @@ __device__ __forceinline__ double rcp_core(double d) {
   return fma(y, e, y);
 }
 
-// exp() of N independent arguments with the Horner steps interleaved across
-// the arguments: one wave alone on a SIMD then overlaps the N dependent FMA
-// chains instead of paying the fp64 pipeline latency N x 12 times in a row.
+// exp() of the RT kernels (Planck exponent and slant transmittances): same
+// shifter / exponent-field scheme as exp_core with ONE reduction FMA (n * ln2 is
+// exact inside the FMA; ln2 rounded to double is off by 2.3e-17 per unit of n:
+// 2e-14 at |x| = 700, nothing at n = 0) and a degree-9 interpolant on
+// [-ln2/2, ln2/2] whose constant and linear coefficients are exactly 1: it is
+// 1 + r + r^2 g(r) with g through the Chebyshev nodes (tools/gen_exp_coef.py;
+// relative error 7e-14 in the value and 1.4e-11 in the DERIVATIVE).  The
+// derivative is what the intensity sums see -- they add differences of
+// transmittances of neighbouring layers -- and the exact first-order term keeps
+// optically thin columns (all arguments near 0) at full precision; an
+// unconstrained degree-8 fit (1e-12 in the value) was off by 1e-8 there.
+// 13 VALU operations instead of 16.  The spectra's tolerance is 1e-6
+// (BASELINE.json north_star); the parity tests hold the kernels to 1e-10.
+// N independent arguments are evaluated with their Horner steps interleaved:
+// one wave alone on a SIMD then overlaps the N dependent FMA chains instead of
+// paying the fp64 pipeline latency N x 9 times in a row.
 template <int N>
-__device__ __forceinline__ void exp_core_n(const double (&x)[N], double (&out)[N]) {
+__device__ __forceinline__ void exp_rt_n(const double (&x)[N], double (&out)[N]) {
   double t[N], r[N], q[N];
 #pragma unroll
   for (int a = 0; a < N; a++) t[a] = fma(x[a], 1.4426950408889634074, kExpShift);
 #pragma unroll
-  for (int a = 0; a < N; a++) {
-    const double n = t[a] - kExpShift;
-    r[a] = fma(n, -6.93147180369123816490e-01, x[a]);
-    r[a] = fma(n, -1.90821492927058770002e-10, r[a]);
-  }
-  constexpr double cf[11] = {2.763263963904103e-07, 2.755724091857897e-06, 2.4801485482328494e-05,
-                             0.00019841269890047113, 0.0013888888952314775, 0.008333333333319601,
-                             0.0416666666664881, 0.1666666666666668, 0.5000000000000019, 1.0, 1.0};
+  for (int a = 0; a < N; a++) r[a] = fma(t[a] - kExpShift, -6.93147180559945286227e-01, x[a]);
+  constexpr double cf[9] = {2.4867870179687727e-05, 0.00019841224599656011, 0.0013888839110572009,
+                            0.0083333333442029804,  0.041666666786265731,   0.16666666666662586,
+                            0.49999999999955108,    1.0,                    1.0};
 #pragma unroll
-  for (int a = 0; a < N; a++) q[a] = 2.5110037605963777e-08;
+  for (int a = 0; a < N; a++) q[a] = 2.7617564785876086e-06;
 #pragma unroll
-  for (int j = 0; j < 11; j++) {
+  for (int j = 0; j < 9; j++) {
 #pragma unroll
     for (int a = 0; a < N; a++) q[a] = fma(q[a], r[a], cf[j]);
   }
 #pragma unroll
   for (int a = 0; a < N; a++) out[a] = exp_scale(q[a], t[a]);
+}
+
+__device__ __forceinline__ double exp_rt(double x) {
+  const double xs[1] = {x};
+  double o[1];
+  exp_rt_n<1>(xs, o);
+  return o[0];
 }
 
 // Largest optical depth whose slant transmittances exp(-tau / mu_a) all stay in

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const double tau = acc[r];
-      const double g = exp_core(fmax(-tau, kExpMin)) * rk;
+      const double g = exp_rt(fmax(-tau, kExpMin)) * rk;
       double gprev = __shfl_up(g, 1, 16);
       if (m == 0) gprev = gcarry[r];
       const unsigned long long over = __ballot(kvalid && tau > p.toomuch);

@@ -9,7 +9,17 @@ synthetic walkers on the headline grid: 100 layers x 1e4 wavenumbers, 4 opacity
 molecules (H2O, CO, CO2, CH4), 27 table temperatures, H2-H2 CIA, ray angles
 0/20/40/60/80 deg, toomuch = 10.  Profiles and spectra stay
 resident in HBM inside the timed region.  N > 1 shards the wavenumber axis by
-block across the ranks (one process per GPU, launched by torch.distributed.run).
+block across the ranks, one process per GPU: under torch.distributed.run (RANK /
+WORLD_SIZE in the environment) this process is one rank; run plainly with
+--gpus N > 1 it starts `python -m torch.distributed.run --nproc-per-node N` on
+itself as a CHILD process (before torch or HIP are touched here), relays the
+child's output and exits with its code.
+
+--dry-gloo replaces the GPU engine by a stub (spectra = a known function of the
+profile and the sample index) on CPU tensors with the gloo backend: it exercises
+the launch path, the sharded step loop, the bucketed all-gather and the
+one-JSON-line contract where there is no GPU (tests/test_bench_launch.py).  Its
+line carries "dry": true and measures nothing.
 
 Prints ONE JSON line on rank 0 (contract: see the task statement; `roofline`
 and `cpu_baseline` objects included).
@@ -104,6 +114,71 @@ def cpu_baseline(case, profs, seconds_target=12.0):
                       f"one walker per thread, {dt:.1f} s wall"}
 
 
+def self_launch(ngpus, argv, port=0):
+    """`python bench.py --gpus N` (N > 1) without a launcher: run the ranks as a
+    child `python -m torch.distributed.run` of this script, relay its stdout
+    (rank 0's one JSON line) and stderr, return its exit code."""
+    import socket
+    import subprocess
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class StubEngine:
+    """--dry-gloo stand-in for bart_amd.engine (no GPU, no tables): the spectrum of
+    a profile is a known function of the profile and the absolute sample index,
+    so the reassembled [nwalkers, W] result can be checked exactly."""
+
+    def __init__(self, nwave):
+        self.W, self.lo, self.hi = nwave, 0, nwave
+
+    def init(self, tcfg, shard=None, device=None):
+        if shard is not None:
+            r, n = shard
+            self.lo, self.hi = self.W * r // n, self.W * (r + 1) // n   # Engine::setup's split
+            if self.hi <= self.lo:
+                raise RuntimeError("--shard leaves this rank without wavenumber samples")
+
+    def local_range(self):
+        return self.lo, self.hi
+
+    @staticmethod
+    def expected(prof, lo, hi):
+        import torch
+        i = torch.arange(lo, hi, dtype=torch.float64)
+        return prof.sum(1, keepdim=True) * 1e-3 + i[None, :]
+
+    def run_batch_dev(self, d_prof, d_spec):
+        d_spec.copy_(self.expected(d_prof, self.lo, self.hi))
+        return d_spec
+
+    def timing_begin(self):
+        pass
+
+    def timing_end(self):
+        return 0.0, 0
+
+    def algorithmic_bytes(self, nwalkers):
+        return 0.0
+
+    def free(self):
+        pass
+
+    @staticmethod
+    def GatherPipeline(*args, **kw):
+        from bart_amd import engine
+        return engine.GatherPipeline(*args, **kw)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,27 +198,42 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--dry-gloo", action="store_true",
+                    help="no GPU: stub engine, CPU tensors, gloo backend (launch-path check, not a measurement)")
+    ap.add_argument("--master-port", type=int, default=0,
+                    help="rendezvous port of the self-launched N > 1 run (0: pick a free one)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing here has
+        # imported torch or touched HIP yet, and the ranks are CHILD processes (a
+        # process that has initialised the GPU must never exec or re-launch itself).
+        sys.exit(self_launch(a.gpus, sys.argv[1:], a.master_port))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run "
-                     "(one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = a.dry_gloo
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the engine has no CPU path")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     use_dist = world > 1 or (a.force_collective and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner through C stdio on stdout when the first
+        # RCCL (and gloo) print a banner through C stdio on stdout when the first
         # communicator comes up; the contract is ONE JSON line there.  File
         # descriptor 1 points at stderr until the communicator exists and the C
         # buffers are flushed.
@@ -152,21 +242,28 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if dry:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
             ctypes.CDLL(None).fflush(None)
         finally:
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    from bart_amd import engine, synth
+    from bart_amd import synth
+    if dry:
+        engine = StubEngine(a.nwave)
+    else:
+        from bart_amd import engine
 
     # ---- synthetic inputs (rank 0 of the node writes, everyone reads)
     wd = a.workdir or os.path.join(tempfile.gettempdir(),
                                    "bartrt_bench_%s" % os.environ.get("MASTER_PORT", "single"))
-    case = synth.make_case(wd, nlayers=a.nlayers, nwave=a.nwave, write=(local_rank == 0),
-                           reuse=True)
+    case = synth.make_case(wd, nlayers=a.nlayers, nwave=a.nwave,
+                           write=(local_rank == 0 and not dry), reuse=True)
     if use_dist:
         dist.barrier()
     engine.init(case.tcfg, shard=(rank, world) if world > 1 else None, device=local_rank)
@@ -202,10 +299,10 @@ def main():
             out = step(i)
         if use_dist and warmup:
             out = (drain(warmup - 1) or [out])[-1]
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         if record:
             engine.timing_begin()
         t0 = time.perf_counter()
@@ -214,10 +311,10 @@ def main():
             out = o if o is not None else out
         if use_dist:
             out = (drain(steps - 1) or [out])[-1]
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
         kern_ms, nlaunch = engine.timing_end() if record else (0.0, 0)
         if use_dist:
@@ -225,6 +322,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ok = out.shape == (nwalk, a.nwave) and bool(torch.isfinite(out).all())
+        if dry:   # the reassembled spectra of the last step, sample for sample
+            ok = ok and bool(torch.equal(out, StubEngine.expected(d_prof[(steps - 1) % nsets], 0, a.nwave)))
         return dt, kern_ms, nlaunch, ok, profs_h[0]
 
     nwalk = a.walkers * world            # weak scaling: per-GPU work is fixed
@@ -239,7 +338,19 @@ def main():
                              "rt_kernel_ms": skm / max(snl, 1),
                              "algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
 
-    if rank == 0:
+    if rank == 0 and dry:
+        assert ok
+        print(json.dumps({
+            "metric": "forward spectra/sec (100 layers x 1e4 wavenumbers)", "dry": True,
+            "value": None, "unit": "spectra/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "DRY RUN (stub engine, gloo, CPU): launch path and step loop only, "
+                                   "%d walkers per rank per step, %d samples" % (a.walkers, a.nwave),
+                       "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave,
+                       "parallelism": "wavenumber-block shard x%d + all-gather" % world},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    elif rank == 0:
         assert ok
         value = nwalk * a.steps / dt
         alg = engine.algorithmic_bytes(nwalk)          # bytes per RT launch on this GPU
@@ -287,8 +398,9 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    from bart_amd import transit_module as trm
-    trm.free_memory()
+    if not dry:
+        from bart_amd import transit_module as trm
+        trm.free_memory()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,48 @@
+"""`python bench.py --gpus N` must launch itself: with N > 1
+and no RANK in the environment the script starts torch.distributed.run on itself
+as a child process, the ranks run the sharded step loop, and exactly ONE JSON
+line comes back on stdout.  Run here with --dry-gloo: a stub engine on CPU
+tensors over gloo, whose reassembled spectra are checked sample for sample
+inside bench.py; the GPU engine takes the same code path with nccl."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e,
+                          capture_output=True, text=True, timeout=600)
+
+
+def test_gpus2_self_launch_one_json_line():
+    r = _bench("--gpus", "2", "--dry-gloo", "--steps", "11", "--warmup", "3", "--walkers", "3",
+               "--nwave", "2501", "--gather-steps", "4", "--sweep", "")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout            # the contract: ONE line on stdout
+    j = json.loads(lines[0])
+    assert j["dry"] is True and j["value"] is None      # a dry run is never a measurement
+    assert j["n_gpus"] == 2 and j["steps"] == 11 and j["warmup"] == 3
+    assert j["scaling"] == "weak" and j["config"]["walkers_per_step"] == 6   # walkers scale with N
+    assert j["ms_per_step"] > 0
+
+
+def test_child_failure_becomes_the_exit_code():
+    # an impossible shard (more ranks than samples) fails in the ranks; the
+    # launcher must pass the failure on, not print a line
+    r = _bench("--gpus", "2", "--dry-gloo", "--steps", "1", "--warmup", "0", "--walkers", "1",
+               "--nwave", "1", "--sweep", "")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_single_rank_needs_no_launcher():
+    r = _bench("--dry-gloo", "--steps", "3", "--warmup", "1", "--walkers", "2", "--nwave", "700", "--sweep", "")
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip())
+    assert j["n_gpus"] == 1 and j["dry"] is True

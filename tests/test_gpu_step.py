@@ -195,7 +195,7 @@ def test_sharded_step_equals_unsharded(demo_case, wg, ptg):
             status = torch.empty(n, dtype=torch.int32, device="cuda")
             trm.check(trm.lib().bartrt_step_profiles_dev(
                 C.c_void_p(d_par.data_ptr()), n, params.shape[1], C.c_void_p(prof.data_ptr()),
-                C.c_void_p(status.data_ptr()), None))
+                C.c_void_p(status.data_ptr()), engine._stream_ptr()))   # the stream run_batch_dev uses
             blocks.append(engine.run_batch_dev(prof).clone())
             if r == world - 1:
                 spec = torch.cat(blocks, dim=1).contiguous()
@@ -203,7 +203,7 @@ def test_sharded_step_equals_unsharded(demo_case, wg, ptg):
                 band = torch.empty((n, 10), dtype=torch.float64, device="cuda")
                 trm.check(trm.lib().bartrt_step_bandflux_dev(
                     C.c_void_p(spec.data_ptr()), n, C.c_void_p(status.data_ptr()),
-                    C.c_void_p(band.data_ptr()), None))
+                    C.c_void_p(band.data_ptr()), engine._stream_ptr()))
                 torch.cuda.synchronize()
                 assert np.array_equal(status.cpu().numpy(), status0)
                 np.testing.assert_allclose(band.cpu().numpy(), band0, rtol=1e-13)

@@ -10,9 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
-SOURCES = ["capi.hip", "engine.hip", "kernels.hip", "step.hip", "mcmc.hip", "lbl.hip", "transit_geom.hip",
-           "io.cpp"]
-HEADERS = ["engine.hpp", "kernels.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
+SOURCES = ["rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "lbl.hip", "transit_geom.hip",
+           "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "io.cpp"]   # longest first
+HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
 
 
@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return obj
 
     # translation units are independent: a few compilers side by side
-    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
     subprocess.check_call(cmd)

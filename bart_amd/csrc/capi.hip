@@ -98,6 +98,15 @@ int bartrt_set_scattering(int flag, double value) {
   return BARTRT_OK;
 }
 
+int bartrt_set_integ(int rule) {
+  NEED_ENGINE();
+  if (rule < 0 || rule > 2) return fail(BARTRT_EINVAL, "set_integ: rule must be 0 (transmittance), 1 (simpson) or 2 (trapz_tau)");
+  g_eng->integ = rule;
+  return BARTRT_OK;
+}
+
+int bartrt_get_integ(void) { NEED_ENGINE(); return g_eng->integ; }
+
 int bartrt_get_nlayers(void) { NEED_ENGINE(); return g_eng->L; }
 int bartrt_get_nspecies(void) { NEED_ENGINE(); return g_eng->S; }
 int bartrt_get_nprof(void) { NEED_ENGINE(); return (g_eng->S + 1) * g_eng->L; }
@@ -298,6 +307,36 @@ int bartrt_timing_end(double *kernel_ms, int *nlaunch) {
     if (nlaunch) *nlaunch = e->ev_used / 2;
     e->timing = false;
     e->ev_used = 0;
+    return BARTRT_OK;
+  });
+}
+
+int bartrt_walked_begin(void) {
+  NEED_ENGINE();
+  g_eng->want_walked = true;
+  g_eng->walked_nwalkers = 0;
+  return BARTRT_OK;
+}
+
+int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *wn_per_column,
+                      char *kernel, int kernel_len) {
+  NEED_ENGINE();
+  return guarded([&] {
+    Engine *e = g_eng;
+    e->want_walked = false;
+    HIPCHK(hipDeviceSynchronize());
+    const int n = e->walked_nwalkers, nc = e->walked_info.ncolumns;
+    if (nwalkers) *nwalkers = n;
+    if (ncolumns) *ncolumns = nc;
+    if (wn_per_column) *wn_per_column = e->walked_info.wn_per_column;
+    if (kernel && kernel_len > 0) {
+      std::strncpy(kernel, e->walked_info.kernel, kernel_len - 1);
+      kernel[kernel_len - 1] = 0;
+    }
+    if (walked && n > 0) {
+      if ((size_t)cap < (size_t)n * nc) throw std::invalid_argument("walked_end: buffer too small");
+      HIPCHK(hipMemcpy(walked, e->d_walked, sizeof(int) * (size_t)n * nc, hipMemcpyDeviceToHost));
+    }
     return BARTRT_OK;
   });
 }

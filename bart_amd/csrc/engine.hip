@@ -42,6 +42,7 @@ Engine::~Engine() {
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_mass);
   fr(d_prep_consts); fr(d_diam); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
+  fr(d_walked);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
@@ -61,6 +62,13 @@ void Engine::init(int argc, const char **argv) {
   if (shard_n < 1 || shard_rank < 0 || shard_rank >= shard_n)
     throw IoError{"transit_init: bad --shard rank/nranks"};
   setup(read_tcfg(cfile), shard_rank, shard_n);
+}
+
+int parse_integ(const std::string &v) {
+  if (v == "0" || v == "transmittance") return 0;
+  if (v == "1" || v == "simpson") return 1;
+  if (v == "2" || v == "trapz_tau" || v == "trapz") return 2;
+  throw IoError{"integ: '" + v + "' is not an integration rule (0 transmittance, 1 simpson, 2 trapz_tau)"};
 }
 
 static bool file_exists(const std::string &p) {
@@ -113,6 +121,14 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     if (!(starrad > 0)) throw IoError{"transit cfg: bad 'starrad'"};
   } else if (sol != "eclipse") {
     throw IoError{"unknown solution '" + sol + "' (eclipse or transit)"};
+  }
+  // integration rule of the eclipse geometry (integ.hpp): `integ` in the cfg (this
+  // engine's own key: the reference's source, which would settle the rule, is
+  // absent), overridden by BARTRT_INTEG; number or name
+  {
+    std::string v = cfg_has(cfg, "integ") ? cfg["integ"] : "0";
+    if (const char *ev = std::getenv("BARTRT_INTEG")) if (*ev) v = ev;
+    integ = parse_integ(v);
   }
   atm = read_atm(cfg["atm"]);
   mol = read_molfile(cfg["molfile"]);
@@ -389,7 +405,7 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
   // per-walker workspaces (records, flags) are sized by cap_walkers; the
   // caller's profile and spectrum buffers are used in place
   if (n > cap_walkers && d_prof_in != d_prof) ensure_walkers(n);
-  if (lbl && solution == 0 && !want_tau && !want_intens && !lbl_eager) {
+  if (lbl && solution == 0 && !want_tau && !want_intens && !lbl_eager && integ == 0) {
     // lazy fused path: layers' line sums are evaluated only as deep as the
     // optical depth requires
     run_chunk(d_prof_in, n, d_spec_out, d_okp, st, false, nullptr, true);
@@ -448,6 +464,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.coef = d_coef; r.idx = d_idx; r.kstop = d_kstop;
   r.ext = d_ext;
   r.cloud_on = has_cloud || over_cloud;
+  r.integ = integ;
   r.toomuch = toomuch;
   r.spec = d_spec_out;
   r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;
@@ -471,9 +488,23 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     }
     HIPCHK(hipEventRecord(ev[ev_used], st));
   }
+  r.walked_out = nullptr;
+  if (want_walked && solution == 0 && !lbl_fused) {
+    // the finest column any eclipse kernel records is 8 wavenumbers wide
+    const size_t need = (size_t)n * ((size_t)(r.W + 7) / 8 + 64);
+    if (need > walked_cap) {
+      if (d_walked) HIPCHK(hipFree(d_walked));
+      d_walked = nullptr;
+      HIPCHK(hipMalloc(&d_walked, need * sizeof(int)));
+      walked_cap = need;
+    }
+    HIPCHK(hipMemsetAsync(d_walked, 0, need * sizeof(int), st));
+    r.walked_out = d_walked;
+    walked_nwalkers = n;
+  }
   if (lbl_fused) lbl_rt_eclipse(*this, d_prof_in, n, r, st);
   else if (solution == 1) HIPCHK(launch_transit(r, st));
-  else HIPCHK(launch_rt(r, block, st));
+  else HIPCHK(launch_rt(r, block, st, want_walked ? &walked_info : nullptr));
   if (timing) {
     HIPCHK(hipEventRecord(ev[ev_used + 1], st));
     ev_used += 2;

@@ -11,9 +11,11 @@
 namespace bartrt {
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
-hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st);
+hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *info = nullptr);
 hipError_t launch_transit(const RtArgs &a, hipStream_t st);
 hipError_t launch_chord_table(const PrepArgs &a, hipStream_t st);  // transit geometry, after launch_prep
+
+int parse_integ(const std::string &v);  // "0" / "transmittance", "1" / "simpson", "2" / "trapz_tau"
 
 struct StepArgs;  // converters around the engine (step.hip)
 struct Lbl;       // line-by-line extinction (lbl.hip)
@@ -31,6 +33,7 @@ struct Engine {
   double toomuch = 20.0, gsurf = 0, refpress = 0, refradius = 0;
   int scat_flag = 0, iH2 = -1, iHe = -1, has_cloud = 0;
   int solution = 0;       // 0 eclipse (emergent flux), 1 transit (modulation)
+  int integ = 0;          // integration rule of the eclipse geometry (integ.hpp); cfg `integ`, BARTRT_INTEG
   double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;
   int device = 0;
@@ -66,6 +69,12 @@ struct Engine {
   // parameter is among them, so the RT kernels add the deck's surface term
   const double *prep_over_once = nullptr;
   bool prep_over_cloud = false;
+  // diagnostics of the next RT launches: layers walked per (walker, kernel column)
+  bool want_walked = false;
+  int *d_walked = nullptr;
+  size_t walked_cap = 0;
+  int walked_nwalkers = 0;
+  RtLaunchInfo walked_info{};
   // timing of RT launches
   bool timing = false;
   std::vector<hipEvent_t> ev;

@@ -1,0 +1,227 @@
+// Integration rules of the eclipse geometry (DESIGN.md conventions C6 / C8; the
+// parity tests hold each rule to its scalar CPU restatement).  The reference's engine
+// is absent (empty submodule), so which rule it applies cannot be checked: the
+// product carries the three candidates as a switch (cfg key `integ`, environment
+// BARTRT_INTEG, bartrt_set_integ) and every eclipse kernel is built for each.
+//
+//   0  transmittance  tau by trapezoid over radius; I(mu) = int B d(exp(-tau/mu)),
+//                     trapezoid in the transmittance (the default).
+//   1  simpson        SURVEY.md App. A-4 as recalled: tau[k] by the Simpson /
+//                     trapezoid hybrid over the layers k .. top (panels (0,1,2),
+//                     (2,3,4), ... from the top, the trapezoid of (k-1, k) for odd
+//                     k); I(mu) = (1/mu) int B exp(-tau/mu) dtau by the same hybrid
+//                     over the points 0 .. last from the top (an even count starts
+//                     with the trapezoid of (0, 1)), padded by one point of zero
+//                     integrand one unit of tau past `last` when a layer exists
+//                     there.
+//   2  trapz_tau      tau as in 0; I(mu) = (1/mu) int B exp(-tau/mu) dtau by plain
+//                     trapezoid over 0 .. last.
+// A cloud deck reached below `toomuch` adds its surface term B exp(-tau/mu) in
+// every rule (and ends rule 1's point list without the padded point).
+#pragma once
+#include "kernels.hpp"
+
+namespace bartrt {
+
+enum { kIntegTransmittance = 0, kIntegSimpson = 1, kIntegTrapzTau = 2, kIntegCount = 3 };
+
+// Simpson weights of the panel (k-2, k-1, k) over radius, per layer, in LDS:
+// sW[3 k + (0,1,2)] for even k >= 2 (zero elsewhere).  dr(k) = r_{k-1} - r_k is
+// word 0 of the layer's coefficient record.  Called by every thread of the
+// workgroup after the records are staged; the caller synchronises.  The table has
+// kSimpsonPad extra (zero) layers: the unrolled layer blocks index a few layers
+// past the column's end before masking them.
+constexpr int kSimpsonPad = 8;
+__host__ __device__ inline size_t simpson_lds_doubles(int L) { return 3 * (size_t)(L + kSimpsonPad); }
+__device__ __forceinline__ void simpson_radius_weights(double *sW, const double *sC, int NC, int L, int tid,
+                                                       int nthreads) {
+  for (int k = tid; k < L + kSimpsonPad; k += nthreads) {
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+    if (k >= 2 && (k & 1) == 0 && k < L) {
+      const double h0 = sC[(k - 1) * NC], h1 = sC[k * NC], hs = h0 + h1;
+      if (h0 == 0.0 || h1 == 0.0) {
+        w0 = 0.5 * h0; w1 = 0.5 * hs; w2 = 0.5 * h1;
+      } else {
+        w0 = hs / 6.0 * (2.0 - h1 / h0);
+        w1 = hs / 6.0 * (hs * hs / (h0 * h1));
+        w2 = hs / 6.0 * (2.0 - h0 / h1);
+      }
+    }
+    sW[3 * k] = w0; sW[3 * k + 1] = w1; sW[3 * k + 2] = w2;
+  }
+}
+
+// Optical depth of a column walked from the top, one layer per call (lane = one
+// wavenumber).  `live`: the layer counts (the column has not passed toomuch and
+// the layer is in range); lv = live ? 0.5 : 0.
+template <int INTEG>
+struct TauColumn {
+  double tau = 0.0, eprev = 0.0;
+  __device__ __forceinline__ void layer(int, bool, double lv, double e, double dr, const double *) {
+    tau += (eprev + e) * dr * lv;
+    eprev = e;
+  }
+};
+
+template <>
+struct TauColumn<kIntegSimpson> {
+  double tau = 0.0, eprev = 0.0, e2 = 0.0, s_even = 0.0;
+  // sW: the workgroup's Simpson weights (simpson_radius_weights); k is wave-uniform
+  __device__ __forceinline__ void layer(int k, bool live, double lv, double e, double dr, const double *sW) {
+    if (k & 1) {
+      const double t = fma((eprev + e) * dr, lv, s_even);
+      tau = live ? t : tau;
+    } else if (k >= 2) {
+      const double s = fma(sW[3 * k], e2, fma(sW[3 * k + 1], eprev, fma(sW[3 * k + 2], e, s_even)));
+      s_even = live ? s : s_even;
+      tau = live ? s : tau;
+    }
+    e2 = eprev;
+    eprev = e;
+  }
+};
+
+// Emergent intensity per ray angle of a column walked from the top.
+//   layer(A, live, lv, tau, Bprev, B, E): after the layer's optical depth, Planck
+//     term B (Bprev: the layer above) and transmittances E[a] = exp(-tau / mu_a);
+//   flux(p, A, deck, Bprev, L, out): after the walk; deck = the column reached a
+//     cloud deck below toomuch.  Returns sum_a wgt[a] I_a; out (optional): I_a.
+template <int INTEG, int AMAX>
+struct ColumnIntens;
+
+template <int AMAX>
+struct ColumnIntens<kIntegTransmittance, AMAX> {
+  double I[AMAX], fprev[AMAX];
+  __device__ __forceinline__ ColumnIntens() {
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { I[a] = 0.0; fprev[a] = 1.0; }
+  }
+  __device__ __forceinline__ void layer(int A, bool, double lv, double, double Bprev, double B,
+                                        const double (&E)[AMAX]) {
+    const double hb = (Bprev + B) * lv;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      if (a >= A) break;
+      I[a] = fma(hb, fprev[a] - E[a], I[a]);
+      fprev[a] = E[a];
+    }
+  }
+  __device__ __forceinline__ double flux(const RtArgs &p, int A, bool deck, double Bprev, int, double *out) {
+    double F = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      if (a >= A) break;
+      const double Ia = I[a] + (deck ? Bprev * fprev[a] : 0.0);
+      F += p.wgt[a] * Ia;
+      if (out) out[a] = Ia;
+    }
+    return F;
+  }
+};
+
+template <int AMAX>
+struct ColumnIntens<kIntegTrapzTau, AMAX> {
+  double I[AMAX], y1[AMAX], x1 = 0.0;
+  __device__ __forceinline__ ColumnIntens() {
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { I[a] = 0.0; y1[a] = 0.0; }
+  }
+  __device__ __forceinline__ void layer(int A, bool live, double lv, double tau, double, double B,
+                                        const double (&E)[AMAX]) {
+    const double h = (tau - x1) * lv;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      if (a >= A) break;
+      const double y = B * E[a];
+      I[a] = fma(y1[a] + y, h, I[a]);
+      y1[a] = live ? y : y1[a];
+    }
+    x1 = live ? tau : x1;
+  }
+  __device__ __forceinline__ double flux(const RtArgs &p, int A, bool deck, double, int, double *out) {
+    double F = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      if (a >= A) break;
+      const double Ia = fma(I[a], p.invmu[a], deck ? y1[a] : 0.0);
+      F += p.wgt[a] * Ia;
+      if (out) out[a] = Ia;
+    }
+    return F;
+  }
+};
+
+// Simpson weights of the panel over (x - h0 - h1, x - h1, x); zero-width halves
+// fall back to the two trapezoids.
+__device__ __forceinline__ void simpson_tau_weights(double h0, double h1, double &w0, double &w1, double &w2) {
+  const bool deg = h0 == 0.0 || h1 == 0.0;
+  const double hs = h0 + h1;
+  const double r0 = rcp_core(deg ? 1.0 : h0), r1 = rcp_core(deg ? 1.0 : h1);
+  const double s6 = hs * (1.0 / 6.0);
+  w0 = deg ? 0.5 * h0 : s6 * (2.0 - h1 * r0);
+  w1 = deg ? 0.5 * hs : s6 * (hs * hs * (r0 * r1));
+  w2 = deg ? 0.5 * h1 : s6 * (2.0 - h0 * r1);
+}
+
+template <int AMAX>
+struct ColumnIntens<kIntegSimpson, AMAX> {
+  // points so far (n), the last two abscissae and integrands, the running sums
+  // of the panels that end on an even / odd point index (P0 / P1; P1 starts
+  // with the trapezoid of the first interval)
+  double P0[AMAX], P1[AMAX], y1[AMAX], y2[AMAX], x1 = 0.0, x2 = 0.0;
+  int n = 0;
+  __device__ __forceinline__ ColumnIntens() {
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { P0[a] = 0.0; P1[a] = 0.0; y1[a] = 0.0; y2[a] = 0.0; }
+  }
+  // appends the point (x, y[]) for the lanes with `live`
+  __device__ __forceinline__ void point(int A, bool live, double x, const double (&y)[AMAX]) {
+    const double h0 = x1 - x2, h1 = x - x1;
+    double w0, w1, w2;
+    simpson_tau_weights(h0, h1, w0, w1, w2);
+    const bool second = n == 1, odd = (n & 1) != 0;
+    const bool add0 = live && n >= 2 && !odd, add1 = live && n >= 1 && odd;
+    // the second point closes the first interval: a trapezoid into P1
+    w0 = second ? 0.0 : w0;
+    w1 = second ? 0.5 * h1 : w1;
+    w2 = second ? 0.5 * h1 : w2;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      if (a >= A) break;
+      const double c = fma(w0, y2[a], fma(w1, y1[a], w2 * y[a]));
+      P0[a] += add0 ? c : 0.0;
+      P1[a] += add1 ? c : 0.0;
+      y2[a] = live ? y1[a] : y2[a];
+      y1[a] = live ? y[a] : y1[a];
+    }
+    x2 = live ? x1 : x2;
+    x1 = live ? x : x1;
+    n += live ? 1 : 0;
+  }
+  __device__ __forceinline__ void layer(int A, bool live, double, double tau, double, double B,
+                                        const double (&E)[AMAX]) {
+    double y[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) y[a] = a < A ? B * E[a] : 0.0;
+    point(A, live, tau, y);
+  }
+  __device__ __forceinline__ double flux(const RtArgs &p, int A, bool deck, double, int L, double *out) {
+    double ysurf[AMAX], zero[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { ysurf[a] = deck ? y1[a] : 0.0; zero[a] = 0.0; }
+    // one padded point (integrand 0, one unit of tau further) while a layer exists below
+    point(A, !deck && n < L, x1 + 1.0, zero);
+    const bool odd_end = ((n - 1) & 1) != 0;   // parity of the last point's index
+    double F = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      if (a >= A) break;
+      const double Ia = fma(odd_end ? P1[a] : P0[a], p.invmu[a], ysurf[a]);
+      F += p.wgt[a] * Ia;
+      if (out) out[a] = Ia;
+    }
+    return F;
+  }
+};
+
+}  // namespace bartrt

@@ -42,7 +42,15 @@ TCfg read_tcfg(const std::string &path) {
     size_t sp = line.find_first_of(" \t");
     std::string key = line.substr(0, sp);
     std::string val = sp == std::string::npos ? "" : trim(line.substr(sp));
-    c[key] = val;
+    // makecfg.makeTransit writes one `key value` line per value of a multi-line
+    // BART option (code/makecfg.py:93-104: `linedb a.tli` then `linedb b.tli`):
+    // the file lists accumulate, comma-separated like csfile; any other repeated
+    // key keeps its last value
+    auto it = c.find(key);
+    if (it != c.end() && !it->second.empty() && !val.empty() && (key == "linedb" || key == "csfile"))
+      it->second += "," + val;
+    else
+      c[key] = val;
   }
   return c;
 }

@@ -162,6 +162,7 @@ struct RtArgs {
   const idx_t *idx;
   const int *kstop;
   int cloud_on;            // kstop marks a cloud deck (adds surface emission)
+  int integ;               // integration rule of the eclipse geometry (integ.hpp: 0 / 1 / 2)
   double toomuch;
   double invmu[kMaxAngles];
   double wgt[kMaxAngles];  // pi (sin^2 hi - sin^2 lo)
@@ -169,9 +170,17 @@ struct RtArgs {
   double *tau_out;         // optional [W][L] (single walker), may be null
   int *last_out;           // optional [W]
   double *intens_out;      // optional [A][W] intensities per ray angle (single walker)
+  int *walked_out;         // optional diagnostics: layers walked per (walker, column of the launched kernel)
   // transit geometry
   const double *rtop, *ds;
   double inv_starrad2;
+};
+
+// What launch_rt launched (diagnostics; the byte model of bench.py)
+struct RtLaunchInfo {
+  const char *kernel = "";
+  int wn_per_column = 64;   // granularity of RtArgs::walked_out
+  int ncolumns = 0;         // entries of walked_out per walker
 };
 
 // ---------------------------------------------------------------------------

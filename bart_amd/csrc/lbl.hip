@@ -542,14 +542,34 @@ static T *upv(const std::vector<T> &v) {
   return d;
 }
 
-void lbl_init(Engine &e, const std::string &path) {
+void lbl_init(Engine &e, const std::string &paths) {
   Lbl *b = new Lbl();
   delete e.lbl;
   e.lbl = b;
-  b->tli = read_tli(path);
+  // `linedb` may name several TLI files (comma / blank separated; one line each
+  // in the cfg, code/makecfg.py:93-104): their databases are merged in file order
   Tli &t = b->tli;
-  if (t.db.empty()) throw IoError{"TLI file '" + path + "' holds no database"};
-  if ((int)t.db.size() > kMaxGroup) throw IoError{"TLI file: too many databases"};
+  {
+    std::string cur;
+    auto flush = [&] {
+      if (cur.empty()) return;
+      Tli one = read_tli(cur);
+      if (one.db.empty()) throw IoError{"TLI file '" + cur + "' holds no database"};
+      if (t.db.empty()) { t.wn_lo = one.wn_lo; t.wn_hi = one.wn_hi; }
+      t.wn_lo = std::min(t.wn_lo, one.wn_lo);
+      t.wn_hi = std::max(t.wn_hi, one.wn_hi);
+      for (auto &db : one.db) t.db.push_back(std::move(db));
+      cur.clear();
+    };
+    for (char ch : paths) {
+      if (ch == ',' || ch == ' ' || ch == '\t') flush();
+      else cur.push_back(ch);
+    }
+    flush();
+  }
+  const std::string &path = paths;
+  if (t.db.empty()) throw IoError{"linedb '" + path + "' names no TLI file"};
+  if ((int)t.db.size() > kMaxGroup) throw IoError{"TLI file(s): too many databases"};
   LblDev &d = b->dev;
   std::vector<double> nu0, elow, gf, ztab, ztemp;
   std::vector<int> liso;

@@ -54,8 +54,9 @@ struct Lbl {
   ~Lbl();
 };
 
-// Reads the TLI named by the cfg's `linedb`, uploads the lines.
-void lbl_init(Engine &e, const std::string &path);
+// Reads the TLI file(s) named by the cfg's `linedb` (comma / blank separated), merges
+// their databases, uploads the lines.
+void lbl_init(Engine &e, const std::string &paths);
 // ext[w][l][W_local] (atm layer order) for nwalkers profiles, into e.lbl->d_ext.
 void lbl_extinction(Engine &e, const double *d_prof, int nwalkers, hipStream_t st);
 // Fused lazy form for eclipse spectra: per wavenumber tile the layers are

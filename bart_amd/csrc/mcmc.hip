@@ -26,8 +26,11 @@ void mcmc_run(Engine &e, int nch, int npars, long nsteps, const double *params, 
   if (nch < 1 || npars < 1 || nsteps < 1) throw IoError{"mcmc_run: bad sizes"};
   if (ndata != e.step->nfilters) throw IoError{"mcmc_run: data length must equal the number of filters"};
   std::vector<int> free_;
-  for (int j = 0; j < npars; j++)
+  for (int j = 0; j < npars; j++) {
+    if (stepsize[j] < 0)
+      throw IoError{"mcmc_run: stepsize < 0 (a shared parameter in MC3's convention) is not supported"};
     if (stepsize[j] > 0) free_.push_back(j);
+  }
   const int nfree = (int)free_.size();
   std::mt19937_64 rng(seed);
   std::normal_distribution<double> normal(0.0, 1.0);
@@ -65,9 +68,10 @@ void mcmc_run(Engine &e, int nch, int npars, long nsteps, const double *params, 
       out[rows[k]] = sentinel ? inf : c;
     }
   };
+  // the box applies to the free parameters; a fixed one keeps its configured value
   auto clip = [&](std::vector<double> &p) {
     for (int i = 0; i < nch; i++)
-      for (int j = 0; j < npars; j++) {
+      for (int j : free_) {
         double &v = p[(size_t)i * npars + j];
         v = std::min(std::max(v, pmin[j]), pmax[j]);
       }
@@ -138,7 +142,7 @@ void mcmc_run(Engine &e, int nch, int npars, long nsteps, const double *params, 
         for (int j : free_) pi[j] = xi[j] + gam * (x1[j] - x2[j]) + 1e-3 * stepsize[j] * normal(rng);
       }
       inside[i] = 1;
-      for (int j = 0; j < npars; j++) inside[i] = inside[i] && pi[j] >= pmin[j] && pi[j] <= pmax[j];
+      for (int j : free_) inside[i] = inside[i] && pi[j] >= pmin[j] && pi[j] <= pmax[j];
     }
     chisq_of(prop, inside, cp);
     for (int i = 0; i < nch; i++) {

@@ -1,0 +1,711 @@
+// Specialised eclipse kernels (compile-time ray-angle / molecule / CIA counts and
+// integration rule), shared by the per-rule translation units rt_eclipse_i*.hip.
+//
+//  rt_eclipse_fast   one lane per (walker, wavenumber) walks the layers from the
+//                    top: buffer loads with scalar plane offsets, two pairs of
+//                    register slots in flight, layer records from LDS.
+//  rt_eclipse_split  5-8 walkers: producer / consumer wave pair per column.
+//  rt_eclipse_quad   1-4 walkers: 16 wavenumbers x 4 layers (or 8 x 8) per wave
+//                    and step, the optical depth by a lane-row prefix scan.
+//
+// INTEG: the integration rule (integ.hpp).  Rule 0 is the tuned default; rules 1
+// and 2 are the same walks with another accumulation (the bench runs rule 0).
+#pragma once
+#include "integ.hpp"
+#include "kernels.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+#include <utility>
+
+// upper bound on resident waves per SIMD the specialised kernels are compiled
+// for: lets the compiler spend registers on loads in flight (measured best: 3-4)
+#ifndef BARTRT_WPE
+#define BARTRT_WPE 4
+#endif
+
+namespace bartrt {
+
+// Kernel choice by 64-wavenumber columns per launch (measured at W = 1e4, L = 100:
+// 157 columns per walker; microseconds per launch, quad-layer / split / single-wave):
+//   1 walker 26 / 39 / 54     2 walkers 33 / 38 / 48     4 walkers 45 / 47 / 50
+//   5 walkers 54 / 52 / 52    6 walkers 58 / 53 / 55     8 walkers 73 / 68 / 75
+//   9 walkers 81 / 80 / 80    10 walkers 90 / 85 / 84  (single-wave from here on)
+constexpr long kQuadMaxColumns = 640;
+constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this: 1 walker 23 us, 2 walkers 30 us
+constexpr long kSplitMaxColumns = 1300;
+
+// ---------------------------------------------------------------------------
+// XCD-aware block -> (tile, walker) map.  Blocks b and b+8 share an XCD (and
+// its L2), so all walkers of one wavenumber tile are placed on one XCD, walker
+// index fastest: they stream the same grid rows at about the same time and
+// the XCD's L2 serves the repeats.
+__device__ inline void block_to_work(int b, int nwalkers, int &tile, int &walker) {
+  const int xcd = b & 7, j = b >> 3;
+  walker = j % nwalkers;
+  tile = (j / nwalkers) * 8 + xcd;
+}
+
+// LDS beyond the layer records: rule 1 keeps the Simpson weights of the radius grid
+template <int INTEG>
+__host__ __device__ inline size_t integ_lds_doubles(int L) {
+  return INTEG == kIntegSimpson ? simpson_lds_doubles(L) : 0;
+}
+
+// Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
+// bases (SGPR) + one 32-bit lane offset for every load, and two pairs of
+// register slots of 2M+2C loads kept in flight ahead of the arithmetic, so that
+// the one or two waves a SIMD holds at small batch sizes cover the HBM latency
+// by themselves.
+// SQ: the last ray angle has exactly half the cosine of the first (launch_rt
+// orders them so; 0 and 60 degrees of the usual raygrid), so its transmittance
+// is the first one's square: exp(-2 tau / mu) = exp(-tau / mu)^2 -- one
+// multiplication instead of one of the six exponentials of a layer.
+template <int AT, int MT, int CT, bool SQ, int INTEG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+void rt_eclipse_fast(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NR = NLD > 0 ? NLD : 1;
+  const int L = p.L, W = p.W;
+  int tile, w;
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  const double *sW = smem + (size_t)L * NC + (size_t)L * NI;  // rule 1 only
+  {
+    const double *gC = p.coef + (size_t)w * L * NC;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, blockDim.x);
+  }
+  __syncthreads();
+  if (INTEG == kIntegSimpson) {
+    simpson_radius_weights(const_cast<double *>(sW), sC, NC, L, threadIdx.x, blockDim.x);
+    __syncthreads();
+  }
+
+  const int i = tile * blockDim.x + threadIdx.x;
+  const bool valid = i < W;
+  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
+  const double nu = p.wn[ii];
+  const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+  const double nu4 = (nu * nu) * (nu * nu);
+  const TableLoader<M, C> tab(p, ii, sI);
+  auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
+
+  TauColumn<INTEG> tc;
+  ColumnIntens<INTEG, A> ci;
+  double Bprev = 0.0;
+  bool active = true;
+  const int kend = p.kstop[w];
+  const double tcap = tau_cap(p, A);
+
+  // One layer's arithmetic.  Straight-line: layer indices past the end are
+  // clamped and masked instead of branched around, so that inside an unrolled
+  // block the compiler waits (counted vmcnt) on exactly the loads a layer
+  // needs and leaves the younger ones in flight.
+  // The record of a layer is read from LDS one layer ahead (cf / cfn alternate
+  // between two register sets), so its latency is not waited out at the head of
+  // the layer that uses it; masking by multiplication keeps the reads of the
+  // path length and of c2/T out of conditional blocks.
+  auto read_rec = [&](int k, double (&cf)[NC]) {
+    const double *c = sC + (k < kend ? k : kend) * NC;
+#pragma unroll
+    for (int j = 0; j < NC; j++) cf[j] = c[j];
+  };
+  auto layer = [&](int k, const double (&r)[NR], const double (&cf)[NC], double (&cfn)[NC]) {
+    const bool live = active && k <= kend;
+    read_rec(k + 1, cfn);
+    const double lv = live ? 0.5 : 0.0;
+    double e = cf[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+    for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
+    tc.layer(k, live, lv, e, cf[0], sW);
+    // Planck exponent and the A slant-path exponents in one interleaved batch
+    const double tcl = fmin(tc.tau, tcap);
+    constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
+    double xs[AE + 1], ex[AE + 1], es[A];
+    xs[AE] = fmin(cf[1] * nu, 700.0);
+#pragma unroll
+    for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
+    exp_rt_n<AE + 1>(xs, ex);
+#pragma unroll
+    for (int a = 0; a < AE; a++) es[a] = ex[a];
+    if (SQ) es[A - 1] = ex[0] * ex[0];
+    const double B = bnum * rcp_core(ex[AE] - 1.0);
+    ci.layer(A, live, lv, tc.tau, Bprev, B, es);
+    Bprev = B;
+    active = active && !(live && tc.tau > p.toomuch);
+  };
+  auto clampk = [&](int k) { return k < kend ? k : kend; };
+
+  // two pairs of slots; each pair is reloaded two layers before it is used and
+  // the loads that cross the loop's back edge were issued two layers earlier
+  double a0[NR], a1[NR], b0[NR], b1[NR];
+  load_layer(clampk(0), a0);
+  load_layer(clampk(1), a1);
+  double cfE[NC], cfO[NC];
+  read_rec(0, cfE);
+  int k0 = 0;
+  for (; k0 <= kend; k0 += 4) {
+    load_layer(clampk(k0 + 2), b0);
+    load_layer(clampk(k0 + 3), b1);
+    layer(k0, a0, cfE, cfO);
+    layer(k0 + 1, a1, cfO, cfE);
+    load_layer(clampk(k0 + 4), a0);
+    load_layer(clampk(k0 + 5), a1);
+    layer(k0 + 2, b0, cfE, cfO);
+    layer(k0 + 3, b1, cfO, cfE);
+    if (!__any(active)) break;
+  }
+  const double F = ci.flux(p, A, p.cloud_on && active, Bprev, L, nullptr);
+  if (valid) p.spec[(size_t)w * W + i] = F;
+  if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
+    p.walked_out[(size_t)w * p.ntiles + tile] = (k0 + 4 < kend + 1 ? k0 + 4 : kend + 1);
+}
+
+// Few-walker variant (5-8 walkers at W = 1e4; below that the quad-layer
+// kernel is faster still): the layer loop is split over TWO waves per 64
+// wavenumbers.  Wave 0 (producer) streams the tables and advances the optical
+// depth and the Planck term; wave 1 (consumer) turns each tau into the A
+// transmittances and accumulates the intensities.  The halves are about equal
+// in issue slots, so the serial time per layer halves at unchanged total work
+// -- it pays while the single-wave columns cannot load the 1 024 SIMDs evenly
+// (8 walkers: 68 vs 75 us; from 9 walkers on the single-wave kernel is as fast).
+// Hand-off: an LDS ring of two 4-layer halves per lane -- rule 0:
+// [tau, (B_{k-1}+B_k)/2 * live], rules 1 / 2: [tau, live ? B_k : -1] -- and ONE
+// raw workgroup barrier per 4 layers (the consumer reads half b while the
+// producer fills half b+1).
+template <int AT, int MT, int CT, bool SQ, int INTEG>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+void rt_eclipse_split(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NR = NLD > 0 ? NLD : 1;
+  const int L = p.L, W = p.W;
+  int tile, w;
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  double *sX = smem + (size_t)L * NC + (size_t)L * NI;  // [2 halves][4 layers][tau, hb][64]
+  int *sFlag = reinterpret_cast<int *>(sX + 1024);      // [half] producer saw every lane finished
+  double *sEnd = sX + 1024 + 2;                         // [64] B of the last layer (cloud deck term)
+  const double *sW = sEnd + 64;                         // rule 1 only
+  {
+    const double *gC = p.coef + (size_t)w * L * NC;
+    const idx_t *gI = p.idx + (size_t)w * L * NI;
+    stage2_to_lds(sC, gC, L * NC, sI, gI, L * NI, threadIdx.x, 128);
+    if (threadIdx.x < 2) sFlag[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (INTEG == kIntegSimpson) {
+    simpson_radius_weights(const_cast<double *>(sW), sC, NC, L, threadIdx.x, 128);
+    __syncthreads();
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
+  const int i = tile * 64 + lane;
+  const bool valid = i < W;
+  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
+  const int kend = p.kstop[w];
+  const int nblk = kend / 4 + 1;  // 4-layer blocks; both waves run the same count
+
+  if (role == 0) {
+    // ---------------- producer: extinction, tau, Planck ----------------
+    const double nu = p.wn[ii];
+    const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+    const double nu4 = (nu * nu) * (nu * nu);
+    const TableLoader<M, C> tab(p, ii, sI);
+    auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
+    TauColumn<INTEG> tc;
+    double Bprev = 0.0;
+    bool active = true;
+    auto layer = [&](int k, const double (&r)[NR]) {
+      const int kc = k < kend ? k : kend;
+      const bool live = active && k <= kend;
+      const double *c = sC + kc * NC;
+      double cf[NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) cf[j] = c[j];
+      const double lv = live ? 0.5 : 0.0;
+      double e = cf[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+      for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
+      tc.layer(k, live, lv, e, cf[0], sW);
+      const double B = bnum * rcp_core(exp_rt(fmin(cf[1] * nu, 700.0)) - 1.0);
+      double *slot = sX + (k & 7) * 128;   // half (k/4)&1, layer k&3
+      slot[lane] = tc.tau;
+      slot[64 + lane] = INTEG == kIntegTransmittance ? (Bprev + B) * lv : (live ? B : -1.0);
+      Bprev = B;
+      active = active && !(live && tc.tau > p.toomuch);
+    };
+    // LDS writes of a 4-layer block complete, then meet the consumer (raw
+    // barrier: a __syncthreads() fence would also drain the table loads in flight)
+    auto handoff = [&]() {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    auto clampk = [&](int k) { return k < kend ? k : kend; };
+    double a0[NR], a1[NR], b0[NR], b1[NR];
+    load_layer(clampk(0), a0);
+    load_layer(clampk(1), a1);
+    int blk = 0;
+    for (; blk < nblk; blk++) {
+      const int k0 = blk * 4;
+      load_layer(clampk(k0 + 2), b0);
+      load_layer(clampk(k0 + 3), b1);
+      layer(k0, a0);
+      layer(k0 + 1, a1);
+      load_layer(clampk(k0 + 4), a0);
+      load_layer(clampk(k0 + 5), a1);
+      layer(k0 + 2, b0);
+      layer(k0 + 3, b1);
+      // the exit decision travels with the block, so both waves leave after
+      // the same barrier
+      const bool stop = !__any(active);
+      if (lane == 0) sFlag[blk & 1] = stop ? 1 : 0;
+      handoff();
+      if (stop) break;
+    }
+    sEnd[lane] = (p.cloud_on && active) ? Bprev : 0.0;
+    handoff();
+    if (p.walked_out && lane == 0)
+      p.walked_out[(size_t)w * p.ntiles + tile] = (4 * blk + 4 < kend + 1 ? 4 * blk + 4 : kend + 1);
+  } else {
+    // ---------------- consumer: transmittances and intensities ----------------
+    ColumnIntens<INTEG, A> ci;
+    const double tcap = tau_cap(p, A);
+    for (int blk = 0; blk < nblk; blk++) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int stop = sFlag[blk & 1];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double *slot = sX + ((blk & 1) * 4 + u) * 128;
+        const double tau = slot[lane], hb = slot[64 + lane];
+        const double tcl = fmin(tau, tcap);
+        constexpr int AE = SQ ? A - 1 : A;
+        double xs[AE], es[A];
+#pragma unroll
+        for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
+        {
+          double ex[AE];
+          exp_rt_n<AE>(xs, ex);
+#pragma unroll
+          for (int a = 0; a < AE; a++) es[a] = ex[a];
+          if (SQ) es[A - 1] = ex[0] * ex[0];
+        }
+        if constexpr (INTEG == kIntegTransmittance) {
+#pragma unroll
+          for (int a = 0; a < A; a++) {
+            ci.I[a] = fma(hb, ci.fprev[a] - es[a], ci.I[a]);
+            ci.fprev[a] = es[a];
+          }
+        } else {
+          const bool live = hb >= 0.0;   // the producer's "layer counts" flag
+          ci.layer(A, live, live ? 0.5 : 0.0, tau, 0.0, live ? hb : 0.0, es);
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane(stop)) break;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const double bsurf = sEnd[lane];   // > 0: the deck was reached below toomuch
+    const double F = ci.flux(p, A, bsurf != 0.0, bsurf, L, nullptr);
+    if (valid) p.spec[(size_t)w * W + i] = F;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Quad-layer variant: a wave takes 16 wavenumbers and FOUR layers at a time.
+// Lane (q = l / 16, m = l % 16) owns wavenumber m in the layers j = 4 s + q: per
+// step s the four lane rows load and evaluate four consecutive layers side by
+// side, the optical depth is a 4-lane prefix sum on top of the running value of
+// the previous step (the wavefront scan of the tau integral), and every lane
+// turns its own tau into its layer's Planck term and A transmittances.  The
+// previous layer's values a trapezoid step needs come from the lane row below
+// (row 3 of the previous step for row 0).  Same arithmetic per (layer,
+// wavenumber) as the single-wave kernel, but a column is 25 steps deep instead
+// of 100 layers, and a launch is made of four times as many, four times shorter
+// waves: ten walkers are 6 250 of them over 1 024 SIMDs instead of 1 570 that
+// leave half of the SIMDs with two and half with one.  The `toomuch` exit is
+// per 16 wavenumbers and per step of four layers.
+// R = lane rows = layers per step (4, or 8 for the smallest launches: 8
+// wavenumbers x 8 layers per wave, twice the waves, half the depth).
+//
+// Rule 1 (Simpson) in this layout: the panel that ends on layer j is evaluated by
+// the lane that owns j, from the values of the rows q-1 and q-2 (the two carries
+// of rows 0 / 1 come from the previous step); R is even, so a lane's panels all
+// end on the parity of q and each lane keeps ONE sum.  The padded point falls to
+// the row after the one that passed `toomuch` (row 0 of the next step when that
+// was the last row), and at the end the rows whose parity is that of the last
+// point's index are added up.  The optical depth is the prefix sum of the even
+// rows' radius panels plus, on odd rows, the trapezoid of the last interval.
+template <int AT, int MT, int CT, bool SQ, int R, int INTEG>
+__global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
+  static_assert(!(SQ && INTEG != kIntegTransmittance), "the squared-transmittance shortcut is built for rule 0 only");
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
+  constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
+  constexpr int WN = 64 / R;           // wavenumbers per wave
+  constexpr bool SIMPSON = INTEG == kIntegSimpson;
+  const int L = p.L, W = p.W;
+  int tile, w;
+  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  const double *sW = smem + (size_t)L * NC + (size_t)L * NI;  // rule 1 only
+  stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
+                threadIdx.x, 256);
+  __syncthreads();
+  if (SIMPSON) {
+    simpson_radius_weights(const_cast<double *>(sW), sC, NC, L, threadIdx.x, 256);
+    __syncthreads();
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int q = lane / WN, m = lane % WN;
+  const int i0 = (tile * 4 + (threadIdx.x >> 6)) * WN;  // this wave's first wavenumber
+  if (i0 >= W) return;
+  const unsigned ii = i0 + m < W ? (unsigned)(i0 + m) : (unsigned)(W - 1);
+  const double nu = p.wn[ii];
+  const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+  const double nu4 = (nu * nu) * (nu * nu);
+  const int kend = p.kstop[w];
+  const double tcap = tau_cap(p, A);
+
+  // per-lane table addressing: plane offset of the lane's layer + row + lane
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
+  const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
+  auto load_layer = [&](int j, double (&r)[NR]) {
+    const idx_t *ix = sI + j * NI;
+    if (M > 0) {
+      const idx_t mine = ix[0];
+      const long long base = p.window ? row_window_base<R>(mine) : 0ll;
+      const unsigned long long left = p.kappa_bytes - (unsigned long long)base;
+      const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.kappa) + base), 0,
+          (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+      const unsigned po = (unsigned)(mine - base) + off;
+#pragma unroll
+      for (int mm = 0; mm < M; mm++) {
+        r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
+        r[2 * mm + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + planeB + mm * rowB), 0, 0));
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const unsigned po = (unsigned)ix[1 + cc] + off;
+      r[2 * M + 2 * cc] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)po, 0, 0));
+      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)(po + rowB), 0, 0));
+    }
+  };
+  auto clampk = [&](int k) { return k < kend ? k : kend; };
+
+  // the lanes of one wavenumber: bits m, WN + m, 2 WN + m, ... of a ballot
+  const unsigned long long col_bits = (R == 4 ? 0x0001000100010001ull : 0x0101010101010101ull) << m;
+  const unsigned long long below_bits = col_bits & ((1ull << (WN * q)) - 1ull);
+  const int from_below = (lane + 64 - WN) & 63;       // row q - 1 (the last row for row 0)
+  const int from_below2 = (lane + 64 - 2 * WN) & 63;  // row q - 2 (rule 1)
+
+  double I[A];
+#pragma unroll
+  for (int a = 0; a < A; a++) I[a] = 0.0;
+  double Fs = 0.0;  // surface term of a cloud deck (one lane per wavenumber sets it)
+  // carries of row 0: extinction, Planck term, transmittances of the layer just
+  // above this step (row R - 1 of the previous step), and the optical depth there
+  double c_e = 0.0, c_B = 0.0, c_E[AE], c_tau = 0.0;
+#pragma unroll
+  for (int a = 0; a < AE; a++) c_E[a] = 1.0;
+  // rule 1: second carries (row R - 2 / R - 1 of the previous step for rows 0 / 1),
+  // the running even-index Simpson sum of the optical depth, the index of the last
+  // point of the intensity integral and the "next step's row 0 is the padded point" flag
+  double c2_e = 0.0, c2_tau = 0.0, c_y[A], c2_y[A], c_S = 0.0;
+#pragma unroll
+  for (int a = 0; a < A; a++) { c_y[a] = 0.0; c2_y[a] = 0.0; }
+  int nend = kend;
+  bool pad_next = false;
+  bool active = true;  // no layer above this step passed `toomuch` (per wavenumber, all rows agree)
+
+  auto step = [&](int s, const double (&rv)[NR]) {
+    const int j = R * s + q, jc = clampk(j);
+    const bool inrange = j <= kend;
+    const double *c = sC + jc * NC;
+    double cf[NC];
+#pragma unroll
+    for (int x = 0; x < NC; x++) cf[x] = c[x];
+    double e = cf[2 + 2 * M + 2 * C] * nu4;
+#pragma unroll
+    for (int x = 0; x < NLD; x++) e = fma(cf[2 + x], rv[x], e);
+    // extinction of the layer above
+    const double e_below = __shfl(e, from_below);
+    const double eprev = q == 0 ? c_e : e_below;
+    c_e = e_below;
+    const double tau_above_step = c_tau;   // optical depth of row R - 1 of the previous step
+    double tau;
+    if constexpr (!SIMPSON) {
+      // optical depth: R-lane prefix sum of the step's increments + the running value
+      double v = (eprev + e) * cf[0] * ((inrange && active) ? 0.5 : 0.0);
+#pragma unroll
+      for (int d = 1; d < R; d <<= 1) {
+        const double t = __shfl(v, (lane + 64 - d * WN) & 63);
+        if (q >= d) v += t;
+      }
+      tau = c_tau + v;
+    } else {
+      // even rows contribute the radius panel that ends on them; odd rows add the
+      // trapezoid of their last interval on top of the even sum below them
+      const double e_below2 = __shfl(e, from_below2);
+      const double e2 = q < 2 ? c2_e : e_below2;
+      c2_e = e_below2;
+      const double *wS = sW + 3 * jc;
+      double v = ((q & 1) == 0 && j >= 2 && inrange && active)
+                     ? fma(wS[0], e2, fma(wS[1], eprev, wS[2] * e)) : 0.0;
+#pragma unroll
+      for (int d = 1; d < R; d <<= 1) {
+        const double t = __shfl(v, (lane + 64 - d * WN) & 63);
+        if (q >= d) v += t;
+      }
+      const double S = c_S + v;
+      c_S = __shfl(S, (R - 1) * WN + m);
+      tau = (q & 1) ? fma((eprev + e) * cf[0], 0.5, S) : S;
+    }
+    c_tau = __shfl(tau, (R - 1) * WN + m);
+    // which layers of this step are still above the cut
+    const unsigned long long over = __ballot(inrange && active && tau > p.toomuch);
+    const bool live = inrange && active && (over & below_bits) == 0ull;
+    // Planck term and transmittances of this lane's layer
+    const double tcl = fmin(tau, tcap);
+    double xs[AE + 1], ex[AE + 1];
+    xs[AE] = fmin(cf[1] * nu, 700.0);
+#pragma unroll
+    for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
+    exp_rt_n<AE + 1>(xs, ex);
+    const double B = bnum * rcp_core(ex[AE] - 1.0);
+    if constexpr (INTEG == kIntegTransmittance) {
+      // the layer above: row q - 1, or the carry for row 0
+      const double B_below = __shfl(B, from_below);
+      const double Bprev = q == 0 ? c_B : B_below;
+      c_B = B_below;
+      const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
+      double Eprev[A], E[A];
+#pragma unroll
+      for (int a = 0; a < AE; a++) {
+        const double E_below = __shfl(ex[a], from_below);
+        Eprev[a] = q == 0 ? c_E[a] : E_below;
+        c_E[a] = E_below;
+        E[a] = ex[a];
+      }
+      if (SQ) {
+        Eprev[A - 1] = Eprev[0] * Eprev[0];
+        E[A - 1] = E[0] * E[0];
+      }
+#pragma unroll
+      for (int a = 0; a < A; a++) I[a] = fma(hb, Eprev[a] - E[a], I[a]);
+      if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) {  // deck reached below toomuch
+#pragma unroll
+        for (int a = 0; a < A; a++) Fs = fma(p.wgt[a] * B, E[a], Fs);
+      }
+    } else {
+      // integrand of this lane's layer and of the one / two layers above it
+      const double tau_b1 = __shfl(tau, from_below);
+      const double tau1 = q == 0 ? tau_above_step : tau_b1;
+      double y[A], y1[A];
+#pragma unroll
+      for (int a = 0; a < A; a++) {
+        y[a] = B * ex[a];
+        const double yb = __shfl(y[a], from_below);
+        y1[a] = q == 0 ? c_y[a] : yb;
+        c_y[a] = yb;
+      }
+      if constexpr (INTEG == kIntegTrapzTau) {
+        const double h = (tau - tau1) * (live ? 0.5 : 0.0);
+#pragma unroll
+        for (int a = 0; a < A; a++) I[a] = fma(y1[a] + y[a], h, I[a]);
+      } else {
+        const double tau_b2 = __shfl(tau, from_below2);
+        const double tau2 = q < 2 ? c2_tau : tau_b2;
+        c2_tau = tau_b2;
+        double y2[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+          const double yb2 = __shfl(y[a], from_below2);
+          y2[a] = q < 2 ? c2_y[a] : yb2;
+          c2_y[a] = yb2;
+        }
+        // the cut: the first row of this wavenumber that passed toomuch
+        const unsigned long long mine = over & col_bits;
+        const int f = mine ? (int)(__ffsll((long long)mine) - 1) / WN : -1;
+        const bool cut_here = active && f >= 0;
+        // the padded point: the row after the cut (row 0 of the next step when the
+        // cut was the last row), as long as the atmosphere has a layer there
+        const bool pad = j < L && ((cut_here && q == f + 1) || (pad_next && q == 0));
+        if (cut_here) nend = R * s + f + ((R * s + f + 1 < L) ? 1 : 0);
+        pad_next = cut_here && f == R - 1;
+        const double x = pad ? tau1 + 1.0 : tau;
+        double w0, w1, w2;
+        simpson_tau_weights(tau1 - tau2, x - tau1, w0, w1, w2);
+        if (j == 1) { w0 = 0.0; w1 = 0.5 * (x - tau1); w2 = w1; }  // the first interval: a trapezoid
+        const bool counts = (live || pad) && j >= 1;
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+          const double cterm = fma(w0, y2[a], fma(w1, y1[a], w2 * (pad ? 0.0 : y[a])));
+          I[a] += counts ? cterm : 0.0;
+        }
+      }
+      if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) {  // deck reached below toomuch
+#pragma unroll
+        for (int a = 0; a < A; a++) Fs = fma(p.wgt[a], y[a], Fs);
+      }
+    }
+    active = active && (over & col_bits) == 0ull;
+  };
+
+  // rule 1 may need the row after the column's last layer for the padded point
+  const int klast = SIMPSON ? (kend + 1 < L ? kend + 1 : L - 1) : kend;
+  double ra[NR], rb[NR];
+  load_layer(clampk(q), ra);
+  int s = 0;
+  for (; R * s <= klast; s += 2) {
+    load_layer(clampk(R * (s + 1) + q), rb);
+    step(s, ra);
+    if (!__any(active || pad_next)) break;
+    load_layer(clampk(R * (s + 2) + q), ra);
+    if (R * (s + 1) <= klast) {
+      step(s + 1, rb);
+      if (!__any(active || pad_next)) { s++; break; }
+    }
+  }
+  // the rows of a wavenumber hold its layers' terms: sum them; row 0 writes
+  const bool mine_counts = !SIMPSON || ((q & 1) == (nend & 1));
+  double F = Fs;
+#pragma unroll
+  for (int a = 0; a < A; a++) {
+    const double scale = INTEG == kIntegTransmittance ? p.wgt[a] : p.wgt[a] * p.invmu[a];
+    F = fma(scale, mine_counts ? I[a] : 0.0, F);
+  }
+  for (int o = WN; o < 64; o <<= 1) F += __shfl_xor(F, o);
+  if (q == 0 && i0 + m < W) p.spec[(size_t)w * W + i0 + m] = F;
+  if (p.walked_out && lane == 0) {
+    const int layers = R * (s + 1) < kend + 1 ? R * (s + 1) : kend + 1;
+    p.walked_out[(size_t)w * (4 * p.ntiles) + tile * 4 + (threadIdx.x >> 6)] = layers;
+  }
+}
+
+// If one ray angle has exactly half the cosine of another (0 and 60 degrees of
+// the usual raygrid 0 20 40 60 80), put that pair first and last: the SQ kernels
+// take the last transmittance as the square of the first.
+inline bool order_angles_for_square(RtArgs &r) {
+  for (int i = 0; i < r.A; i++)
+    for (int j = 0; j < r.A; j++) {
+      if (i == j || std::fabs(r.invmu[j] - 2.0 * r.invmu[i]) > 8.9e-16 * r.invmu[j]) continue;
+      auto swap_angles = [&](int x, int y) {
+        std::swap(r.invmu[x], r.invmu[y]);
+        std::swap(r.wgt[x], r.wgt[y]);
+      };
+      swap_angles(0, i);
+      if (j == 0) j = i;  // the doubled angle sat in slot 0 and moved to i
+      swap_angles(r.A - 1, j);
+      return true;
+    }
+  return false;
+}
+
+// Launches the specialised kernel for this shape and batch size under rule INTEG;
+// returns false when the shape has none (the caller falls back to the generic
+// kernel).  `kmode`: forced variant (BARTRT_KERNEL), empty = by batch size.
+// info (optional): what was launched (name, wavenumbers per recorded column).
+template <int INTEG>
+bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::string &kmode, bool force_window,
+                    bool allow_sq, hipError_t &err, RtLaunchInfo *info) {
+  const int ntiles8 = (a.ntiles + 7) / 8 * 8;
+  const int nblocks = ntiles8 * a.nwalkers;
+  const size_t sh = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) + integ_lds_doubles<INTEG>(a.L)) +
+                    sizeof(idx_t) * (size_t)a.L * idx_stride(a.C);
+  // (the specialised kernels rebuild their buffer descriptor per layer, so the
+  // table may be of any size; one layer's pair of planes must stay below 4 GB)
+  const bool plane_ok = 2ull * a.M * a.W * 8ull < (1ull << 31);
+  if (!(a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
+  // (the producer/consumer kernel adds 9 kB of its own)
+  RtArgs b = a;
+  // the squared-transmittance shortcut is instantiated for the default rule only
+  const bool sq = INTEG == kIntegTransmittance && allow_sq && order_angles_for_square(b);
+  // too few single-wave columns to load the 1 024 SIMDs evenly -> several
+  // waves per 64 wavenumbers: four 16-wavenumber waves that take four layers at
+  // a time (quad-layer), or a producer / consumer pair
+  const long columns = (long)a.nwalkers * ((a.W + 63) / 64);
+  const int ntiles64 = (a.W + 63) / 64;
+  const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
+  // the quad-layer kernel addresses the tables with per-lane 32-bit offsets
+  // (a grid of 4 GB or more through a window that moves with the step's layers)
+  const bool octo = kmode == "octo" || (kmode.empty() && columns <= kOctoMaxColumns);
+  b.window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
+  const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, octo ? 8 : 4));
+  err = hipSuccess;
+  constexpr bool SQOK = INTEG == kIntegTransmittance;
+  if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
+    // the smallest launches take eight layers per step (8 wavenumbers per wave)
+    b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;
+    const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+    if (info) { info->kernel = octo ? "rt_eclipse_quad<R=8>" : "rt_eclipse_quad<R=4>"; info->wn_per_column = octo ? 8 : 16; info->ncolumns = 4 * b.ntiles; }
+#define BARTRT_QUAD(MM, CC)                                                                                          \
+  if (a.M == MM && a.C == CC) {                                                                                      \
+    if (octo) {                                                                                                      \
+      if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, SQOK, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
+      else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
+    } else {                                                                                                         \
+      if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, SQOK, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
+      else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
+    }                                                                                                                \
+    err = hipGetLastError();                                                                                         \
+    return true;                                                                                                     \
+  }
+    BARTRT_MC_LIST(BARTRT_QUAD)
+#undef BARTRT_QUAD
+  }
+  if (kmode == "split" || (kmode.empty() && columns <= kSplitMaxColumns)) {
+    b.ntiles = ntiles64;
+    const size_t shs = sh + sizeof(double) * (1024 + 2 + 64);
+    if (info) { info->kernel = "rt_eclipse_split"; info->wn_per_column = 64; info->ncolumns = b.ntiles; }
+#define BARTRT_SPLIT(MM, CC)                                                                                       \
+  if (a.M == MM && a.C == CC) {                                                                                    \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC, SQOK, INTEG>), dim3(nb64), dim3(128), shs, st, b);     \
+    else hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC, false, INTEG>), dim3(nb64), dim3(128), shs, st, b);       \
+    err = hipGetLastError();                                                                                       \
+    return true;                                                                                                   \
+  }
+    BARTRT_MC_LIST(BARTRT_SPLIT)
+#undef BARTRT_SPLIT
+  }
+  b.ntiles = a.ntiles;
+  if (info) { info->kernel = "rt_eclipse_fast"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
+#define BARTRT_FAST(MM, CC)                                                                                        \
+  if (a.M == MM && a.C == CC) {                                                                                    \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks), dim3(block), sh, st, b);  \
+    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, false, INTEG>), dim3(nblocks), dim3(block), sh, st, b);    \
+    err = hipGetLastError();                                                                                       \
+    return true;                                                                                                   \
+  }
+  BARTRT_MC_LIST(BARTRT_FAST)
+#undef BARTRT_FAST
+  return false;
+}
+
+}  // namespace bartrt

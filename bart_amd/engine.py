@@ -310,5 +310,22 @@ def timing_end():
     return ms.value, n.value
 
 
+def walked_begin():
+    """Record, for the eclipse launches that follow, how many layers each wave walks."""
+    _check(trm.lib().bartrt_walked_begin())
+
+
+def walked_end():
+    """-> (walked[nwalkers, ncolumns], wavenumbers per column, kernel name) of the last launch."""
+    n, nc, wpc = C.c_int(), C.c_int(), C.c_int()
+    name = C.create_string_buffer(128)
+    _check(trm.lib().bartrt_walked_end(None, 0, C.byref(n), C.byref(nc), C.byref(wpc), name, 128))
+    # the record itself (the first call switched recording off; the buffer stays)
+    out = np.zeros((n.value, nc.value), np.int32)
+    if out.size:
+        _check(trm.lib().bartrt_walked_end(_ptr(out), out.size, C.byref(n), C.byref(nc), C.byref(wpc), name, 128))
+    return out, wpc.value, name.value.decode()
+
+
 def algorithmic_bytes(nwalkers: int) -> float:
     return trm.lib().bartrt_algorithmic_bytes(int(nwalkers))

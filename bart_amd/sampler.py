@@ -64,11 +64,21 @@ def gelman_rubin(chains: np.ndarray) -> np.ndarray:
         return np.sqrt(((n - 1) / n * W + B / n) / W)
 
 
+def _check_stepsize(stepsize):
+    """MC3 reads a negative stepsize as "shared with parameter -stepsize" (its
+    `stepsize` key, examples/demo/BART_eclipse.cfg:84-87); shared parameters are
+    not implemented here and must not be mistaken for fixed ones."""
+    if (np.asarray(stepsize) < 0).any():
+        raise ValueError("stepsize < 0 (a parameter shared with another one, in MC3's convention) "
+                         "is not supported: give every parameter its own stepsize, or 0 to fix it")
+
+
 def run(model, cfg: SamplerConfig, log=None):
     """model(params[nchains, npars]) -> bandflux[nchains, ndata] (-1 rows = rejected).
     Returns dict(chain [nchains, nsteps, npars], chisq [nchains, nsteps], bestp,
     best_chisq, accept_rate, grstat)."""
     rng = np.random.default_rng(cfg.seed)
+    _check_stepsize(cfg.stepsize)
     free = np.where(cfg.stepsize > 0)[0]
     nfree, nch = len(free), cfg.nchains
     nsteps = max(1, int(np.ceil(cfg.numit / nch)))
@@ -87,7 +97,10 @@ def run(model, cfg: SamplerConfig, log=None):
     # start: the configured point jittered by the stepsizes, inside the box
     x = np.tile(cfg.params, (nch, 1))
     x[:, free] += cfg.stepsize[free] * rng.normal(size=(nch, nfree))
-    x = np.clip(x, cfg.pmin, cfg.pmax)
+    # the box applies to the free parameters; a fixed one keeps its configured
+    # value even outside [pmin, pmax]
+    clip_free = lambda v: np.clip(v[:, free], cfg.pmin[free], cfg.pmax[free])
+    x[:, free] = clip_free(x)
     x[0] = cfg.params
     c = chisq_of(x)
     for _ in range(20):                      # re-draw chains that start on a rejected model
@@ -97,7 +110,7 @@ def run(model, cfg: SamplerConfig, log=None):
         xb = np.tile(cfg.params, (int(bad.sum()), 1))
         xb[:, free] += 0.1 * cfg.stepsize[free] * rng.normal(size=(len(xb), nfree))
         x[bad] = xb
-        x = np.clip(x, cfg.pmin, cfg.pmax)
+        x[:, free] = clip_free(x)
         c = chisq_of(x)
     if not np.isfinite(c).any():
         raise RuntimeError("no chain starts on a physical model: check params/pmin/pmax")
@@ -125,7 +138,8 @@ def run(model, cfg: SamplerConfig, log=None):
     for t0 in range(0, nsteps, B):
         nb = min(B, nsteps - t0)
         me = np.broadcast_to(idx, (nb, nch))
-        r1 = others(me[..., None])
+        # a lone chain has no partner: the difference term vanishes, the jitter moves it
+        r1 = others(me[..., None]) if nch > 1 else me
         r2 = others(np.stack([me, r1], axis=-1)) if nch > 2 else r1
         z = others(np.stack([me, r1, r2], axis=-1)) if snooker else None
         jit = 1e-3 * step_free * rng.normal(size=(nb, nch, nfree))
@@ -152,7 +166,7 @@ def run(model, cfg: SamplerConfig, log=None):
                 gam = 1.0 if t % 10 == 0 else gamma0
                 pf = xf + gam * (xf[r1[b]] - xf[r2[b]]) + jit[b]
             prop[:, free] = pf
-            inside = ((prop >= pmin) & (prop <= pmax)).all(axis=1)
+            inside = ((pf >= pmin[free]) & (pf <= pmax[free])).all(axis=1)
             if inside.all():
                 cp = chisq_of(prop)
             else:
@@ -185,6 +199,7 @@ def run_native(worker, cfg: SamplerConfig, log=None):
     if hi - lo != worker.nwave:
         raise ValueError("run_native: the engine is sharded; use run()")
     nch = cfg.nchains
+    _check_stepsize(cfg.stepsize)
     nsteps = max(1, int(np.ceil(cfg.numit / nch)))
     npars = len(cfg.params)
     a = lambda v: np.ascontiguousarray(v, np.double)

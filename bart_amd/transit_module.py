@@ -82,6 +82,8 @@ def lib():
         L.bartrt_get_tau.argtypes = [p, p, i, i]
         L.bartrt_get_lbl_extinction.argtypes = [p, i, p, i, i]
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
+        L.bartrt_set_integ.argtypes = [i]
+        L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
         L.bartrt_algorithmic_bytes.argtypes = [i]
         L.bartrt_algorithmic_bytes.restype = d
         _lib = L
@@ -137,3 +139,19 @@ def run_transit(profiles, nwave):
 
 def free_memory():
     check(lib().bartrt_free_memory())
+
+
+# ---- beyond the reference module ----------------------------------------
+INTEG_RULES = ("transmittance", "simpson", "trapz_tau")
+
+
+def set_integ(rule):
+    """Integration rule of the eclipse geometry (include/bartrt.h, bartrt_set_integ):
+    0 / 'transmittance' (default), 1 / 'simpson' (SURVEY.md App. A-4), 2 / 'trapz_tau'."""
+    if isinstance(rule, str):
+        rule = INTEG_RULES.index(rule)
+    check(lib().bartrt_set_integ(int(rule)))
+
+
+def get_integ() -> int:
+    return check(lib().bartrt_get_integ())

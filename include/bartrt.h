@@ -64,6 +64,17 @@ int bartrt_run_transit(const double *prof, int nprof, double *spec, int nwave);
 /* trm.free_memory()  [BARTfunc.py:406]. */
 int bartrt_free_memory(void);
 
+/* Integration rule of the eclipse geometry (no counterpart in the reference's
+ * module: its engine, whose source would settle the rule, is an empty submodule --
+ * DESIGN.md conventions C6 / C8).  0 = trapezoid in the transmittance (default);
+ * 1 = the Simpson / trapezoid hybrid of SURVEY.md App. A-4 for the optical depth
+ * (over radius) and for B exp(-tau/mu) (over tau, zero-padded past `last`);
+ * 2 = plain trapezoid in tau of B exp(-tau/mu).  Also the cfg key `integ` (number
+ * or transmittance / simpson / trapz_tau) and the environment variable
+ * BARTRT_INTEG, read by bartrt_init; every eclipse kernel is built for each rule. */
+int bartrt_set_integ(int rule);
+int bartrt_get_integ(void);
+
 /* ---- batched / device-resident variants (same arithmetic) ------------- */
 
 /* nwalkers profiles -> nwalkers spectra; ok[w] = 0 marks a profile the
@@ -177,6 +188,14 @@ int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext,
  * begin resets; end returns accumulated device ms and launch count. */
 int bartrt_timing_begin(void);
 int bartrt_timing_end(double *kernel_ms, int *nlaunch);
+/* Diagnostics for the byte model of bench.py: between begin and end every eclipse
+ * launch records how many layers each wave walked before all its lanes passed
+ * `toomuch`.  end returns the record of the LAST launch: walked[nwalkers][ncolumns]
+ * (columns of wn_per_column consecutive wavenumbers, as the launched kernel tiles
+ * the grid) and that kernel's name. */
+int bartrt_walked_begin(void);
+int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *wn_per_column,
+                      char *kernel, int kernel_len);
 /* algorithmic bytes one launch of the RT kernel moves for `nwalkers`
  * (2*L*W*M*8 + 2*L*W*8*ncia + (S+1)*L*8 + W*8 per spectrum) */
 double bartrt_algorithmic_bytes(int nwalkers);

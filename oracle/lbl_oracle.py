@@ -80,7 +80,7 @@ class LblOracle:
         self.mass = np.array([mol["mass"][mol["name"].index(s)] for s in self.species])
         self.diam = np.array([mol["diam"][mol["name"].index(s)] for s in self.species]) * 1e-8
         self.molid = {n: i for n, i in zip(mol["name"], mol["id"])}
-        self.dbs = read_tli(k["linedb"])
+        self.dbs = [db for f in k["linedb"].replace(",", " ").split() for db in read_tli(f)]
         self.nwidth = float(k.get("nwidth", 20))
         self.ethresh = float(k.get("ethresh", 1e-6))
         lo, hi, d = float(k["wnlow"]), float(k["wnhigh"]), float(k.get("wndelt", 1.0))

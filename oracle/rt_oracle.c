@@ -182,56 +182,86 @@ int orc_extinction(const rt_oracle_cfg *c, const double *prof, double *ext,
   return 0;
 }
 
-/* Simpson's rule on a non-uniform grid x[0..n-1] (n points).  With an odd
- * number of intervals the first interval is taken by trapezoid and Simpson
- * panels cover the rest. */
-static double simpson_nu(const double *x, const double *y, int n) {
+/* One Simpson panel over the three points (x0, x0 + h0, x0 + h0 + h1); with a
+ * zero-width half it degenerates to the trapezoids of its two intervals. */
+static double simpson_panel(double h0, double h1, double y0, double y1, double y2) {
+  if (h0 == 0.0 || h1 == 0.0)
+    return 0.5 * h0 * (y0 + y1) + 0.5 * h1 * (y1 + y2);
+  double hs = h0 + h1;
+  return hs / 6.0 * (y0 * (2.0 - h1 / h0) + y1 * hs * hs / (h0 * h1) + y2 * (2.0 - h0 / h1));
+}
+
+/* Simpson / trapezoid hybrid on n points with interval widths h[0..n-2]
+ * (h[i] = x[i+1] - x[i]): an odd number of points is covered by Simpson
+ * panels; with an even number the FIRST interval is taken by a trapezoid and
+ * the panels cover the rest (the integrator recalled for
+ * Transit's tau and intensity integrals; unverified against source). */
+static double simps_hybrid(const double *h, const double *y, int n) {
   if (n < 2) return 0.0;
   double res = 0.0;
   int start = 0;
-  if (((n - 1) & 1) == 1) {
-    res += 0.5 * (x[1] - x[0]) * (y[0] + y[1]);
+  if ((n & 1) == 0) {
+    res += 0.5 * h[0] * (y[0] + y[1]);
     start = 1;
   }
-  for (int j = start; j + 2 <= n - 1; j += 2) {
-    double h0 = x[j + 1] - x[j], h1 = x[j + 2] - x[j + 1];
-    if (h0 == 0.0 || h1 == 0.0) { /* degenerate panel: fall back to trapezoid */
-      res += 0.5 * h0 * (y[j] + y[j + 1]) + 0.5 * h1 * (y[j + 1] + y[j + 2]);
-      continue;
-    }
-    double hs = h0 + h1;
-    res += hs / 6.0 * (y[j] * (2.0 - h1 / h0) + y[j + 1] * hs * hs / (h0 * h1) +
-                       y[j + 2] * (2.0 - h0 / h1));
-  }
+  for (int j = start; j + 2 <= n - 1; j += 2)
+    res += simpson_panel(h[j], h[j + 1], y[j], y[j + 1], y[j + 2]);
   return res;
 }
 
 /* Per-wavenumber column solve.  e_col[k], r_col[k], t_col[k] are indexed
  * from the TOP layer (k = 0) downwards.  Returns intensities per angle and
- * tau[k]; *last_out = index of the deepest layer included. */
+ * tau[k]; *last_out = index of the deepest layer included.
+ *
+ * integ = ORC_INTEG_TRAPZ (0, the default):
+ *   tau by trapezoid in radius from the top; I = int B d(exp(-tau/mu)),
+ *   trapezoid in the transmittance.
+ * integ = ORC_INTEG_SIMPSON (1), App. A-4 as recalled:
+ *   tau[k] = integral of the extinction from layer k up to the top by the
+ *   hybrid above, the points taken FROM LAYER k UPWARDS: with an even number of
+ *   points the trapezoid covers the interval next to layer k and the Simpson
+ *   panels end at the top, i.e. panels (0,1,2), (2,3,4), ... in this file's
+ *   top-down index, plus the trapezoid of (k-1, k) for odd k.
+ *   I(mu) = (1/mu) int B exp(-tau/mu) dtau by the same hybrid over the points
+ *   0 .. last taken from the top, padded by ONE point of zero integrand one
+ *   unit of tau beyond `last` when a layer exists there (n = min(last + 2, L)
+ *   points; no padding when the column ends on the bottom layer or on a cloud
+ *   deck reached below toomuch).
+ * integ = ORC_INTEG_TRAPZ_TAU (2): tau as in 0; I = (1/mu) int B exp(-tau/mu) dtau
+ *   by plain trapezoid over 0 .. last. */
 static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
                            const double *e_col, const double *r_col,
                            const double *t_col, int kcloud, double *tau,
                            double *intens, int *last_out) {
   const int A = c->nangles;
   int last = L - 1;
-  double *path = (double *)malloc(sizeof(double) * L);
-  for (int k = 0; k < L; k++) path[k] = r_col[0] - r_col[k]; /* depth from top */
+  double *dr = (double *)malloc(sizeof(double) * L);   /* dr[k] = r[k-1] - r[k] */
+  dr[0] = 0.0;
+  for (int k = 1; k < L; k++) dr[k] = r_col[k - 1] - r_col[k];
   tau[0] = 0.0;
   int kend = (kcloud >= 0) ? kcloud : L - 1;
+  double s_even = 0.0;   /* Simpson: tau at the last even index */
   for (int k = 1; k <= kend; k++) {
-    if (c->integ == ORC_INTEG_SIMPSON)
-      tau[k] = simpson_nu(path, e_col, k + 1);
-    else
-      tau[k] = tau[k - 1] + 0.5 * (e_col[k - 1] + e_col[k]) * (path[k] - path[k - 1]);
+    if (c->integ == ORC_INTEG_SIMPSON) {
+      if (k & 1) {
+        tau[k] = s_even + 0.5 * (e_col[k - 1] + e_col[k]) * dr[k];
+      } else {
+        s_even += simpson_panel(dr[k - 1], dr[k], e_col[k - 2], e_col[k - 1], e_col[k]);
+        tau[k] = s_even;
+      }
+    } else {
+      tau[k] = tau[k - 1] + 0.5 * (e_col[k - 1] + e_col[k]) * dr[k];
+    }
     if (tau[k] > c->toomuch) { last = k; break; }
     last = k;
   }
   if (kend == 0) last = 0;
   for (int k = last + 1; k < L; k++) tau[k] = tau[last]; /* not computed deeper */
-  double *f = (double *)malloc(sizeof(double) * L);
+  const int deck = kcloud >= 0 && last == kcloud && !(tau[last] > c->toomuch);
+  double *f = (double *)malloc(sizeof(double) * (L + 1));
   double *bk = (double *)malloc(sizeof(double) * L);
   double *ek = (double *)malloc(sizeof(double) * L);
+  double *hx = (double *)malloc(sizeof(double) * (L + 1));
   for (int k = 0; k <= last; k++) bk[k] = orc_planck(wn, t_col[k]);
   for (int a = 0; a < A; a++) {
     double mu = cos(c->angles_deg[a] * ORC_PI / 180.0);
@@ -241,7 +271,14 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
     }
     double I;
     if (c->integ == ORC_INTEG_SIMPSON) {
-      I = simpson_nu(tau, f, last + 1) / mu;
+      int n = last + 1;
+      for (int k = 0; k < last; k++) hx[k] = tau[k + 1] - tau[k];
+      if (!deck && last + 1 < L) { /* one padded point: integrand 0, one unit of tau further */
+        hx[last] = 1.0;
+        f[last + 1] = 0.0;
+        n = last + 2;
+      }
+      I = simps_hybrid(hx, f, n) / mu;
     } else if (c->integ == ORC_INTEG_TRAPZ_TAU) {
       I = 0.0;
       for (int k = 1; k <= last; k++) I += 0.5 * (f[k - 1] + f[k]) * (tau[k] - tau[k - 1]);
@@ -256,13 +293,14 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
       for (int k = 1; k <= last; k++) I += 0.5 * (bk[k - 1] + bk[k]) * (ek[k - 1] - ek[k]);
     }
     /* opaque cloud deck reached before toomuch: it emits as a surface */
-    if (kcloud >= 0 && last == kcloud && !(tau[last] > c->toomuch)) I += f[last];
+    if (deck) I += f[last];
     intens[a] = I;
   }
   free(bk);
   free(ek);
   free(f);
-  free(path);
+  free(hx);
+  free(dr);
   *last_out = last;
 }
 

@@ -34,9 +34,11 @@ extern "C" {
 #define ORC_AMAGAT 2.68679e19
 #define ORC_PI     3.141592653589793
 
-/* intensity integration rule: 0 (default) trapezoid in the transmittance
- * exp(-tau/mu); 1 Simpson in tau (tau itself by Simpson in radius too);
- * 2 trapezoid in tau of B exp(-tau/mu) */
+/* intensity integration rule (rt_oracle.c, column_eclipse): 0 (default)
+ * trapezoid in the transmittance exp(-tau/mu); 1 the Simpson / trapezoid hybrid
+ * of SURVEY.md App. A-4 for tau (over radius) and for B exp(-tau/mu) (over tau,
+ * zero-padded past `last`); 2 plain trapezoid in tau of B exp(-tau/mu).
+ * The product carries the same switch (cfg key `integ`, BARTRT_INTEG). */
 enum { ORC_INTEG_TRAPZ = 0, ORC_INTEG_SIMPSON = 1, ORC_INTEG_TRAPZ_TAU = 2 };
 enum { ORC_SOL_ECLIPSE = 0, ORC_SOL_TRANSIT = 1 };
 

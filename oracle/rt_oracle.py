@@ -70,7 +70,12 @@ def read_tcfg(path: str) -> dict:
         if not line or line[0] in "#;":
             continue
         parts = line.split(None, 1)
-        out[parts[0]] = parts[1].strip() if len(parts) > 1 else ""
+        key, val = parts[0], parts[1].strip() if len(parts) > 1 else ""
+        # one line per value of a multi-line BART option (code/makecfg.py:93-104)
+        if key in ("linedb", "csfile") and out.get(key) and val:
+            out[key] += "," + val
+        else:
+            out[key] = val
     return out
 
 
@@ -144,7 +149,7 @@ class OracleEngine:
     """Oracle counterpart of the product engine: built from a transit cfg."""
 
     def __init__(self, tcfg: str, wn_lo: int | None = None, wn_hi: int | None = None,
-                 integ: int = 0):
+                 integ: int | None = None):
         k = read_tcfg(tcfg)
         self.keys = k
         atm = read_atm(k["atm"])
@@ -194,7 +199,12 @@ class OracleEngine:
         c = _Cfg()
         c.nlayers, c.nspecies, c.nmol = self.L, S, len(self.opmol)
         c.ntemp, c.nwave, c.nangles = len(self.tgrid), W, len(self.angles)
-        c.ncia, c.integ = len(s1), integ
+        c.ncia = len(s1)
+        if integ is None:      # the cfg key the product reads too (number or name)
+            v = k.get("integ", "0")
+            integ = {"transmittance": 0, "simpson": 1, "trapz_tau": 2, "trapz": 2}.get(v)
+            integ = int(v) if integ is None else integ
+        c.integ = int(integ)
         c.solution = 0 if k.get("solution", "eclipse") == "eclipse" else 1
         c.press, c.mass, c.opmol = _p(self.press), _p(self.mass), _p(self.opmol)
         c.tgrid, c.kappa, c.wn = _p(self.tgrid), _p(self.kappa), _p(self.wn)
@@ -224,6 +234,10 @@ class OracleEngine:
 
     def set_scattering(self, flag, value):
         self.c.scat_flag, self.c.scat_value = int(flag), float(value)
+
+    def set_integ(self, rule):
+        """0 transmittance trapezoid, 1 Simpson hybrid (App. A-4), 2 trapezoid in tau."""
+        self.c.integ = int(rule)
 
     def set_extra_extinction(self, ext):
         """ext [L][W] (atm layer order) added to the extinction, or None."""

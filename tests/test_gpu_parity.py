@@ -144,13 +144,18 @@ def wide_cases(tmp_path_factory):
             for nm in (6, 8)}
 
 
+@pytest.mark.parametrize("integ", [0, 1, 2])
 @pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad", "octo"])
-def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode):
+def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode, integ):
     """The RT kernels (generic fallback, single-wave specialised, producer/consumer
-    split, quad-layer with four and with eight lane rows) on the same batches --
+    split, quad-layer with four and with eight lane rows) under each integration
+    rule (0 transmittance trapezoid, 1 the Simpson hybrid of SURVEY App. A-4, 2
+    trapezoid in tau; oracle/rt_oracle.c column_eclipse) on the same batches --
     four molecules + one CIA pair, six + two, eight + two -- without and with an
-    opaque cloud deck (its surface term takes a different route in each kernel).
-    BARTRT_KERNEL is read once per process, so each variant runs in a child."""
+    opaque cloud deck (its surface term takes a different route in each kernel),
+    and with `toomuch` lowered so the cut (and rule 1's padded point) falls in the
+    middle of the column.  BARTRT_KERNEL is read once per process, so each variant
+    runs in a child; the rule travels as BARTRT_INTEG."""
     import subprocess, sys, os
     from oracle import rt_oracle as orc
     cases = [small_case, wide_cases[6], wide_cases[8]]
@@ -158,27 +163,68 @@ def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode):
     for c in cases:
         profs = walkers(c, 5, seed=8)
         np.save(os.path.join(c.dir, "p.npy"), profs)
-        jobs.append((os.path.join(c.dir, "p.npy"), c.tcfg, os.path.join(c.dir, "s_%s.npy" % mode)))
+        jobs.append((os.path.join(c.dir, "p.npy"), c.tcfg, os.path.join(c.dir, "s_%s_%d.npy" % (mode, integ))))
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
             "from bart_amd import engine, transit_module as trm\n"
             "for pfile, tcfg, out in %r:\n"
-            "    p = np.load(pfile); engine.init(tcfg); a = engine.run_batch(p)\n"
+            "    p = np.load(pfile); engine.init(tcfg); assert trm.get_integ() == %d\n"
+            "    a = engine.run_batch(p)\n"
             "    trm.set_cloudtop(-1.0); b = engine.run_batch(p)\n"
             "    np.save(out, np.array([a, b])); trm.free_memory()\n"
-            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), jobs))
-    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_KERNEL=mode),
-                          timeout=600)
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), jobs, integ))
+    subprocess.check_call([sys.executable, "-c", code],
+                          env=dict(os.environ, BARTRT_KERNEL=mode, BARTRT_INTEG=str(integ)), timeout=600)
+    others = []
     for c, (pfile, _, out) in zip(cases, jobs):
         profs, got = np.load(pfile), np.load(out)
-        o = orc.OracleEngine(c.tcfg)
+        o = orc.OracleEngine(c.tcfg, integ=integ)
         np.testing.assert_allclose(got[0], o.run_batch(profs), rtol=RTOL)
         o.set_cloudtop(-1.0)
         np.testing.assert_allclose(got[1], o.run_batch(profs), rtol=RTOL)
         assert not np.allclose(got[0], got[1])
+        o.set_integ((integ + 1) % 3)
+        others.append(np.abs(o.run_batch(profs) / got[1] - 1).max())
+    assert max(others) > 1e-6          # the rules are different discretisations
 
 
+@pytest.mark.parametrize("integ", [1, 2])
+def test_integration_rules_outputs_and_setter(small_case, integ):
+    """Rules 1 and 2 through the in-process setter (bartrt_set_integ): spectrum,
+    optical depth (rule 1 integrates it by the Simpson hybrid over radius) with
+    `last`, and the per-angle intensities of the generic kernel, against the oracle;
+    toomuch lowered to 0.7 puts the cut (and rule 1's padded point) mid-column."""
+    import re
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = small_case
+    cfg2 = c.tcfg + ".toomuch%d" % integ
+    open(cfg2, "w").write(re.sub(r"(?m)^toomuch .*$", "toomuch 0.7", open(c.tcfg).read()))
+    for cfg in (c.tcfg, cfg2):
+        engine.init(cfg)
+        try:
+            assert trm.get_integ() == 0
+            trm.set_integ(integ)
+            o = orc.OracleEngine(cfg, integ=integ)
+            profs = walkers(c, 7, seed=31)
+            np.testing.assert_allclose(engine.run_batch(profs), o.run_batch(profs), rtol=RTOL)
+            spec = trm.run_transit(profs[0], trm.get_no_samples())
+            tau, last = engine.get_tau()
+            rspec, rtau, rlast = o.run(profs[0], want_tau=True)
+            assert np.array_equal(last, rlast)
+            np.testing.assert_allclose(tau, rtau, rtol=RTOL, atol=1e-300)
+            np.testing.assert_allclose(spec, rspec, rtol=RTOL)
+            inten = np.zeros((5, trm.get_no_samples()))
+            trm.check(trm.lib().bartrt_get_intensity(trm._ptr(inten), 5, inten.shape[1]))
+            np.testing.assert_allclose(inten, o.intensity(profs[0]), rtol=RTOL)
+            with pytest.raises(trm.TransitError):
+                trm.set_integ(3)
+        finally:
+            trm.free_memory()
+
+
+@pytest.mark.parametrize("integ", [0, 1, 2])
 @pytest.mark.parametrize("nlayers", [3, 4, 5, 13, 100, 209])
-def test_cloud_deck_sweep_across_layer_steps(tmp_path, nlayers):
+def test_cloud_deck_sweep_across_layer_steps(tmp_path, nlayers, integ):
     """Small batches run the quad-layer kernel (four layers per step, one per lane
     row): move the cloud deck through the column so the stop layer lands in every
     row of a step, at step edges, and above the top."""
@@ -187,7 +233,8 @@ def test_cloud_deck_sweep_across_layer_steps(tmp_path, nlayers):
     c = synth.make_case(str(tmp_path), nlayers=nlayers, nwave=130)
     engine.init(c.tcfg)
     try:
-        o = orc.OracleEngine(c.tcfg)
+        trm.set_integ(integ)
+        o = orc.OracleEngine(c.tcfg, integ=integ)
         profs = walkers(c, 2, seed=6)
         lp = np.log10(c.press_bar)
         tops = np.concatenate([np.linspace(lp.min() - 0.5, lp.max() + 0.5, 12), lp[[0, -1, nlayers // 2]]])

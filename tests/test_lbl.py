@@ -77,6 +77,75 @@ def test_lbl_extinction_and_spectrum_match_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_extinction_chunks_keep_per_walker_overrides(tmp_path, monkeypatch):
+    """The eager line-by-line path works through the walkers in chunks bounded by the
+    size of ext[walkers][L][W]; the walkers' own cloud-top / scattering parameters
+    (BARTfunc.py:350-360) must follow them into every chunk (chunks after
+    the first fell back to the engine-wide values).  Two walkers per chunk and one
+    chunk for all give the same band fluxes, and so does walker by walker."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=600, nwave=150, nlayers=10, cia=True)
+    L, W = 10, 150
+    engine.init(c.tcfg)
+    try:
+        ptargs = [1.145 * 6.95508e10, 6075.0, 100.0, 0.047 * 1.4959787066e13, 897.70]
+        engine.step_setup(ptargs, 0.0, 1e9, c.abund0, [c.species.index("CO")], [0], [W],
+                          np.full(W, 1.0 / W), np.ones(W), 0.1)
+        engine.step_set_extras(0, 1, 1)      # cloud top and scattering travel with each walker
+        rng = np.random.default_rng(11)
+        base = np.array([-2.0, 0.0, 1.0, 0.0, 0.98, -1.0, 1.0, 0.0])   # PT(5), log10 cloudtop, scattering, CO
+        pars = base + rng.normal(0, [0.1, 0.1, 0.1, 0.0, 0.01, 1.0, 0.8, 0.3], (5, 8))
+        whole, st = engine.step_batch(pars, 1)
+        assert (st == 0).all() and np.ptp(whole) > 0
+        monkeypatch.setenv("BARTRT_LBL_CHUNK_BYTES", str(2 * L * W * 8))
+        chunked, _ = engine.step_batch(pars, 1)
+        assert np.array_equal(chunked, whole)
+        monkeypatch.setenv("BARTRT_LBL_CHUNK_BYTES", "1")
+        single = np.array([engine.step_batch(q[None, :], 1)[0][0] for q in pars])
+        assert np.array_equal(single, whole)
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
+def test_several_linedb_files_are_merged(tmp_path):
+    """makecfg writes one `linedb <file>` line per TLI (code/makecfg.py:93-104):
+    two files, one molecule each, on two lines give the extinction of the single
+    file that holds both databases -- bit for bit (the second line used
+    to replace the first)."""
+    from bart_amd import engine, synth, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=700, nwave=180, nlayers=8)
+    prof = c.profiles()
+    engine.init(c.tcfg)
+    try:
+        one = engine.lbl_extinction(prof)
+    finally:
+        trm.free_memory()
+    parts = []
+    for i, db in enumerate(c.linedbs):
+        parts.append(str(tmp_path / ("part%d.tli" % i)))
+        synth.write_tli(parts[-1], [db], 1900.0, 2100.0)
+    two = str(tmp_path / "two.cfg")
+    lines = [l for l in open(c.tcfg) if not l.startswith("linedb")]
+    open(two, "w").write("".join(lines) + "".join("linedb %s\n" % p for p in parts))
+    assert lbl_oracle.LblOracle(two).dbs[1]["molecule"] == "CO"
+    engine.init(two)
+    try:
+        assert np.array_equal(engine.lbl_extinction(prof), one)
+    finally:
+        trm.free_memory()
+    # a repeated key that is not a file list keeps its last value
+    open(two, "a").write("nwidth 3\n")
+    engine.init(two)
+    try:
+        narrow = engine.lbl_extinction(prof)
+        assert (narrow <= one).all() and (narrow < one).any()
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kw", [
     dict(ptop=1e-6, pbottom=1e-3, nwave=333),              # Doppler cores only: the pair kernel, ragged last wave
     dict(ptop=1.0, pbottom=100.0, nwave=300),              # pressure-broadened only: the tile kernel

@@ -40,6 +40,27 @@ def test_recovers_a_gaussian_posterior(walk):
     assert np.all(post[:, 1] <= 4.5)                      # never accepted a rejected model
 
 
+def test_edge_cases_lone_chain_fixed_outside_box_shared_stepsize():
+    """a single chain (no partner to difference with) moves by its jitter
+    instead of raising; a fixed parameter outside [pmin, pmax] keeps its value and
+    does not veto every proposal; a negative stepsize (MC3: shared parameter) is
+    refused rather than treated as fixed."""
+    model, data = _linear_model([1.0, 2.0])
+    cfg = sampler.SamplerConfig(params=np.array([0.9, 2.1, 12.0]), pmin=np.array([-5.0, -5.0, 0.0]),
+                                pmax=np.array([5.0, 5.0, 10.0]), stepsize=np.array([0.1, 0.1, 0.0]),
+                                data=data, uncert=np.full(12, 0.05), nchains=1, numit=400,
+                                burnin=10, walk="demc", seed=1)
+    res = sampler.run(model, cfg)
+    assert res["chain"].shape == (1, 400, 3) and np.all(res["chain"][:, :, 2] == 12.0)
+    assert res["accept_rate"] > 0 and np.ptp(res["chain"][0, :, 0]) > 0
+    cfg.nchains, cfg.numit = 6, 3000
+    res = sampler.run(model, cfg)
+    assert np.all(res["chain"][:, :, 2] == 12.0) and res["accept_rate"] > 0.05
+    cfg.stepsize = np.array([0.1, -1.0, 0.0])
+    with pytest.raises(ValueError, match="shared"):
+        sampler.run(model, cfg)
+
+
 def test_config_from_reference_style_cfg(tmp_path):
     p = tmp_path / "BART.cfg"
     p.write_text("[MCMC]\nparams = -2.0 0.0 1.0\npmin = -5 -2 -2\npmax = -1 1 1\n"

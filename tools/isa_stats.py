@@ -1,6 +1,6 @@
 """Instruction mix of an RT kernel's layer loop from the gfx950 assembly (no GPU needed).
 usage: python tools/isa_stats.py [mangled-kernel-substring] > profiles/<tag>_isa_<kernel>.txt
-Compiles csrc/kernels.hip to assembly with the build's flags, takes the largest
+Compiles csrc/rt_eclipse_i<rule>.hip (the rule is the last template argument of the name) to assembly with the build's flags, takes the largest
 basic block of the kernel (the straight-line block of four layers) and counts
 instructions by class."""
 import collections
@@ -15,12 +15,14 @@ FP64 = ("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_min_f64", "v_max
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "rt_eclipse_fastILi5ELi4ELi1ELb1E"
+    want = sys.argv[1] if len(sys.argv) > 1 else "rt_eclipse_fastILi5ELi4ELi1ELb1ELi0E"
+    m = re.search(r"Li(\d)E$", want)
+    integ = m.group(1) if m else "0"
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
                                "--cuda-device-only", "-S", "-x", "hip",
-                               os.path.join(ROOT, "bart_amd", "csrc", "kernels.hip"), "-o", out],
+                               os.path.join(ROOT, "bart_amd", "csrc", "rt_eclipse_i%s.hip" % integ), "-o", out],
                               stderr=subprocess.DEVNULL)
         s = open(out).read()
     name = re.search(r"^(_ZN6bartrt\w*%s\w*):" % re.escape(want), s, re.M).group(1)

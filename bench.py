@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PEAK_FP64_TFLOPS = 78.6  # MI355X vector fp64 peak (MI355X_MICROARCH.md): 256 CUs x 64 lanes x 2 x 2.4 GHz
 
 
 # HD 209458b system values of the demo TEP file (examples/demo/HD209458b.tep) and the
@@ -112,6 +113,74 @@ def cpu_baseline(case, profs, seconds_target=12.0):
     return {"value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
             "sample": f"{n} spectra of the same workload (100x1e4, 4 molecules), "
                       f"one walker per thread, {dt:.1f} s wall"}
+
+
+def source_id():
+    """Short hash of the kernel sources: ties committed profiler figures (PMC traffic,
+    instruction mix) to the build they were taken on; bench.py reports them only when
+    the sources are unchanged."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bart_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def _cia_temps(path):
+    lines = open(path).read().split("\n")
+    return np.array([float(x) for x in lines[lines.index("@TEMPERATURES") + 1].split()])
+
+
+def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
+    """HBM bytes one RT launch has to move, from the launch's own walkers:
+
+    * effective: the SURVEY 8d figure (two T planes x M molecules + two CIA planes per
+      layer and wavenumber, per walker, no credit for reuse) restricted to the layers
+      each wave actually walked before all its lanes passed `toomuch`;
+    * unique: the same with every (layer, T plane, molecule, wavenumber column) row
+      counted ONCE per launch however many of the launch's walkers read it -- the
+      walkers of a launch share table planes, and whichever implementation is used
+      has to fetch a row from HBM only once per launch: this is the compulsory
+      traffic the HBM roofline fraction is quoted on (+ records in, spectra out).
+    walked[nwalkers][ncols]: layers walked per column of wn_per_col wavenumbers."""
+    nw, ncols = walked.shape
+    L = len(case.press_bar)
+    M = len(case.opmol)
+    S = len(case.species)
+    T = profs.reshape(nw, S + 1, L)[:, 0, ::-1]            # [walker][k], k = 0 top
+    tg = np.asarray(case.tgrid)
+    j = np.clip(np.searchsorted(tg, T, side="right") - 1, 0, len(tg) - 2)
+    cia_t = [_cia_temps(f) for f in case.cia[:ncia]]
+    jc = [np.clip(np.searchsorted(t, np.clip(T, t[0], t[-1]), side="right") - 1, 0, max(len(t) - 2, 0))
+          for t in cia_t]
+    width = np.minimum(wn_per_col, nwave - wn_per_col * np.arange(ncols)).clip(min=0)
+    k = np.arange(L)
+    eff = uniq = 0.0
+    walked_lw = 0.0
+    for c in range(ncols):
+        if width[c] <= 0:
+            continue
+        act = walked[:, c][:, None] > k[None, :]            # [walker][layer]
+        walked_lw += act.sum() * width[c]
+        eff += act.sum() * width[c] * (2 * M + 2 * len(cia_t)) * 8.0
+        used = np.zeros((L, len(tg) + 1), bool)
+        for w in range(nw):
+            used[k[act[w]], j[w][act[w]]] = True
+            used[k[act[w]], j[w][act[w]] + 1] = True
+        uniq += used.sum() * M * width[c] * 8.0
+        for t, jj in zip(cia_t, jc):
+            usedc = np.zeros((L, len(t) + 1), bool)
+            for w in range(nw):
+                usedc[k[act[w]], jj[w][act[w]]] = True
+                usedc[k[act[w]], jj[w][act[w]] + 1] = True
+            # (the same CIA plane serves every layer that brackets it: count planes, not (layer, plane))
+            uniq += usedc.any(axis=0).sum() * width[c] * 8.0
+    NC, NI = 3 + 2 * M + 2 * len(cia_t), 1 + len(cia_t)
+    fixed = nw * L * (NC + NI) * 8.0 + nw * nwave * 8.0 + nwave * 8.0   # records, spectra out, wavenumbers
+    return {"effective_bytes": eff + fixed, "unique_bytes": uniq + fixed,
+            "layers_walked_frac": walked_lw / (nw * L * float(nwave)),
+            "layer_wavenumbers_walked": walked_lw}
 
 
 def self_launch(ngpus, argv, port=0):
@@ -324,10 +393,11 @@ def main():
         ok = out.shape == (nwalk, a.nwave) and bool(torch.isfinite(out).all())
         if dry:   # the reassembled spectra of the last step, sample for sample
             ok = ok and bool(torch.equal(out, StubEngine.expected(d_prof[(steps - 1) % nsets], 0, a.nwave)))
-        return dt, kern_ms, nlaunch, ok, profs_h[0]
+        return dt, kern_ms, nlaunch, ok, profs_h
 
     nwalk = a.walkers * world            # weak scaling: per-GPU work is fixed
-    dt, kern_ms, nlaunch, ok, profs0 = timed(nwalk, a.steps, a.warmup, True)
+    dt, kern_ms, nlaunch, ok, profs_all = timed(nwalk, a.steps, a.warmup, True)
+    profs0 = profs_all[0]
 
     sweep = {}
     if world == 1 and a.sweep:
@@ -336,7 +406,7 @@ def main():
             sdt, skm, snl, sok, _ = timed(b, k, 8, True)
             sweep[str(b)] = {"spectra_per_s": b * k / sdt, "ms_per_step": sdt / k * 1e3,
                              "rt_kernel_ms": skm / max(snl, 1),
-                             "algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
+                             "survey8d_algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
 
     if rank == 0 and dry:
         assert ok
@@ -353,16 +423,44 @@ def main():
     elif rank == 0:
         assert ok
         value = nwalk * a.steps / dt
-        alg = engine.algorithmic_bytes(nwalk)          # bytes per RT launch on this GPU
+        alg = engine.algorithmic_bytes(nwalk)          # SURVEY 8d bytes per RT launch on this GPU
         per_launch_s = kern_ms / 1e3 / max(nlaunch, 1)
-        achieved = alg / per_launch_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and world == 1 and a.walkers == 10:
-            try:
-                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # ---- what one launch has to move: untimed passes over the same batches with
+        # the kernels recording how deep each wave walked (bartrt_walked_*)
+        nsets = profs_all.shape[0]
+        models, kname = [], ""
+        d_out = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
+        for sset in range(nsets):
+            engine.walked_begin()
+            engine.run_batch_dev(torch.from_numpy(profs_all[sset]).to(dev), d_out)
+            torch.cuda.synchronize()
+            walked, wpc, kname = engine.walked_end()
+            models.append(launch_byte_model(case, profs_all[sset], walked, wpc, hi - lo))
+        mean = lambda key: float(np.mean([m[key] for m in models]))
+        uniq, eff, wfrac = mean("unique_bytes"), mean("effective_bytes"), mean("layers_walked_frac")
+        # ---- committed profiler figures of THIS build (tools/profile_round.sh), if any
+        sid = source_id()
+        same = lambda j: (j.get("source_id") == sid and j.get("walkers") == nwalk and j.get("nwave") == a.nwave
+                          and j.get("nlayers") == a.nlayers and world == 1)
+        traffic = traffic_src = None
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if same(j):
+                traffic, traffic_src = j["traffic_bytes_per_launch"], "profiles/%s_pmc.json" % j.get("tag", "?")
+        except Exception:
+            pass
+        fp64 = None
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "isa_latest.json")))
+            if j.get("source_id") == sid and j["kernel_family"] in kname:
+                flop = mean("layer_wavenumbers_walked") * (2 * j["fp64_fma_per_layer"] + j["fp64_other_per_layer"])
+                fp64 = {"flop_per_launch": flop, "achieved": flop / per_launch_s / 1e12, "peak": PEAK_FP64_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flop / per_launch_s / 1e12 / PEAK_FP64_TFLOPS,
+                        "note": "fp64 VALU operations the kernel's layer loop issues per (layer, wavenumber) "
+                                "(FMA = 2) x (layer, wavenumber) pairs walked; vector fp64 peak, no MFMA on this path",
+                        "source": "profiles/%s" % j.get("file", "isa_latest.json")}
+        except Exception:
+            pass
         res = {
             "metric": "forward spectra/sec (100 layers x 1e4 wavenumbers)",
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": a.steps,
@@ -372,21 +470,41 @@ def main():
             "config": {
                 "workload": "H2O+CO+CO2+CH4 eclipse, %d layers x %d wavenumbers, %d walkers "
                             "batched per GPU per step, opacity-table path, 27 T planes, "
-                            "H2-H2 CIA, 5 ray angles" % (a.nlayers, a.nwave, a.walkers),
-                "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave,
+                            "H2-H2 CIA, 5 ray angles, toomuch 10, integration rule 0 (integ=0: trapezoid "
+                            "in the transmittance); walkers: PT_line T(p) with parameters uniform in the demo "
+                            "retrieval's prior box, %d distinct batches cycled.  Departure from SURVEY 8d: "
+                            "the synthetic opacities are a log-normal line forest of median ~1 cm2/g "
+                            "(bart_amd/synth.py kappa_layer) instead of exp(N(-25,3)) cm2/g, which would be a "
+                            "transparent atmosphere; with it the photosphere lies inside the column and the "
+                            "`toomuch` cut skips the fraction of layers reported as 1 - roofline.layers_walked_frac"
+                            % (a.nlayers, a.nwave, a.walkers, nsets),
+                "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave, "integ": 0,
                 "parallelism": "wavenumber-block shard x%d + all-gather" % world if world > 1
                                else "single GPU",
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
-                         "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
-                         "kernel": "bartrt::rt_eclipse_fast<5, 4, 1, true> at the default 10 walkers per GPU "
-                                   "(launch_rt picks rt_eclipse_quad / _split below 9 walkers)",
-                         "launches": nlaunch,
-                         "avg_launch_ms": per_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg,
-                         # the same launch against the bytes the PMC pass saw leave L2
-                         "traffic_GBps": traffic / per_launch_s / 1e9 if traffic else None,
-                         "traffic_frac": traffic / per_launch_s / 1e9 / PEAK_HBM_GBS if traffic else None},
+            "roofline": {
+                "bound": "hbm", "achieved": uniq / per_launch_s / 1e9, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": uniq / per_launch_s / 1e9 / PEAK_HBM_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_GBps": traffic / per_launch_s / 1e9 if traffic else None,
+                "bytes_model": "achieved = unique_bytes_per_launch / avg launch time: every (layer, T plane, "
+                               "molecule, 64-wavenumber column) row the launch's walkers read down to the layer "
+                               "where their wave stopped, counted once per launch (walkers share planes; a row "
+                               "has to come from HBM once per launch whatever the implementation), + CIA rows, "
+                               "layer records in, spectra out.  Computed from the launch's own profiles and the "
+                               "kernels' walked-layer record (bartrt_walked_*), averaged over the cycled batches",
+                "unique_bytes_per_launch": uniq,
+                "effective_bytes_per_launch": eff,
+                "layers_walked_frac": wfrac,
+                "kernel": kname, "launches": nlaunch, "avg_launch_ms": per_launch_s * 1e3,
+                # SURVEY 8d's per-spectrum figure x walkers: no credit for rows shared between the
+                # walkers of a launch or for layers below the cut, so it is NOT bounded by the HBM
+                # peak (the shared rows are served by L2) -- kept as a labelled throughput figure
+                "survey8d_algorithmic_bytes_per_launch": alg,
+                "survey8d_algorithmic_GBps": alg / per_launch_s / 1e9,
+                "fp64": fp64,
+            },
+            "source_id": sid,
         }
         if sweep:
             res["batch_sweep"] = sweep

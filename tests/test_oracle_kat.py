@@ -162,6 +162,84 @@ def test_simpson_switch_is_close_to_trapezoid(tmp_path):
     assert np.max(np.abs(a / b - 1)) < 0.05 and not np.array_equal(a, b)
 
 
+def _parabola_hybrid(x, y):
+    """Simpson / trapezoid hybrid written independently of rt_oracle.c: with an even
+    number of points the first interval is a trapezoid; every following pair of
+    intervals is the exact integral of the parabola through its three points
+    (numpy polyfit + polyint, not the closed-form panel weights)."""
+    x, y = np.asarray(x, float), np.asarray(y, float)
+    n, res, start = len(x), 0.0, 0
+    if n < 2:
+        return 0.0
+    if n % 2 == 0:
+        res, start = 0.5 * (x[1] - x[0]) * (y[0] + y[1]), 1
+    for j in range(start, n - 2, 2):
+        xs = x[j:j + 3] - x[j]
+        if xs[1] == 0 or xs[2] == xs[1]:
+            res += 0.5 * xs[1] * (y[j] + y[j + 1]) + 0.5 * (xs[2] - xs[1]) * (y[j + 1] + y[j + 2])
+            continue
+        P = np.polyint(np.polyfit(xs / xs[2], y[j:j + 3], 2))
+        res += (np.polyval(P, 1.0) - np.polyval(P, 0.0)) * xs[2]
+    return res
+
+
+@pytest.mark.parametrize("toomuch", [0.7, 10.0, 1e30])
+def test_rule1_is_the_simpson_hybrid_of_appendix_a4(tmp_path, toomuch):
+    """Rule 1 (SURVEY.md App. A-4 as recalled) pinned against an independent numpy
+    statement: tau[k] = hybrid over the layers k .. top taken from layer k upwards;
+    I(mu) = (1/mu) hybrid over (tau, B exp(-tau/mu)) from the top down to `last`,
+    plus one zero point one unit of tau further when a layer exists there."""
+    case = synth.make_case(str(tmp_path), nwave=12, nlayers=31, toomuch=toomuch)
+    e = orc.OracleEngine(case.tcfg, integ=1)
+    prof = case.profiles(temp=np.linspace(1900.0, 700.0, 31))
+    spec, tau, last = e.run(prof, want_tau=True)
+    inten = e.intensity(prof)
+    ext, rad = e.extinction(prof)
+    r, L = rad[::-1], 31
+    for i in range(12):
+        ecol, k1 = ext[::-1, i], last[i]
+        for k in range(1, k1 + 1):
+            up = np.arange(k, -1, -1)                     # from layer k up to the top
+            want = _parabola_hybrid(r[up] - r[k], ecol[up])
+            assert abs(tau[i, k] / want - 1) < 1e-12
+        assert k1 == L - 1 or tau[i, k1] > toomuch
+        for a, ang in enumerate(e.angles):
+            mu = np.cos(np.radians(ang))
+            x = list(tau[i, :k1 + 1])
+            y = [orc.planck(e.wn[i], prof[0][L - 1 - k]) * np.exp(-tau[i, k] / mu) for k in range(k1 + 1)]
+            if k1 + 1 < L:
+                x.append(x[-1] + 1.0); y.append(0.0)
+            assert abs(inten[a, i] / (_parabola_hybrid(x, y) / mu) - 1) < 1e-11
+    # rule 2 is the plain trapezoid of the same integrand on rule 0's optical depth
+    e2 = orc.OracleEngine(case.tcfg, integ=2)
+    _, tau2, last2 = e2.run(prof, want_tau=True)
+    in2 = e2.intensity(prof)
+    _, tau0, last0 = orc.OracleEngine(case.tcfg, integ=0).run(prof, want_tau=True)
+    assert np.array_equal(tau2, tau0) and np.array_equal(last2, last0)
+    i, k1 = 5, last2[5]
+    y = np.array([orc.planck(e.wn[i], prof[0][L - 1 - k]) * np.exp(-tau2[i, k]) for k in range(k1 + 1)])
+    assert abs(in2[0, i] / np.sum(0.5 * (y[1:] + y[:-1]) * np.diff(tau2[i, :k1 + 1])) - 1) < 1e-12
+
+
+def test_rules_agree_on_a_finely_layered_isothermal_column(tmp_path):
+    """Isothermal, weak grey opacity, 200 layers: every rule converges on
+    B (1 - exp(-tau/mu)); rule 0 is exact, rules 1 and 2 to their truncation error."""
+    case = synth.make_case(str(tmp_path), nwave=6, nlayers=200, opmol=("H2O",), cia=False, toomuch=1e30,
+                           ptop=1e-3, pbottom=10.0)
+    op = orc.read_opacity(case.opacity)
+    synth.write_opacity(case.opacity, op["ids"], op["temps"], op["press"], op["wn"],
+                        kappa=np.full(op["kappa"].shape, 2e-2))
+    prof = case.profiles(temp=np.full(200, 1300.0))
+    res = {}
+    for rule in (0, 1, 2):
+        e = orc.OracleEngine(case.tcfg, integ=rule)
+        I, (_, tau, last) = e.intensity(prof), e.run(prof, want_tau=True)
+        B = orc.planck(e.wn[2], 1300.0)
+        exact = np.array([B * (1 - np.exp(-tau[2, last[2]] / np.cos(np.radians(a)))) for a in e.angles])
+        res[rule] = np.abs(I[:, 2] / exact - 1).max()
+    assert res[0] < 1e-13 and res[1] < 2e-4 and res[2] < 2e-3 and res[1] < res[2]
+
+
 def test_radpress_reference_level(tmp_path):
     case, e = _engine(tmp_path, nwave=8, opmol=(), cia=False)
     _, rad = e.extinction(case.profiles())

@@ -27,13 +27,16 @@ def kernel_stats(d, out):
 
 
 def pmc_mean(d, kernel, counter):
+    """Mean counter value, mean duration (us), launch count and the kernel's own name
+    over the dispatches whose name contains `kernel`."""
     f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
-    v, t = [], []
+    v, t, names = [], [], set()
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
             v.append(float(r["Counter_Value"]))
             t.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    return sum(v) / len(v), sum(t) / len(t) / 1e3, len(v)
+            names.add(r["Kernel_Name"])
+    return sum(v) / len(v), sum(t) / len(t) / 1e3, len(v), sorted(names)
 
 
 if __name__ == "__main__":
@@ -43,12 +46,18 @@ if __name__ == "__main__":
     if len(sys.argv) >= 6:
         fetch, write, calib = sys.argv[3:6]
         expected = float(sys.argv[6]) if len(sys.argv) > 6 else 80.0e6
-        cal_kb, _, _ = pmc_mean(calib, "rt_eclipse", "FETCH_SIZE")
+        sys.path.insert(0, ROOT)
+        import bench
+        cal_kb, _, _, cal_names = pmc_mean(calib, "rt_eclipse", "FETCH_SIZE")
         factor = expected / (cal_kb * 1024.0)
-        f_kb, f_us, n = pmc_mean(fetch, "rt_eclipse", "FETCH_SIZE")
-        w_kb, w_us, _ = pmc_mean(write, "rt_eclipse", "WRITE_SIZE")
+        f_kb, f_us, n, names = pmc_mean(fetch, "rt_eclipse", "FETCH_SIZE")
+        w_kb, w_us, _, _ = pmc_mean(write, "rt_eclipse", "WRITE_SIZE")
         res = {
-            "kernel": "bartrt::rt_eclipse<5,4,1>",
+            "tag": tag, "source_id": bench.source_id(),
+            # the workload of tools/profile_round.sh's PMC passes (bench.py defaults)
+            "walkers": int(os.environ.get("PMC_WALKERS", 10)), "nwave": 10000, "nlayers": 100,
+            "kernel": names[0] if len(names) == 1 else names,
+            "calibration_kernel": cal_names[0] if len(cal_names) == 1 else cal_names,
             "launches_averaged": n,
             "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB_raw": w_kb,
             "fetch_calibration": {

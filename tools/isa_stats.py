@@ -15,7 +15,7 @@ FP64 = ("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_min_f64", "v_max
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "rt_eclipse_fastILi5ELi4ELi1ELb1ELi0E"
+    want = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "rt_eclipse_fastILi5ELi4ELi1ELb1ELi0E"
     m = re.search(r"Li(\d)E$", want)
     integ = m.group(1) if m else "0"
     with tempfile.TemporaryDirectory() as d:
@@ -64,6 +64,18 @@ def main():
         print("  %-26s %4d" % (k, v))
     vm = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(l.strip() for l in body))
     print("counted vmcnt waits in the kernel:", dict(collections.Counter(int(x) for x in vm)))
+    if "--json" in sys.argv:
+        # the figures bench.py's fp64 line is computed from, tied to the sources they were taken on
+        import json
+        sys.path.insert(0, ROOT)
+        import bench
+        out = sys.argv[sys.argv.index("--json") + 1]
+        fma = sum(1 for m in big if m.startswith(("v_fma_f64", "v_fmac_f64")))
+        oth = sum(1 for m in big if m.startswith(FP64)) - fma
+        json.dump({"kernel": name, "kernel_family": "rt_eclipse_fast", "source_id": bench.source_id(),
+                   "fp64_fma_per_layer": fma / 4, "fp64_other_per_layer": oth / 4,
+                   "instructions_per_layer": len(big) / 4, "file": os.path.basename(out)},
+                  open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":

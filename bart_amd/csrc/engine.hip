@@ -233,13 +233,21 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     try {
       read_opacity_block(cfg["opacityfile"], oh, lo, hi, h);
     } catch (...) { (void)hipHostFree(h); throw; }
-    HIPCHK(hipMalloc(&d_kappa, n * sizeof(double)));
-    HIPCHK(hipMemcpy(d_kappa, h, n * sizeof(double), hipMemcpyHostToDevice));
+    // the file's order o[L][Nt][M][W] goes up as it lies and is re-laid out on the
+    // device with each wavenumber's molecules contiguous (kernels.hpp, "Table layout")
+    double *d_file = nullptr;
+    hipError_t er = hipMalloc(&d_file, n * sizeof(double));
+    if (er == hipSuccess) er = hipMemcpy(d_file, h, n * sizeof(double), hipMemcpyHostToDevice);
     (void)hipHostFree(h);
+    if (er == hipSuccess) er = hipMalloc(&d_kappa, n * sizeof(double));
+    if (er == hipSuccess) er = launch_grid_transpose(d_file, d_kappa, (long)L * Nt, M, Wl, stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(stream);
+    if (d_file) (void)hipFree(d_file);
+    HIPCHK(er);
   }
-  // CIA: resample on the local grid (linear in wn, zero outside the file) and
-  // lay out nt+1 planes per pair (the extra plane repeats the last one so the
-  // kernel may always read planes j and j+1).
+  // CIA: resample on the local grid (linear in wn, zero outside the file) and lay
+  // out, per table, nt-1 pair planes [W][2] = (alpha_j, alpha_j+1) per wavenumber:
+  // one 16-byte load per table and layer (kernels.hpp, "Table layout").
   std::vector<double> cia_planes, cia_temp;
   PrepArgs &pa = prep;
   if (cfg_has(cfg, "csfile")) {
@@ -257,9 +265,10 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
       pa.cia_nt[cc] = (int)c.temp.size();
       pa.cia_toff[cc] = (int)cia_temp.size();
       const size_t nw = c.wn.size();
-      for (size_t t = 0; t <= c.temp.size(); t++) {
-        size_t tt = std::min(t, c.temp.size() - 1);
-        const double *al = c.alpha.data() + tt * nw;
+      // resampled planes [nt][Wl] first, then the (lower, upper) pair planes
+      std::vector<double> planes(c.temp.size() * (size_t)Wl);
+      for (size_t t = 0; t < c.temp.size(); t++) {
+        const double *al = c.alpha.data() + t * nw;
         for (int i = 0; i < Wl; i++) {
           double x = wn_loc[i], v = 0.0;
           if (x >= c.wn.front() && x <= c.wn.back()) {
@@ -271,7 +280,16 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
             v = (al[j] - al[j - 1]) / (x1 - x0) * (x - x0) + al[j - 1];
             if (x == x1) v = al[j];
           }
-          cia_planes.push_back(v);
+          planes[t * Wl + i] = v;
+        }
+      }
+      pa.cia_poff[cc] = (int)(cia_planes.size() / ((size_t)2 * Wl));
+      const size_t npair = std::max<size_t>(c.temp.size() - 1, 1);
+      for (size_t t = 0; t < npair; t++) {
+        const size_t hi_t = std::min(t + 1, c.temp.size() - 1);
+        for (int i = 0; i < Wl; i++) {
+          cia_planes.push_back(planes[t * Wl + i]);
+          cia_planes.push_back(planes[hi_t * Wl + i]);
         }
       }
       cia_temp.insert(cia_temp.end(), c.temp.begin(), c.temp.end());

@@ -14,6 +14,7 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *info = nullptr);
 hipError_t launch_transit(const RtArgs &a, hipStream_t st);
 hipError_t launch_chord_table(const PrepArgs &a, hipStream_t st);  // transit geometry, after launch_prep
+hipError_t launch_grid_transpose(const double *src, double *dst, long planes, int M, int W, hipStream_t st);
 
 int parse_integ(const std::string &v);  // "0" / "transmittance", "1" / "simpson", "2" / "trapz_tau"
 

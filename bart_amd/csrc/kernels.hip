@@ -107,17 +107,18 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     const int l = L - 1 - k;
     double e = c[2 + 2 * M + 2 * C] * nu4;
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
-    const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + ii;
+    // grid [plane][W][M], CIA [pair plane][W][2] (kernels.hpp, "Table layout")
+    const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + (size_t)ii * M;
 #pragma unroll
     for (int m = 0; m < (MT >= 0 ? MT : kMaxMol); m++) {
       if (MT < 0 && m >= M) break;
-      e += c[2 + 2 * m] * kb[(size_t)m * W] + c[3 + 2 * m] * kb[MW + (size_t)m * W];
+      e += c[2 + 2 * m] * kb[m] + c[3 + 2 * m] * kb[MW + m];
     }
 #pragma unroll
     for (int cc = 0; cc < (CT >= 0 ? CT : kMaxCia); cc++) {
       if (CT < 0 && cc >= C) break;
-      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + ii;
-      e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[W];
+      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + 2 * (size_t)ii;
+      e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[1];
     }
     tc.layer(k, active, active ? 0.5 : 0.0, e, c[0], sW);
     const double B = bnum * rcp_core(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
@@ -151,6 +152,24 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   if (p.walked_out && (threadIdx.x & 63) == 0)
     p.walked_out[(size_t)w * (p.ntiles * (blockDim.x / 64)) + tile * (blockDim.x / 64) + (threadIdx.x >> 6)] =
         k < kend ? k + 1 : kend + 1;
+}
+
+// The opacity file's order [planes][M][W] -> the kernels' [planes][W][M]
+// (kernels.hpp, "Table layout"); one workgroup per (plane, 64-wavenumber tile)
+__global__ __launch_bounds__(64) void grid_transpose(const double *src, double *dst, int M, int W, int ntiles) {
+  const long plane = blockIdx.x / ntiles;
+  const int i = (int)(blockIdx.x % ntiles) * 64 + threadIdx.x;
+  if (i >= W) return;
+  for (int m = 0; m < M; m++)
+    dst[(plane * W + i) * M + m] = src[(plane * M + m) * W + i];
+}
+
+hipError_t launch_grid_transpose(const double *src, double *dst, long planes, int M, int W, hipStream_t st) {
+  if (planes <= 0 || M <= 0 || W <= 0) return hipSuccess;
+  const int ntiles = (W + 63) / 64;
+  if (planes * ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(grid_transpose, dim3((unsigned)(planes * ntiles)), dim3(64), 0, st, src, dst, M, W, ntiles);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -161,8 +161,9 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
         jc = bracket_dev(tg, tginv, nt, Tc);
         fc = (Tc - tg[jc]) * tginv[jc];
       }
-      // a single-temperature table is stored twice so plane jc+1 exists
-      ix[1 + cc] = (idx_t)(p.cia_toff[cc] + cc + jc) * p.W * 8;
+      // pair plane jc of table cc holds (alpha_jc, alpha_jc+1) per wavenumber (a
+      // single-temperature table: one pair plane with its values twice)
+      ix[1 + cc] = (idx_t)(p.cia_poff[cc] + jc) * p.W * 16;
       c[2 + 2 * M + 2 * cc] = n1 * n2 * (1.0 - fc);
       c[3 + 2 * M + 2 * cc] = n1 * n2 * fc;
     }

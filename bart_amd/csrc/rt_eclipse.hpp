@@ -390,10 +390,10 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   const int kend = p.kstop[w];
   const double tcap = tau_cap(p, A);
 
-  // per-lane table addressing: plane offset of the lane's layer + row + lane
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  // per-lane table addressing: plane offset of the lane's layer + the lane's
+  // wavenumber inside the plane (kernels.hpp, "Table layout")
   const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
-  const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
+  const unsigned vk = ii * 8u * (unsigned)M, vc = ii * 16u, planeB = (unsigned)M * (unsigned)W * 8u;
   auto load_layer = [&](int j, double (&r)[NR]) {
     const idx_t *ix = sI + j * NI;
     if (M > 0) {
@@ -403,19 +403,10 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char *>(reinterpret_cast<const char *>(p.kappa) + base), 0,
           (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
-      const unsigned po = (unsigned)(mine - base) + off;
-#pragma unroll
-      for (int mm = 0; mm < M; mm++) {
-        r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
-        r[2 * mm + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + planeB + mm * rowB), 0, 0));
-      }
+      load_table_lane<M>(rs_k, (unsigned)(mine - base) + vk, 0, planeB, r);
     }
 #pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      const unsigned po = (unsigned)ix[1 + cc] + off;
-      r[2 * M + 2 * cc] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)po, 0, 0));
-      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)(po + rowB), 0, 0));
-    }
+    for (int cc = 0; cc < C; cc++) load_cia_lane(rs_c, (unsigned)ix[1 + cc] + vc, 0, r + 2 * M + 2 * cc);
   };
   auto clampk = [&](int k) { return k < kend ? k : kend; };
 

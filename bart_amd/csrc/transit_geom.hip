@@ -81,12 +81,13 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
     const int l = L - 1 - k;
     double e = c[2 + 2 * M + 2 * C] * nu4;
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
-    const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + ii;
+    // grid [plane][W][M], CIA [pair plane][W][2] (kernels.hpp, "Table layout")
+    const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + (size_t)ii * M;
     for (int m = 0; m < M; m++)
-      e += c[2 + 2 * m] * kb[(size_t)m * W] + c[3 + 2 * m] * kb[MW + (size_t)m * W];
+      e += c[2 + 2 * m] * kb[m] + c[3 + 2 * m] * kb[MW + m];
     for (int cc = 0; cc < C; cc++) {
-      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + ii;
-      e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[W];
+      const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + 2 * (size_t)ii;
+      e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[1];
     }
     if (k > 0) {
       sP[(size_t)k * 64 + threadIdx.x] = eprev + e;
@@ -152,10 +153,10 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   const int nkt = (L + 15) / 16, ns = 4 * nkt;
   const double *__restrict__ dsm = p.ds + (size_t)w * chord_table_size(L);
 
-  // table loads: per-lane byte offset = plane offset of the lane's layer + row + lane
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  // table loads: per-lane byte offset = plane offset of the lane's layer + the lane's
+  // wavenumber inside the plane (kernels.hpp, "Table layout")
   const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cia), 0, (int)p.cia_bytes, 0x00020000);
-  const unsigned off = ii * 8u, rowB = (unsigned)W * 8u, planeB = (unsigned)M * rowB;
+  const unsigned vk = ii * 8u * (unsigned)M, vc = ii * 16u, planeB = (unsigned)M * (unsigned)W * 8u;
   auto load_layer = [&](int j, double (&r)[NR]) {
     const idx_t *ix = sI + j * NI;
     if (M > 0) {
@@ -165,19 +166,10 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
       const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char *>(reinterpret_cast<const char *>(p.kappa) + base), 0,
           (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
-      const unsigned po = (unsigned)(mine - base) + off;
-#pragma unroll
-      for (int mm = 0; mm < M; mm++) {
-        r[2 * mm] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + mm * rowB), 0, 0));
-        r[2 * mm + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_k, (int)(po + planeB + mm * rowB), 0, 0));
-      }
+      load_table_lane<M>(rs_k, (unsigned)(mine - base) + vk, 0, planeB, r);
     }
 #pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      const unsigned po = (unsigned)ix[1 + cc] + off;
-      r[2 * M + 2 * cc] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)po, 0, 0));
-      r[2 * M + 2 * cc + 1] = __builtin_bit_cast(double, (v2u)__builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)(po + rowB), 0, 0));
-    }
+    for (int cc = 0; cc < C; cc++) load_cia_lane(rs_c, (unsigned)ix[1 + cc] + vc, 0, r + 2 * M + 2 * cc);
   };
 
   double P[4 * KT];  // pair sums e_{j-1} + e_j of this lane's layers j = 4 s + q

@@ -10,10 +10,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
-SOURCES = ["rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "lbl.hip", "transit_geom.hip",
+SOURCES = ["rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "lbl.hip",
+           "transit_geom.hip",
            "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "io.cpp"]   # longest first
 HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
+
+
+# per-file compiler options (see the comment on rt_eclipse_fast in csrc/rt_eclipse.hpp)
+EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc() -> str:
@@ -37,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
              "-Wall", "-Wno-unused-result", *os.environ.get("BARTRT_CXXFLAGS", "").split()]
     def compile_one(src: str) -> str:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), *flags, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -36,6 +36,7 @@ namespace bartrt {
 constexpr long kQuadMaxColumns = 640;
 constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this: 1 walker 23 us, 2 walkers 30 us
 constexpr long kSplitMaxColumns = 1300;
+constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
 
 // ---------------------------------------------------------------------------
 // XCD-aware block -> (tile, walker) map.  Blocks b and b+8 share an XCD (and
@@ -63,7 +64,16 @@ __host__ __device__ inline size_t integ_lds_doubles(int L) {
 // orders them so; 0 and 60 degrees of the usual raygrid), so its transmittance
 // is the first one's square: exp(-2 tau / mu) = exp(-tau / mu)^2 -- one
 // multiplication instead of one of the six exponentials of a layer.
-template <int AT, int MT, int CT, bool SQ, int INTEG>
+// SCHED only names the instantiation: SCHED = 1 is compiled in its own translation
+// unit (rt_eclipse_i0_ilp.hip) under the compiler's maximum-ILP scheduling strategy.
+// The default (maximum-occupancy) schedule lays the A + 1 exponentials' Horner
+// chains out one after the other -- nine dependent fp64 FMAs in a row, five times
+// -- which a SIMD with three resident waves hides and a SIMD with one or two does
+// not; the ILP schedule keeps the chains interleaved as written, at 211 instead of
+// 138 VGPRs (two resident waves per SIMD instead of three).  Measured on the bench
+// grid: 10 walkers 75 -> 71 us, 16: 113 -> 107, 64: 326 -> 324, 256: 1062 -> 1082;
+// launch_rt_spec takes the ILP build below kIlpMaxColumns columns.
+template <int AT, int MT, int CT, bool SQ, int INTEG, int SCHED = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_fast(RtArgs p) {
   extern __shared__ double smem[];
@@ -623,6 +633,10 @@ inline bool order_angles_for_square(RtArgs &r) {
 // returns false when the shape has none (the caller falls back to the generic
 // kernel).  `kmode`: forced variant (BARTRT_KERNEL), empty = by batch size.
 // info (optional): what was launched (name, wavenumbers per recorded column).
+// the single-wave kernel of rule 0 in its ILP-scheduled build (rt_eclipse_i0_ilp.hip);
+// false: no instantiation for this shape
+bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+
 template <int INTEG>
 bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::string &kmode, bool force_window,
                     bool allow_sq, hipError_t &err, RtLaunchInfo *info) {
@@ -687,6 +701,10 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
   b.ntiles = a.ntiles;
   if (info) { info->kernel = "rt_eclipse_fast"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
+  if (INTEG == kIntegTransmittance && kmode != "mono_occ" && (kmode == "mono_ilp" || columns < kIlpMaxColumns)) {
+    if (info) info->kernel = "rt_eclipse_fast (ILP-scheduled build)";
+    if (launch_rt_fast_ilp(b, sq, block, nblocks, sh, st, err)) return true;
+  }
 #define BARTRT_FAST(MM, CC)                                                                                        \
   if (a.M == MM && a.C == CC) {                                                                                    \
     if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks), dim3(block), sh, st, b);  \

@@ -1,0 +1,22 @@
+// The single-wave eclipse kernel of integration rule 0, compiled under the
+// compiler's maximum-ILP scheduling strategy (bart_amd/build.py passes
+// -mllvm -amdgpu-sched-strategy=max-ilp for this file only): see rt_eclipse_fast
+// in rt_eclipse.hpp for what that changes and when launch_rt_spec takes this build.
+#include "rt_eclipse.hpp"
+
+namespace bartrt {
+
+bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+#define BARTRT_FAST_ILP(MM, CC)                                                                                    \
+  if (b.M == MM && b.C == CC) {                                                                                    \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, true, 0, 1>), dim3(nblocks), dim3(block), sh, st, b);   \
+    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, false, 0, 1>), dim3(nblocks), dim3(block), sh, st, b);     \
+    err = hipGetLastError();                                                                                       \
+    return true;                                                                                                   \
+  }
+  BARTRT_MC_LIST(BARTRT_FAST_ILP)
+#undef BARTRT_FAST_ILP
+  return false;
+}
+
+}  // namespace bartrt

@@ -267,6 +267,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--same-walkers", action="store_true",
+                    help="diagnostic: every walker of a batch carries the batch's first profile (all table "
+                         "planes shared: what the launch costs without its own HBM traffic); not a benchmark")
     ap.add_argument("--dry-gloo", action="store_true",
                     help="no GPU: stub engine, CPU tensors, gloo backend (launch-path check, not a measurement)")
     ap.add_argument("--master-port", type=int, default=0,
@@ -344,6 +347,8 @@ def main():
         steps do not re-read exactly the same table planes."""
         nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
         profs_h = make_profiles(case, nwalk * nsets, seed=20260103).reshape(nsets, nwalk, -1)
+        if a.same_walkers:
+            profs_h[:] = profs_h[:, :1]
         d_prof = torch.from_numpy(profs_h).to(dev)
         # N > 1: the steps' local blocks go into bucket slots; one all-gather per
         # bucket runs on RCCL's stream while the next bucket's kernels run on the
@@ -479,6 +484,8 @@ def main():
                             "`toomuch` cut skips the fraction of layers reported as 1 - roofline.layers_walked_frac"
                             % (a.nlayers, a.nwave, a.walkers, nsets),
                 "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave, "integ": 0,
+                **({"DIAGNOSTIC": "--same-walkers: identical profiles in a batch, not the benchmark"}
+                   if a.same_walkers else {}),
                 "parallelism": "wavenumber-block shard x%d + all-gather" % world if world > 1
                                else "single GPU",
             },

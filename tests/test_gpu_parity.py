@@ -145,7 +145,7 @@ def wide_cases(tmp_path_factory):
 
 
 @pytest.mark.parametrize("integ", [0, 1, 2])
-@pytest.mark.parametrize("mode", ["generic", "mono", "split", "quad", "octo"])
+@pytest.mark.parametrize("mode", ["generic", "mono_occ", "mono_ilp", "split", "quad", "octo"])
 def test_every_kernel_variant_matches_oracle(small_case, wide_cases, mode, integ):
     """The RT kernels (generic fallback, single-wave specialised, producer/consumer
     split, quad-layer with four and with eight lane rows) under each integration

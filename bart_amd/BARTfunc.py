@@ -96,8 +96,9 @@ class WorkerConfig:
 class Worker:
     """Initialisation of BARTfunc.py:134-299 plus a batched ``step``."""
 
-    def __init__(self, cfg: WorkerConfig, shard=None, device=None):
+    def __init__(self, cfg: WorkerConfig, shard=None, device=None, group=None):
         self.cfg = cfg
+        self.group = group      # process group of the wavenumber shards (None: the default group)
         if cfg.PTtype not in PT_NPARS:
             raise ValueError("unknown PTtype %r (known: %s)" % (cfg.PTtype, sorted(PT_NPARS)))
         tep = hostio.TepFile(cfg.tep_name)
@@ -178,7 +179,7 @@ class Worker:
             # block, RCCL all-gather of the spectra, band integration on the full grid
             import torch
             d_par = torch.from_numpy(p).cuda()
-            band_d, status_d, _ = engine.step_batch_sharded(d_par, self.nfilters)
+            band_d, status_d, _ = engine.step_batch_sharded(d_par, self.nfilters, group=self.group)
             torch.cuda.synchronize()
             band, status = band_d.cpu().numpy(), status_d.cpu().numpy()
         else:
@@ -212,7 +213,33 @@ def comm_disconnect(comm):
     comm.Disconnect()
 
 
-def main(comm, argv=None, group=None):
+def shard_group_up(group, wrank: int, ngpu: int, backend: str = "nccl"):
+    """Bring-up of the wavenumber-sharded workers (BARTRT_GPUS = G > 1): the first G
+    ranks of the workers' communicator each drive one GPU.  Rank 0's rendezvous
+    port (BARTRT_PORT) is broadcast over ``group`` and the G ranks join one
+    torch.distributed process group (RCCL) -- or, when the process already has a
+    default group (a launcher created it), a subgroup of its first G ranks.
+    Returns the process group of the shards (None on the other ranks).
+    ``backend`` is "gloo" in the CPU test of this path."""
+    port = np.array([int(os.environ.get("BARTRT_PORT", "29533"))])
+    group.Bcast(port, root=0)
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pg = dist.new_group(ranks=list(range(ngpu)), backend=backend)   # every rank makes the call
+        return pg if wrank < ngpu else None
+    if wrank >= ngpu:
+        return None
+    kw = {}
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(wrank)
+        kw["device_id"] = torch.device("cuda", wrank)
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % int(port[0]),
+                            rank=wrank, world_size=ngpu, **kw)
+    return dist.group.WORLD
+
+
+def main(comm, argv=None, group=None, worker_factory=None, shard_backend="nccl"):
     """The reference's ``main(comm)`` (BARTfunc.py:33-412) on the GPU engine.
 
     ``comm`` is the intercommunicator to the MC3 master, one worker process per
@@ -221,11 +248,16 @@ def main(comm, argv=None, group=None):
     vectors are gathered to worker 0 every step, evaluated there as ONE batch on
     the GPU, and the band fluxes scattered back before each worker answers the
     master -- MC3 is unchanged, the engine is initialised once, and the forward
-    models of a step run batched instead of one engine call per process."""
+    models of a step run batched instead of one engine call per process.
+
+    ``worker_factory(cfg, shard=, device=, group=)`` builds the object whose
+    ``step(params[n, npars]) -> bandflux[n, nfilters]`` evaluates a batch (default:
+    :class:`Worker`); the CPU test of the sharded path passes a stand-in."""
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument("-c", "--config_file", required=True)
     args, _ = ap.parse_known_args(argv)
     cfg = WorkerConfig.from_cfg(args.config_file)
+    make = worker_factory or Worker
     verb = comm.Get_rank() == 0
     array1 = np.zeros(2, int)
     comm_bcast(comm, array1)
@@ -235,21 +267,15 @@ def main(comm, argv=None, group=None):
     # BARTRT_GPUS = G > 1: the first G workers each drive one GPU of the node and
     # hold one wavenumber block of the tables; every step they all evaluate the
     # whole batch on their block and reassemble the spectra with one RCCL
-    # all-gather (Worker.step's sharded path).  Needs G GPUs: not exercised by the
-    # single-GPU test suite.
+    # all-gather (Worker.step's sharded path).  The launch path is covered on CPU
+    # by tests/test_distributed_cpu.py (gloo, two worker processes).
     ngpu = max(1, min(int(os.environ.get("BARTRT_GPUS", "1")), nworkers))
+    shard_pg = None
     if ngpu > 1:
-        port = np.array([int(os.environ.get("BARTRT_PORT", "29533"))])
-        group.Bcast(port, root=0)
-        if wrank < ngpu:
-            import torch
-            import torch.distributed as dist
-            torch.cuda.set_device(wrank)
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(port[0]),
-                                    rank=wrank, world_size=ngpu, device_id=torch.device("cuda", wrank))
-        w = Worker(cfg, shard=(wrank, ngpu), device=wrank) if wrank < ngpu else None
+        shard_pg = shard_group_up(group, wrank, ngpu, shard_backend)
+        w = make(cfg, shard=(wrank, ngpu), device=wrank, group=shard_pg) if wrank < ngpu else None
     else:
-        w = Worker(cfg) if wrank == 0 else None   # the GPU engine lives in worker 0
+        w = make(cfg) if wrank == 0 else None   # the GPU engine lives in worker 0
     if verb and w is not None:
         print("There are {:d} layers and {:d} species.".format(w.nlayers, w.nspecies))
     params = np.zeros(npars, np.double)
@@ -279,9 +305,10 @@ def main(comm, argv=None, group=None):
     nbad = w.nbad if w is not None else None
     if w is not None:
         w.close()
-        if ngpu > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
+    if ngpu > 1 and shard_pg is not None:
+        import torch.distributed as dist
+        if shard_pg is dist.group.WORLD:
+            dist.destroy_process_group()      # this function created it
     if verb and nbad is not None:
         print("Bad iterations of {} due to:".format("chain 0" if nworkers == 1 else "all chains"))
         print("  Temperature: {}".format(nbad[1]))

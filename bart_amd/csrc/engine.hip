@@ -79,15 +79,31 @@ static bool file_exists(const std::string &p) {
 
 void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   cfg = cfg_in;
-  // Keys of the reference's whitelist (code/makecfg.py:36-52) that would change
-  // the physics and are not implemented are refused, not ignored.  (Accepted
-  // without effect: verb, wnosamp, allowq, rad*, orbpars*, tauiso, outtau,
-  // taulevel, modlevel -- sampling and diagnostic controls of the CPU engine.)
-  if (cfg_has(cfg, "cloudext") && cfg_num(cfg, "cloudext", 0.0) != 0.0)
-    throw IoError{"transit cfg: the radius-ramp cloud (cloudrad / cloudfct / cloudext) is not implemented; "
-                  "use cloudtop (opaque deck at a pressure)"};
-  if (cfg_has(cfg, "transparent") && cfg["transparent"] != "0" && cfg["transparent"] != "no")
-    throw IoError{"transit cfg: 'transparent' is not implemented"};
+  // Keys of the reference's whitelist (code/makecfg.py:36-52) accepted without
+  // effect: verb, allowq, rad*, orbpars*, tauiso, outtau, taulevel, modlevel --
+  // sampling and diagnostic controls of the CPU engine.
+  // Radius-ramp cloud (makecfg.py:46-47): `cloudrad <up> <down>` (blank or comma
+  // separated, in units of `cloudfct`, default `radfct`, default km) and `cloudext`
+  // (cm-1): grey extinction 0 above <up>, rising linearly to cloudext at <down>,
+  // cloudext below -- on the radii of each call's own hydrostatic solution.
+  if (cfg_has(cfg, "cloudext") && cfg_num(cfg, "cloudext", 0.0) != 0.0) {
+    std::string cr = cfg_has(cfg, "cloudrad") ? cfg["cloudrad"] : "";
+    for (char &ch : cr) if (ch == ',') ch = ' ';
+    TCfg tmp;
+    tmp["cloudrad"] = cr;
+    const auto v = cfg_list(tmp, "cloudrad");
+    const double fct = cfg_num(cfg, "cloudfct", cfg_num(cfg, "radfct", 1e5));
+    if (v.size() != 2 || !(v[0] > v[1]) || !(v[1] > 0) || !(fct > 0))
+      throw IoError{"transit cfg: cloudext needs `cloudrad <up> <down>` with up > down > 0 (units of cloudfct)"};
+    cloud_rup = v[0] * fct;
+    cloud_rdown = v[1] * fct;
+    cloud_ext = cfg_num(cfg, "cloudext", 0.0);
+    if (!(cloud_ext > 0)) throw IoError{"transit cfg: cloudext must be positive"};
+  }
+  // `transparent` (makecfg.py:44): transit geometry without an opaque core below the
+  // last chord; no effect on the eclipse geometry
+  transparent = cfg_has(cfg, "transparent") && cfg["transparent"] != "0" && cfg["transparent"] != "no" &&
+                cfg["transparent"] != "false";
   // An opacity file that does not exist yet is generated from the line list
   // first (what `transit --justOpacity` does, BART.py:561-565), by a
   // temporary line-by-line engine on the same configuration.
@@ -465,6 +481,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.gsurf = gsurf; pa.refradius = refradius;
   pa.scat_flag = scat_flag; pa.scat_value = scat_value;
   pa.has_cloud = has_cloud; pa.cloudtop = cloudtop;
+  pa.cloud_rup = cloud_rup; pa.cloud_rdown = cloud_rdown; pa.cloud_ext = cloud_ext;
   pa.coef = d_coef; pa.idx = d_idx; pa.kstop = d_kstop;
   pa.ok = d_okp ? d_okp : d_ok;
   pa.rad_out = d_rad;
@@ -498,6 +515,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.ntiles = (r.W + block - 1) / block;
   r.rtop = d_rtop; r.ds = d_ds;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
+  r.transparent = transparent ? 1 : 0;
   if (timing) {
     while ((int)ev.size() < ev_used + 2) {
       hipEvent_t e;

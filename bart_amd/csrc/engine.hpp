@@ -37,6 +37,8 @@ struct Engine {
   int integ = 0;          // integration rule of the eclipse geometry (integ.hpp); cfg `integ`, BARTRT_INTEG
   double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;
+  double cloud_rup = 0, cloud_rdown = 0, cloud_ext = 0;  // radius-ramp cloud (cm, cm, cm-1); 0 = none
+  bool transparent = false;                              // transit geometry: no opaque core
   int device = 0;
   // device-resident inputs
   double *d_kappa = nullptr, *d_cia = nullptr, *d_wn = nullptr, *d_wn_full = nullptr;

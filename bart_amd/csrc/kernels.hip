@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     const double *c = sC + k * NC;
     const idx_t *ix = sI + k * NI;
     const int l = L - 1 - k;
-    double e = c[2 + 2 * M + 2 * C] * nu4;
+    double e = c[2 + 2 * M + 2 * C] * nu4 + c[3 + 2 * M + 2 * C];   // Rayleigh + grey cloud
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
     // grid [plane][W][M], CIA [pair plane][W][2] (kernels.hpp, "Table layout")
     const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + (size_t)ii * M;

@@ -30,8 +30,9 @@ constexpr int kMaxMol = 16;
 //   [1]            c2/T_k = (h c / k_B) / T_k  (cm)
 //   [2 .. 2+2M)    (rho_m (1-f), rho_m f) per table molecule
 //   [.. +2C)       (n1 n2 (1-f), n1 n2 f) / amagat^2 per CIA table
-//   [last]         Rayleigh coefficient (multiplies wn^4)
-__host__ __device__ inline int coef_stride(int M, int C) { return 3 + 2 * M + 2 * C; }
+//   [last - 1]     Rayleigh coefficient (multiplies wn^4)
+//   [last]         grey extinction of the layer, cm-1 (the radius-ramp cloud)
+__host__ __device__ inline int coef_stride(int M, int C) { return 4 + 2 * M + 2 * C; }
 // chord table of the transit geometry: [row tile][step][lane], (L/16)^2 * 256 doubles
 __host__ __device__ inline size_t chord_table_size(int L) {
   const size_t nkt = (size_t)(L + 15) / 16;
@@ -133,6 +134,9 @@ struct PrepArgs {
   // scattering / cloud
   int scat_flag, iH2, iHe, has_cloud;
   double scat_value, cloudtop;
+  // radius-ramp cloud (cfg cloudrad / cloudfct / cloudext): grey extinction 0 above
+  // cloud_rup, rising linearly to cloud_ext at cloud_rdown, cloud_ext below (cm, cm-1)
+  double cloud_rup, cloud_rdown, cloud_ext;
   // optional per-walker overrides [nw][3]: reference radius (cm), cloud-top pressure
   // (barye), scattering value; NaN = the engine's setting (prep_body)
   const double *over;
@@ -175,6 +179,7 @@ struct RtArgs {
   // transit geometry
   const double *rtop, *ds;
   double inv_starrad2;
+  int transparent;         // transit geometry: no opaque core below the last chord (cfg `transparent`)
 };
 
 // What launch_rt launched (diagnostics; the byte model of bench.py)

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
     }
     const double *c = sC + k * NC;
     const idx_t *ix = sI + k * NI;
-    double e = acc + c[2 + 2 * C] * nu4;
+    double e = acc + c[2 + 2 * C] * nu4 + c[3 + 2 * C];   // + Rayleigh + grey cloud
     for (int cc = 0; cc < C; cc++) {
       const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + 2 * (size_t)ii;
       e += c[2 + 2 * cc] * ab[0] + c[3 + 2 * cc] * ab[1];   // CIA pair plane [W][2] (kernels.hpp)

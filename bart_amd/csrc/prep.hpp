@@ -178,6 +178,15 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
       ray *= k0;
     }
     c[2 + 2 * M + 2 * C] = ray;
+    // radius-ramp cloud on this walker's own hydrostatic radii
+    double grey = 0.0;
+    if (p.cloud_ext > 0.0) {
+      const double r = sR[l];
+      grey = r >= p.cloud_rup ? 0.0
+             : (r <= p.cloud_rdown ? p.cloud_ext
+                                   : p.cloud_ext * (p.cloud_rup - r) / (p.cloud_rup - p.cloud_rdown));
+    }
+    c[3 + 2 * M + 2 * C] = grey;
   }
   if (p.rad_out)
     for (int l = threadIdx.x; l < L; l += blockDim.x) p.rad_out[(size_t)w * L + l] = bad ? 0.0 : sR[l];

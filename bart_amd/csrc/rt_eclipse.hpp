@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_W
 void rt_eclipse_fast(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
-  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
   constexpr int NR = NLD > 0 ? NLD : 1;
   const int L = p.L, W = p.W;
   int tile, w;
@@ -132,7 +132,7 @@ void rt_eclipse_fast(RtArgs p) {
     const bool live = active && k <= kend;
     read_rec(k + 1, cfn);
     const double lv = live ? 0.5 : 0.0;
-    double e = cf[2 + 2 * M + 2 * C] * nu4;
+    double e = fma(cf[2 + 2 * M + 2 * C], nu4, cf[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
 #pragma unroll
     for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
     tc.layer(k, live, lv, e, cf[0], sW);
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, BARTRT_W
 void rt_eclipse_split(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
-  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
   constexpr int NR = NLD > 0 ? NLD : 1;
   const int L = p.L, W = p.W;
   int tile, w;
@@ -247,7 +247,7 @@ void rt_eclipse_split(RtArgs p) {
 #pragma unroll
       for (int j = 0; j < NC; j++) cf[j] = c[j];
       const double lv = live ? 0.5 : 0.0;
-      double e = cf[2 + 2 * M + 2 * C] * nu4;
+      double e = fma(cf[2 + 2 * M + 2 * C], nu4, cf[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
 #pragma unroll
       for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
       tc.layer(k, live, lv, e, cf[0], sW);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   static_assert(!(SQ && INTEG != kIntegTransmittance), "the squared-transmittance shortcut is built for rule 0 only");
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
-  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
+  constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
   constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
   constexpr int WN = 64 / R;           // wavenumbers per wave
   constexpr bool SIMPSON = INTEG == kIntegSimpson;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
     double cf[NC];
 #pragma unroll
     for (int x = 0; x < NC; x++) cf[x] = c[x];
-    double e = cf[2 + 2 * M + 2 * C] * nu4;
+    double e = fma(cf[2 + 2 * M + 2 * C], nu4, cf[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
 #pragma unroll
     for (int x = 0; x < NLD; x++) e = fma(cf[2 + x], rv[x], e);
     // extinction of the layer above

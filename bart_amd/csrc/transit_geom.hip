@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
     const double *c = sC + k * NC;
     const idx_t *ix = sI + k * NI;
     const int l = L - 1 - k;
-    double e = c[2 + 2 * M + 2 * C] * nu4;
+    double e = c[2 + 2 * M + 2 * C] * nu4 + c[3 + 2 * M + 2 * C];   // Rayleigh + grey cloud
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
     // grid [plane][W][M], CIA [pair plane][W][2] (kernels.hpp, "Table layout")
     const double *kb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.kappa) + ix[0]) + (size_t)ii * M;
@@ -110,7 +110,10 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
     if (!__any(active)) break;
   }
   if (valid) {
-    p.spec[(size_t)w * W + i] = (rt[0] * rt[0] - 2.0 * integ) * p.inv_starrad2;
+    // below the last chord the planet is an opaque disc -- unless the cfg says
+    // `transparent`: then those rays keep the last chord's transmission
+    const double core = p.transparent ? exp(-tau) * rt[last] * rt[last] : 0.0;
+    p.spec[(size_t)w * W + i] = (rt[0] * rt[0] - 2.0 * integ - core) * p.inv_starrad2;
     if (p.tau_out) {
       for (int k = last + 1; k < L; k++) p.tau_out[(size_t)i * L + k] = tau;
       p.last_out[i] = last;
@@ -126,7 +129,7 @@ template <int MT, int CT, int KT>
 __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int M = MT, C = CT;
-  constexpr int NC = 3 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
+  constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
   const int L = p.L, W = p.W;
   const int b = blockIdx.x;
   const int xcd = b & 7, jb = b >> 3;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
       double rv[NR];
       load_layer(jc, rv);
       const double *c = sC + jc * NC;
-      double e = c[2 + 2 * M + 2 * C] * nu4;
+      double e = fma(c[2 + 2 * M + 2 * C], nu4, c[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
 #pragma unroll
       for (int x = 0; x < NLD; x++) e = fma(c[2 + x], rv[x], e);
       const double below = __shfl(e, (lane + 48) & 63);  // row q - 1, i.e. layer j - 1 (q >= 1)
@@ -294,7 +297,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   static const bool force_window = std::getenv("BARTRT_WINDOW") != nullptr;  // (tests)
   const bool window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
   const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!window || window_fits(a, 4));
-  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesDeep) {
+  if (!generic_only && !a.ext && !a.tau_out && !a.transparent && fits32 && a.L <= 16 * kMfmaTilesDeep) {
     RtArgs b = a;
     b.window = window;
     b.ntiles = (a.W + 63) / 64;

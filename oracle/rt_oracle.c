@@ -121,7 +121,14 @@ int orc_extinction(const rt_oracle_cfg *c, const double *prof, double *ext,
     const double T = temp[l];
     const double nd = c->press[l] / (ORC_KB * T); /* molecules cm-3 */
     double *e = ext + (size_t)l * W;
-    for (int i = 0; i < W; i++) e[i] = c->extra_ext ? c->extra_ext[(size_t)l * W + i] : 0.0;
+    double grey = 0.0;
+    if (c->cloud_ext > 0.0) {
+      double r = rad[l];
+      grey = r >= c->cloud_rup ? 0.0
+             : (r <= c->cloud_rdown ? c->cloud_ext
+                                    : c->cloud_ext * (c->cloud_rup - r) / (c->cloud_rup - c->cloud_rdown));
+    }
+    for (int i = 0; i < W; i++) e[i] = grey + (c->extra_ext ? c->extra_ext[(size_t)l * W + i] : 0.0);
     /* molecular extinction: linear-in-T between the two bracketing planes
      * of the layer's own slab of the grid, times the molecule's mass density */
     if (M > 0) {
@@ -340,6 +347,8 @@ static void column_transit(const rt_oracle_cfg *c, int L, const double *e_col,
    * annulus between r_last and the top only */
   double rl = r_col[last];
   double area = rl * rl + 2.0 * (0.5 * (r_col[0] * r_col[0] - rl * rl) - integ);
+  /* `transparent`: no opaque core, the rays below the last chord keep its transmission */
+  if (c->transparent) area -= exp(-tau[last]) * rl * rl;
   *mod = area / (c->starrad * c->starrad);
   *last_out = last;
 }

@@ -82,6 +82,12 @@ typedef struct {
   int    scat_iHe;          /* species index of He (or -1) */
   double starrad;           /* cm (transit geometry only) */
   const double *extra_ext;  /* optional [L][W] extinction added as is (line-by-line), or NULL */
+  /* radius-ramp cloud (cfg cloudrad / cloudfct / cloudext, code/makecfg.py:46-47):
+   * grey extinction 0 above cloud_rup, linear up to cloud_ext at cloud_rdown,
+   * cloud_ext below; cloud_ext = 0: none.  Unverified against transit's source. */
+  double cloud_rup, cloud_rdown, cloud_ext;
+  int transparent;          /* transit geometry: rays below the last chord keep its transmission */
+  int reserved2;
 } rt_oracle_cfg;
 
 /* Hydrostatic radii.  Follows code/makeatm.py:183-263 (radpress), in cgs and

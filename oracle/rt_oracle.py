@@ -36,6 +36,8 @@ class _Cfg(C.Structure):
         ("refradius", C.c_double), ("cloudtop", C.c_double),
         ("scat_value", C.c_double), ("scat_iH2", C.c_int), ("scat_iHe", C.c_int),
         ("starrad", C.c_double), ("extra_ext", C.c_void_p),
+        ("cloud_rup", C.c_double), ("cloud_rdown", C.c_double), ("cloud_ext", C.c_double),
+        ("transparent", C.c_int), ("reserved2", C.c_int),
     ]
 
 
@@ -222,6 +224,11 @@ class OracleEngine:
             c.starrad = float(k["starrad"]) * 6.96e10
         if "cloudtop" in k:
             c.has_cloud, c.cloudtop = 1, 10.0 ** float(k["cloudtop"]) * 1e6
+        if float(k.get("cloudext", 0) or 0) != 0.0:
+            up, down = (float(x) for x in k["cloudrad"].replace(",", " ").split())
+            fct = float(k.get("cloudfct", k.get("radfct", 1e5)))
+            c.cloud_rup, c.cloud_rdown, c.cloud_ext = up * fct, down * fct, float(k["cloudext"])
+        c.transparent = int(k.get("transparent", "0") not in ("0", "no", "false"))
         self.c = c
         self.nprof = (S + 1) * self.L
 

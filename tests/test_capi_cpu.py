@@ -91,9 +91,9 @@ def test_missing_and_malformed_inputs(lib, tmp_path):
     with pytest.raises(trm.TransitError, match="gsurf"):
         trm.transit_init(3, ["transit", "-c", str(tmp_path / "g.cfg")])
     bad = dict(case.keys)
-    bad.update(cloudrad="7.5e4 7.0e4", cloudfct="1e5", cloudext="1e-6")   # the CPU engine's ramp cloud
+    bad.update(cloudrad="7.0e4 7.5e4", cloudfct="1e5", cloudext="1e-6")   # ramp cloud with its top below its bottom
     synth.write_tcfg(str(tmp_path / "cl.cfg"), bad)
-    with pytest.raises(trm.TransitError, match="cloudext"):
+    with pytest.raises(trm.TransitError, match="cloudrad"):
         trm.transit_init(3, ["transit", "-c", str(tmp_path / "cl.cfg")])
     with open(case.opacity, "r+b") as f:
         f.truncate(4000)

@@ -331,3 +331,72 @@ def test_wavelength_keys_of_the_demo_configuration(demo_case, tmp_path):
         np.testing.assert_allclose(a, o.run(prof), rtol=RTOL)
     finally:
         trm.free_memory()
+
+
+@pytest.mark.parametrize("mode", ["", "generic", "mono_ilp", "split", "quad"])
+def test_radius_ramp_cloud(tmp_path, mode):
+    """cloudrad / cloudfct / cloudext of the reference's transit whitelist
+    (code/makecfg.py:46-47): a grey extinction that rises linearly
+    from 0 at the upper radius to cloudext at the lower one and stays there below, on
+    the radii of each call's own hydrostatic solution -- every eclipse kernel and both
+    transit kernels against the oracle, cloud inside the column so some layers sit in
+    each of its three regimes."""
+    import os, subprocess, sys
+    from bart_amd import synth
+    from oracle import rt_oracle as orc
+    jobs = []
+    for name, extra in (("ecl", {}), ("tra", {"solution": "transit", "starrad": 1.145})):
+        d = str(tmp_path / name)
+        c0 = synth.make_case(d, nlayers=60, nwave=200, write=False)
+        r = np.sort(c0.radius_km)
+        keys = dict(extra, cloudrad="%.1f,%.1f" % (r[35], r[12]), cloudfct=1e5, cloudext=3e-9)
+        c = synth.make_case(d, nlayers=60, nwave=200, extra_keys=keys)
+        profs = walkers(c, 4, seed=17)
+        np.save(os.path.join(d, "p.npy"), profs)
+        jobs.append((os.path.join(d, "p.npy"), c.tcfg, os.path.join(d, "s.npy")))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bart_amd import engine, transit_module as trm\n"
+            "for pfile, tcfg, out in %r:\n"
+            "    engine.init(tcfg); np.save(out, engine.run_batch(np.load(pfile))); trm.free_memory()\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), jobs))
+    env = dict(os.environ)
+    env.pop("BARTRT_KERNEL", None)
+    if mode:
+        env["BARTRT_KERNEL"] = mode
+    subprocess.check_call([sys.executable, "-c", code], env=env, timeout=600)
+    for pfile, tcfg, out in jobs:
+        o = orc.OracleEngine(tcfg)
+        assert o.c.cloud_ext == 3e-9 and o.c.cloud_rup > o.c.cloud_rdown > 0
+        ref = o.run_batch(np.load(pfile))
+        np.testing.assert_allclose(np.load(out), ref, rtol=RTOL)
+        o.c.cloud_ext = 0.0
+        assert np.abs(o.run_batch(np.load(pfile)) / ref - 1).max() > 1e-3      # the cloud matters
+
+
+def test_transparent_planet(tmp_path):
+    """`transparent` (code/makecfg.py:44): transit geometry without an opaque core --
+    the rays below the last chord keep its transmission (DESIGN.md C16, unverified);
+    against the oracle, and with no effect on an eclipse run."""
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    for toomuch in (0.3, 10.0):
+        c = synth.make_case(str(tmp_path / ("t%g" % toomuch)), nlayers=40, nwave=150, toomuch=toomuch,
+                            extra_keys={"solution": "transit", "starrad": 1.145, "transparent": 1})
+        profs = walkers(c, 3, seed=2)
+        engine.init(c.tcfg)
+        try:
+            got = engine.run_batch(profs)
+        finally:
+            trm.free_memory()
+        o = orc.OracleEngine(c.tcfg)
+        assert o.c.transparent == 1
+        np.testing.assert_allclose(got, o.run_batch(profs), rtol=RTOL)
+        o.c.transparent = 0
+        opaque = o.run_batch(profs)
+        assert np.all(got < opaque) and (toomuch > 1 or np.abs(got / opaque - 1).max() > 1e-3)
+    e = synth.make_case(str(tmp_path / "ecl"), nlayers=40, nwave=150, extra_keys={"transparent": 1})
+    engine.init(e.tcfg)
+    try:
+        np.testing.assert_allclose(engine.run_batch(profs), orc.OracleEngine(e.tcfg).run_batch(profs), rtol=RTOL)
+    finally:
+        trm.free_memory()

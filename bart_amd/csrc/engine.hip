@@ -393,7 +393,8 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     // measured on the config-5 shape (tools/lbl_bench.py): tiles rarely turn opaque
     // as a whole, so the lazy fused kernel (55 ms) loses to the eager two-pass form
     // (43 ms) that exposes all layers as parallel work; BARTRT_LBL=lazy selects it
-    lbl_eager = !(m && std::string(m) == "lazy");
+    // (the fused kernel evaluates the line sums on the output points: no oversampling)
+    lbl_eager = !(m && std::string(m) == "lazy") || lbl->dev.osamp > 1;
   }
   HIPCHK(hipMalloc(&d_tau, sizeof(double) * (size_t)Wl * L));
   HIPCHK(hipMalloc(&d_last, sizeof(int) * (size_t)Wl));

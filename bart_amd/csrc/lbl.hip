@@ -106,7 +106,7 @@ struct StateArgs {
   const double *mass;    // [S] amu
   const double *diam;    // [S] cm
   const double *tgrid;   // table mode temperatures
-  double *state;         // [nstate][2 + 3*niso]: T, unused, then (dopfac, alphaL, scale) per isotope
+  double *state;         // [nstate][2 + 3*niso]: T, oversampling factor dv, then (dopfac, alphaL, scale) per isotope
 };
 
 // One workgroup per state, lanes over isotopes.
@@ -129,11 +129,10 @@ __global__ void lbl_states(StateArgs a, LblDev d) {
   }
   p = a.press[l];
   double *out = a.state + (size_t)st * (2 + 3 * d.niso);
-  if (threadIdx.x == 0) { out[0] = T; out[1] = p; }
   const int i = threadIdx.x;
-  if (i >= d.niso) return;
-  const int g = d.iso_group[i];
-  const double mi = d.iso_mass[i] * kAMU;
+  const bool mine = i < d.niso;
+  const int g = d.iso_group[mine ? i : 0];
+  const double mi = d.iso_mass[mine ? i : 0] * kAMU;
   const double dop = sqrt(2.0 * 0.6931471805599453 * kKB * T / mi) / kLS;
   double sum = 0.0;
   const double dm = d.gdiam[g];
@@ -146,6 +145,24 @@ __global__ void lbl_states(StateArgs a, LblDev d) {
     sum += q[(size_t)a.iHe * qs] * dd * dd * sqrt(1.0 / mi + 1.0 / (a.mass[a.iHe] * kAMU));
   }
   const double aL = sqrt(2.0) / (kLS * sqrt(kPI * kKB * T)) * p * sum;
+  {
+    // oversampling factor of this state (one wave per state: a 64-lane minimum of the
+    // isotopes' line half-widths, Doppler at the low end of the full grid)
+    double wmin = mine ? fmax(d.wn_first * dop, aL) : 1e300;
+    for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o));
+    if (threadIdx.x == 0) {
+      int dv = 1;
+      if (d.osamp > 1) {
+        dv = d.osamp;
+        if (d.osamp_rule == 0)
+          for (int k = 0; k < d.ndiv; k++)
+            if (d.wndelt / d.odiv[k] <= 0.5 * wmin) { dv = d.odiv[k]; break; }
+      }
+      out[0] = T;
+      out[1] = (double)dv;
+    }
+  }
+  if (!mine) return;
   // partition function: linear in T on the database grid, clamped
   const double *zt = d.ztemp + d.iso_toff[i], *zz = d.ztab + d.iso_zoff[i];
   const int nt = d.iso_nt[i];
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
   const int st = blockIdx.y;
   const int tile0 = blockIdx.x * 256;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
+  if (sv[1] > 1.0) return;                    // an oversampled state: lbl_accumulate_fine owns it
   if (narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate_pairs owns it
   const double invT = 1.0 / sv[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,6 +362,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
   const int st = blockIdx.y;
   const int tile0 = blockIdx.x * 256;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
+  if (sv[1] > 1.0) return;                     // an oversampled state: lbl_accumulate_fine owns it
   if (!narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate owns it
   const double invT = 1.0 / sv[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -412,6 +431,106 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
   if (i < a.W) {
     if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + i] = acc;
     else a.out[(size_t)st * a.W + i] = acc;
+  }
+}
+
+// Oversampled states (cfg `wnosamp` > 1 and lines narrower than twice the output
+// spacing; LblDev, "Sampling"): the line sums are evaluated on the state's fine grid,
+// dv points per output spacing, and reduced to the output points -- an odd dv averages
+// the dv fine points centred on the output point, an even dv takes dv + 1 with the
+// two ends at half weight; the first / last point of the full grid use the half of the
+// window that lies on the grid, normalised by its own weights.  On its fine grid every
+// state is broad (dv is chosen so that a half-width spans two fine points or more, and
+// a line is cut at nwidth half-widths), so the lane = point form of lbl_accumulate
+// keeps all lanes busy.  One workgroup per (256 output points, state): sub-tiles of
+// about 1 024 fine points, walked by the 256 lanes in up to nine passes whose sums
+// stay in registers while the window of the line list is staged through LDS once per
+// sub-tile; then the fine values meet in LDS and one lane per output point reduces
+// them in ascending order.
+constexpr int kFinePasses = 9;           // (wnosamp <= 2 160: one output point spans 2 161 fine points)
+__global__ __launch_bounds__(256) void lbl_accumulate_fine(LblDev d, AccArgs a) {
+  __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
+  __shared__ double s_fine[256 * kFinePasses];
+  __shared__ int s_wcount[4];
+  const int st = blockIdx.y;
+  const int tile0 = blockIdx.x * 256;
+  const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
+  if (!(sv[1] > 1.0)) return;             // evaluated on the output points: the other two kernels
+  const int dv = (int)sv[1], h = dv / 2;
+  const double invT = 1.0 / sv[0], step = d.wndelt / dv;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long kmax = (long)(d.wfull - 1) * dv;            // last fine point of the full grid
+  const int tile_end = min(tile0 + 256, a.W);
+  // output points per sub-tile: about 1 024 fine points (at most 2 * h + 1 <= 2 161 when dv > 1 024)
+  const int TO = min(256, max(1, 1024 / dv));
+  const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
+  for (int o0 = tile0; o0 < tile_end; o0 += TO) {
+    const int o1 = min(o0 + TO, tile_end);               // output points [o0, o1)
+    const long c0 = (long)(d.i_off + o0) * dv, c1 = (long)(d.i_off + o1 - 1) * dv;
+    const long fa = max(c0 - h, 0L), fb = min(c1 + h, kmax);
+    const int nf = (int)(fb - fa + 1);
+    // fine point k of the full grid: wn_first + k * step, product and sum rounded one
+    // after the other (a fused multiply-add would move points that sit exactly on a
+    // line's cut to the other side of it)
+    const double nu_a = add_rounded(d.wn_first, mul_rounded((double)fa, step));
+    const double nu_b = add_rounded(d.wn_first, mul_rounded((double)fb, step));
+    double acc[kFinePasses], nu[kFinePasses];
+#pragma unroll
+    for (int ps = 0; ps < kFinePasses; ps++) {
+      acc[ps] = 0.0;
+      nu[ps] = add_rounded(d.wn_first, mul_rounded((double)(fa + ps * 256 + threadIdx.x), step));
+    }
+    for (int g = g_lo; g < g_hi; g++) {
+      long j0, j1;
+      double cmax;
+      line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
+      const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
+      for (long base = j0; base < j1; base += 256) {
+        const long j = base + threadIdx.x;
+        LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
+        if (j < j1) r = stage_line(d, sv, invT, thresh, j);
+        const unsigned long long keep = __ballot(r.cut >= 0.0);
+        if (lane == 0) s_wcount[wave] = __popcll(keep);
+        __syncthreads();
+        int pos = __popcll(keep & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) pos += s_wcount[w];
+        const int cnt = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        if (r.cut >= 0.0) {
+          s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < kFinePasses; ps++) {
+          if (ps * 256 >= nf) break;                     // uniform
+          if (ps * 256 + (int)threadIdx.x < nf) {
+            for (int t = 0; t < cnt; t++) {
+              const double dx = fabs(nu[ps] - s_nu0[t]);
+              if (dx <= s_cut[t]) acc[ps] = add_rounded(acc[ps], mul_rounded(s_amp[t], voigt_k(dx * s_xs[t], s_y[t])));
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < kFinePasses; ps++) s_fine[ps * 256 + threadIdx.x] = acc[ps];
+    __syncthreads();
+    if ((int)threadIdx.x < o1 - o0) {
+      const int o = o0 + threadIdx.x;
+      const long c = (long)(d.i_off + o) * dv;
+      const long lo = max(c - h, 0L), hi = min(c + h, kmax);
+      const bool even = (dv & 1) == 0;
+      double sum = 0.0, wsum = 0.0;
+      for (long f = lo; f <= hi; f++) {
+        const double wgt = (even && (f == c - h || f == c + h)) ? 0.5 : 1.0;
+        sum = fma(wgt, s_fine[f - fa], sum);
+        wsum += wgt;
+      }
+      const double v = sum / wsum;
+      if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + o] = v;
+      else a.out[(size_t)st * a.W + o] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -632,6 +751,25 @@ void lbl_init(Engine &e, const std::string &paths) {
   d.ztab = b->d_ztab; d.ztemp = b->d_ztemp;
   d.nwidth = cfg_num(e.cfg, "nwidth", 20.0);
   d.ethresh = cfg_num(e.cfg, "ethresh", 1e-6);
+  // sampling of the line sums (LblDev, "Sampling")
+  {
+    const double os = cfg_num(e.cfg, "wnosamp", 1.0);
+    if (!(os >= 1.0) || os > 2160.0 || os != std::floor(os))
+      throw IoError{"transit cfg: wnosamp must be an integer between 1 and 2160"};
+    d.osamp = (int)os;
+    d.ndiv = 0;
+    for (int k = 1; k <= d.osamp; k++)
+      if (d.osamp % k == 0) {
+        if (d.ndiv >= 64) throw IoError{"wnosamp: too many divisors"};
+        d.odiv[d.ndiv++] = k;
+      }
+    const char *rule = std::getenv("BARTRT_OSAMP_RULE");   // divisor (default) | full
+    d.osamp_rule = rule && std::string(rule) == "full" ? 1 : 0;
+    d.wn_first = e.wn_full.front();
+    d.wndelt = cfg_num(e.cfg, "wndelt", 1.0) * cfg_num(e.cfg, "wnfct", 1.0);   // the grid's own spacing (Engine::setup)
+    d.i_off = e.lo;
+    d.wfull = e.Wfull;
+  }
   // free the host copy of the big arrays
   for (auto &db : t.db) { db.wn.clear(); db.wn.shrink_to_fit(); db.elow.clear(); db.elow.shrink_to_fit();
                           db.gf.clear(); db.gf.shrink_to_fit(); db.isoid.clear(); db.isoid.shrink_to_fit(); }
@@ -672,6 +810,9 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
                      0, st, d, aa);
   hipLaunchKernelGGL(lbl_accumulate_pairs, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
                      0, st, d, aa);
+  if (d.osamp > 1)   // the states evaluated on a finer grid (each state is owned by one of the three)
+    hipLaunchKernelGGL(lbl_accumulate_fine, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
+                       0, st, d, aa);
   HIPCHK(hipGetLastError());
 }
 

@@ -31,6 +31,14 @@ struct LblDev {
   int iso_zoff[kMaxIso], iso_nt[kMaxIso], iso_toff[kMaxIso];
   const double *ztab, *ztemp;    // concatenated partition functions / their temperatures
   double nwidth, ethresh;
+  // Sampling (cfg `wnosamp`): a layer's line sums are evaluated dv times
+  // finer than the output grid and reduced to it; dv = the smallest divisor of osamp
+  // whose spacing wndelt / dv is at most half the layer's narrowest line half-width
+  // (osamp_rule 1: dv = osamp everywhere).  Fine point k of the FULL grid sits at
+  // wn_first + k * wndelt / dv; this engine's block starts at output index i_off.
+  int osamp, osamp_rule, ndiv, i_off, wfull;
+  int odiv[64];                  // divisors of osamp, ascending
+  double wn_first, wndelt;
   // coarse index of the sorted lists: bucket[boff[g] + b] = first line of group g
   // with nu0 >= bmin + b * bstep (b = 0..nbucket; entry nbucket = gend[g])
   const long *bucket;

@@ -8,6 +8,18 @@ BART_user_manual.tex:449-455), the Doppler and Lorentz half-widths
 (examples/demo/transit_demo.cfg:42-44, 57-58).  The Voigt function itself is
 scipy's Faddeeva routine (exact to ~1e-13), deliberately a different algorithm
 from the product's rational approximation.
+
+Sampling (`wnosamp`, examples/demo/transit_demo.cfg:27-29; convention C15 of
+DESIGN.md, SURVEY.md App. A-5 as recalled, unverified): the line sums of a layer
+are evaluated on a grid `dv` times finer than the output grid and reduced to it.
+dv is the smallest divisor of wnosamp whose spacing wndelt / dv is at most half
+the narrowest line half-width of the layer (over the isotopes: max(Doppler HWHM
+at the grid's low end, Lorentz HWHM)); rule "full" takes dv = wnosamp everywhere.
+Reduction (Transit's `downsample` as recalled): an odd factor averages the dv
+fine points centred on the output point; an even factor takes dv + 1 points with
+the two end points at half weight, over dv; the first / last output point use
+the half of that window that lies on the grid, normalised by its own weights.
+wnosamp = 1: the line sums are evaluated on the output points themselves.
 """
 from __future__ import annotations
 
@@ -68,8 +80,30 @@ def read_tli(path: str):
     return dbs
 
 
+def divisors(n: int):
+    return [d for d in range(1, n + 1) if n % d == 0]
+
+
+def downsample(fine: np.ndarray, dv: int) -> np.ndarray:
+    """fine[(W-1) dv + 1] -> out[W] (see the module docstring)."""
+    if dv == 1:
+        return fine.copy()
+    W = (len(fine) - 1) // dv + 1
+    h = dv // 2
+    w = np.ones(2 * h + 1)
+    if dv % 2 == 0:
+        w[0] = w[-1] = 0.5
+    out = np.zeros(W)
+    for i in range(W):
+        c = i * dv
+        lo, hi = max(c - h, 0), min(c + h, len(fine) - 1)
+        ww = w[lo - (c - h): hi - (c - h) + 1]
+        out[i] = np.dot(ww, fine[lo:hi + 1]) / ww.sum()
+    return out
+
+
 class LblOracle:
-    def __init__(self, tcfg: str):
+    def __init__(self, tcfg: str, osamp_rule: str = "divisor", wn_slice=None):
         k = read_tcfg(tcfg)
         self.keys = k
         atm = read_atm(k["atm"])
@@ -85,15 +119,75 @@ class LblOracle:
         self.ethresh = float(k.get("ethresh", 1e-6))
         lo, hi, d = float(k["wnlow"]), float(k["wnhigh"]), float(k.get("wndelt", 1.0))
         self.wn = lo + d * np.arange(int(np.floor((hi - lo) / d + 1e-9)) + 1)
+        self.wn_ref = self.wn[0]              # Doppler widths for dv: at the FULL grid's low end
+        self.wn_first, self.wn_last = self.wn[0], self.wn[-1]
+        self.wndelt = d
+        self.osamp = max(1, int(float(k.get("wnosamp", 1))))
+        self.osamp_rule = osamp_rule
+        if wn_slice is not None:              # a block of the grid (its edges keep the full grid's)
+            self.wn = self.wn[wn_slice[0]:wn_slice[1]]
+
+    def layer_dv(self, T, p, q):
+        """Oversampling factor of a layer (module docstring)."""
+        if self.osamp == 1:
+            return 1
+        if self.osamp_rule == "full":
+            return self.osamp
+        ih2 = self.species.index("H2") if "H2" in self.species else -1
+        ihe = self.species.index("He") if "He" in self.species else -1
+        wmin = np.inf
+        for db in self.dbs:
+            sp = self.species.index(db["molecule"])
+            for info in db["isotopes"]:
+                mi = info["mass"] * AMU
+                aD = self.wn_ref / LS * np.sqrt(2.0 * np.log(2.0) * KB * T / mi)
+                s = 0.0
+                for c in (ih2, ihe):
+                    if c >= 0:
+                        s += q[c] * (0.5 * (self.diam[sp] + self.diam[c])) ** 2 * \
+                            np.sqrt(1.0 / mi + 1.0 / (self.mass[c] * AMU))
+                aL = np.sqrt(2.0) / (LS * np.sqrt(np.pi * KB * T)) * p * s
+                wmin = min(wmin, max(aD, aL))
+        for dv in divisors(self.osamp):
+            if self.wndelt / dv <= 0.5 * wmin:
+                return dv
+        return self.osamp
 
     def _layer(self, T, p, q, per_gram):
-        """Extinction per database at one state: list of [W] arrays."""
+        """Extinction per database at one state, on the output grid: list of [W]
+        arrays (evaluated dv times finer and reduced, see the module docstring)."""
+        dv = self.layer_dv(T, p, q)
+        if dv == 1:
+            return self._layer_on(self.wn, T, p, q, per_gram)
+        # fine grid over this block plus half an output spacing either side, clipped to the full grid
+        h = dv // 2
+        k0 = int(round((self.wn[0] - self.wn_first) / self.wndelt)) * dv
+        k1 = int(round((self.wn[-1] - self.wn_first) / self.wndelt)) * dv
+        kmax = int(round((self.wn_last - self.wn_first) / self.wndelt)) * dv
+        ka, kb = max(k0 - h, 0), min(k1 + h, kmax)
+        fine_x = self.wn_first + np.arange(ka, kb + 1) * (self.wndelt / dv)
+        w = np.ones(2 * h + 1)
+        if dv % 2 == 0:
+            w[0] = w[-1] = 0.5
+        out = []
+        for fine in self._layer_on(fine_x, T, p, q, per_gram):
+            o = np.zeros(len(self.wn))
+            for i in range(len(self.wn)):
+                c = k0 + i * dv
+                lo, hi = max(c - h, 0), min(c + h, kmax)
+                ww = w[lo - (c - h): hi - (c - h) + 1]
+                o[i] = np.dot(ww, fine[lo - ka: hi - ka + 1]) / ww.sum()
+            out.append(o)
+        return out
+
+    def _layer_on(self, grid, T, p, q, per_gram):
+        """Extinction per database at one state on `grid`: list of arrays."""
         out = []
         ih2 = self.species.index("H2") if "H2" in self.species else -1
         ihe = self.species.index("He") if "He" in self.species else -1
         for db in self.dbs:
             sp = self.species.index(db["molecule"])
-            e = np.zeros(len(self.wn))
+            e = np.zeros(len(grid))
             nu0, iso = db["wn"], db["iso"]
             S = np.zeros(len(nu0)); aD = np.zeros(len(nu0)); aL = np.zeros(len(nu0))
             for i, info in enumerate(db["isotopes"]):
@@ -116,22 +210,26 @@ class LblOracle:
             keep = (S >= self.ethresh * S.max()) & (S > 0)
             cut = self.nwidth * np.maximum(aD, aL)
             sl2 = np.sqrt(np.log(2.0))
-            for j in np.where(keep)[0]:
-                w = np.where(np.abs(self.wn - nu0[j]) <= cut[j])[0]
+            near = keep & (nu0 + cut >= grid[0]) & (nu0 - cut <= grid[-1])
+            for j in np.where(near)[0]:
+                a, b = np.searchsorted(grid, [nu0[j] - cut[j], nu0[j] + cut[j]])
+                w = np.arange(max(a - 1, 0), min(b + 1, len(grid)))
+                w = w[np.abs(grid[w] - nu0[j]) <= cut[j]]
                 if len(w) == 0:
                     continue
-                x = sl2 * np.abs(self.wn[w] - nu0[j]) / aD[j]
+                x = sl2 * np.abs(grid[w] - nu0[j]) / aD[j]
                 y = sl2 * aL[j] / aD[j]
                 e[w] += S[j] * sl2 / np.sqrt(np.pi) / aD[j] * wofz(x + 1j * y).real
             out.append(e)
         return out
 
-    def extinction(self, prof):
-        """prof [(S+1), L] -> ext [L, W] in cm-1 (atm layer order)."""
+    def extinction(self, prof, layers=None):
+        """prof [(S+1), L] -> ext [L, W] in cm-1 (atm layer order); `layers`: only
+        these rows are evaluated (the others stay 0)."""
         prof = np.asarray(prof, float).reshape(len(self.species) + 1, -1)
         L = prof.shape[1]
         ext = np.zeros((L, len(self.wn)))
-        for l in range(L):
+        for l in (range(L) if layers is None else layers):
             ext[l] = sum(self._layer(prof[0, l], self.press[l], prof[1:, l], False))
         return ext
 

@@ -76,6 +76,86 @@ def test_lbl_extinction_and_spectrum_match_oracle(tmp_path):
         trm.free_memory()
 
 
+def test_downsample_rule():
+    """The reduction of the oversampled line sums (oracle statement of DESIGN.md C15):
+    odd factor = mean of the centred points, even factor = end points at half weight,
+    grid ends = the half window that exists; a linear function is reproduced inside."""
+    from oracle import lbl_oracle
+    x = np.arange(0.0, 25.0)                     # W = 7 at dv = 4; W = 9 at dv = 3
+    np.testing.assert_allclose(lbl_oracle.downsample(x, 4)[1:-1], x[4:-4:4], rtol=1e-15)
+    np.testing.assert_allclose(lbl_oracle.downsample(x, 3)[1:-1], x[3:-3:3], rtol=1e-15)
+    assert lbl_oracle.downsample(x, 4)[0] == (0 + 1 + 0.5 * 2) / 2.5
+    assert lbl_oracle.downsample(x, 3)[-1] == (23 + 24) / 2
+    y = np.zeros(25); y[10] = 1.0                # a spike two fine points left of output point 3
+    assert lbl_oracle.downsample(y, 4)[2] == 0.5 / 4 and lbl_oracle.downsample(y, 4)[3] == 0.5 / 4
+    assert lbl_oracle.divisors(12) == [1, 2, 3, 4, 6, 12]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(wnosamp=4),                                            # a small factor: dv in {1, 2, 4}
+    dict(wnosamp=2160),                                         # the reference cfgs' value: dv up to a few dozen
+    dict(wnosamp=2160, wndelt=1.0, nwave=40, nlines=150),       # 1 cm-1 sampling (demo): dv in the hundreds
+    dict(wnosamp=5, rule="full"),                               # odd factor on every layer
+    dict(wnosamp=2160, rule="full", nwave=9, nlines=60, nlayers=4),   # one output point per sub-tile
+])
+def test_wnosamp_oversampling_matches_oracle(tmp_path, kw):
+    """`wnosamp` (code/makecfg.py:38, examples/demo/transit_demo.cfg:27-29; VERDICT r1
+    item 2; convention C15): the line sums are evaluated dv times finer than the output
+    grid -- dv per layer the smallest divisor of wnosamp that puts two points on the
+    narrowest half-width -- and reduced to it; against the scipy-Faddeeva oracle's
+    statement of the same rule, incl. the blocks of a sharded engine."""
+    import os
+    import subprocess
+    import sys
+    from bart_amd import synth_lbl
+    from oracle import lbl_oracle
+    kw = dict(kw)
+    rule = kw.pop("rule", "divisor")
+    kw.setdefault("nlines", 900)
+    kw.setdefault("nwave", 150)
+    kw.setdefault("nlayers", 10)
+    c = synth_lbl.make_lbl_case(str(tmp_path), **kw)
+    prof = c.profiles()
+    np.save(os.path.join(c.dir, "p.npy"), prof)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bart_amd import engine, transit_module as trm\n"
+            "p = np.load(%r); out = []\n"
+            "for sh in (None, (0, 3), (1, 3), (2, 3)):\n"
+            "    engine.init(%r, shard=sh); out.append(engine.lbl_extinction(p)); trm.free_memory()\n"
+            "np.save(%r, out[0]); np.save(%r, np.concatenate(out[1:], axis=1))\n"
+            % (root, os.path.join(c.dir, "p.npy"), c.tcfg, os.path.join(c.dir, "e.npy"), os.path.join(c.dir, "s.npy")))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_OSAMP_RULE=rule), timeout=600)
+    ext = np.load(os.path.join(c.dir, "e.npy"))
+    o = lbl_oracle.LblOracle(c.tcfg, osamp_rule=rule)
+    dvs = [o.layer_dv(prof[0, l], o.press[l], prof[1:, l]) for l in range(prof.shape[1])]
+    assert max(dvs) > 1 and all(o.osamp % d == 0 for d in dvs)
+    ref = o.extinction(prof)
+    assert ref.max() > 0
+    np.testing.assert_allclose(ext, ref, rtol=RTOL, atol=1e-30 + 1e-13 * ref.max())
+    assert np.array_equal(np.load(os.path.join(c.dir, "s.npy")), ext)      # sharded blocks: bit for bit
+    o1 = lbl_oracle.LblOracle(c.tcfg)
+    o1.osamp = 1                                          # the output-point evaluation is something else
+    assert np.abs(o1.extinction(prof) - ref).max() > 1e-3 * ref.max()
+
+
+@pytest.mark.gpu
+def test_wnosamp_in_the_generated_opacity_grid(tmp_path):
+    """The `--justOpacity` step honours wnosamp too: grid mode of the same kernels."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle, rt_oracle as orc
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=300, nwave=90, nlayers=5, with_table=True, wnosamp=12,
+                                tlow=700.0, thigh=1900.0, tempdelt=600.0, ptop=1e-4, pbottom=1.0)
+    engine.init(c.tcfg)
+    try:
+        op = orc.read_opacity(c.keys["opacityfile"])
+        ref = lbl_oracle.LblOracle(c.tcfg).opacity_table(op["temps"])
+        np.testing.assert_allclose(op["kappa"], ref, rtol=RTOL, atol=1e-300 + 1e-13 * ref.max())
+    finally:
+        trm.free_memory()
+
+
 @pytest.mark.gpu
 def test_extinction_chunks_keep_per_walker_overrides(tmp_path, monkeypatch):
     """The eager line-by-line path works through the walkers in chunks bounded by the
@@ -254,6 +334,38 @@ def test_lazy_fused_kernel_matches_eager(tmp_path):
                               timeout=300)
         outs[mode] = np.load(out)
     np.testing.assert_allclose(outs["lazy"], outs["eager"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wnosamp,nslice,layers", [(1, 2000, range(0, 100, 4)), (2160, 400, (3, 40, 71, 99))])
+def test_config5_slice_against_the_oracle(tmp_path, wnosamp, nslice, layers):
+    """BASELINE config 5 at full size (1e6 lines, 1e5 points, 100 layers) where the
+    oracle CAN follow: a block of consecutive samples from the middle of
+    the grid, every line of the 1e6-line list that reaches it (the strength threshold
+    is taken over the whole list, as in the full run), against scipy's Faddeeva
+    function at 1e-7 -- the engine holds that block as one wavenumber shard of the
+    full case.  Also with the reference cfgs' wnosamp 2160."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle
+    mols = ("H2O", "CO", "CO2", "CH4")
+    c = synth_lbl.make_lbl_case(str(tmp_path), molecules=mols, nlines=250000, nwave=100000,
+                                wnlow=1000.0, wndelt=0.1, nlayers=100, cia=False, wnosamp=wnosamp)
+    nshard = 100000 // nslice
+    r = nshard // 2 + 1
+    engine.init(c.tcfg, shard=(r, nshard))
+    try:
+        lo, hi = engine.local_range()
+        assert hi - lo == nslice
+        prof = c.profiles()
+        ext = engine.lbl_extinction(prof)
+    finally:
+        trm.free_memory()
+    o = lbl_oracle.LblOracle(c.tcfg, wn_slice=(lo, hi))
+    assert len(o.wn) == nslice and sum(len(db["wn"]) for db in o.dbs) == 1000000
+    layers = list(layers)
+    ref = o.extinction(prof, layers=layers)
+    assert ref[layers].max() > 0 and (ref[layers] > 0).mean() > 0.5
+    np.testing.assert_allclose(ext[layers], ref[layers], rtol=RTOL, atol=1e-30 + 1e-13 * ref.max())
 
 
 @pytest.mark.gpu

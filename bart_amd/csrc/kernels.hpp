@@ -356,7 +356,7 @@ struct TableLoader {
   // issue the loads of layer k into r (no wait).  The descriptor is rebuilt per
   // layer around the layer's own pair of planes (a 64-bit scalar add), so the
   // 32-bit offsets of the buffer instructions never limit the table size.
-  __device__ __forceinline__ void load(int k, double (&r)[NR]) const {
+  __device__ __forceinline__ void load(int k, double *r) const {   // r[NR]
     const idx_t *ix = sI + k * NI;
     if (M > 0) {
       const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kappa + uniform64(ix[0])), 0, span_k, 0x00020000);

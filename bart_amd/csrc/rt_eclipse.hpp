@@ -73,13 +73,16 @@ __host__ __device__ inline size_t integ_lds_doubles(int L) {
 // 138 VGPRs (two resident waves per SIMD instead of three).  Measured on the bench
 // grid: 10 walkers 75 -> 71 us, 16: 113 -> 107, 64: 326 -> 324, 256: 1062 -> 1082;
 // launch_rt_spec takes the ILP build below kIlpMaxColumns columns.
-template <int AT, int MT, int CT, bool SQ, int INTEG, int SCHED = 0>
+// EXT: the line-by-line path's hand-off -- the layer's line extinction ext[w][l][W]
+// (atm layer order) is one more coalesced 8-byte load per layer and one more addend
+// (line-by-line engines have no table: MT = 0).
+template <int AT, int MT, int CT, bool SQ, int INTEG, int SCHED = 0, bool EXT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_fast(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
-  constexpr int NR = NLD > 0 ? NLD : 1;
+  constexpr int NR = NLD + (EXT ? 1 : 0) > 0 ? NLD + (EXT ? 1 : 0) : 1;
   const int L = p.L, W = p.W;
   int tile, w;
   block_to_work(blockIdx.x, p.nwalkers, tile, w);
@@ -106,7 +109,11 @@ void rt_eclipse_fast(RtArgs p) {
   const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
   const double nu4 = (nu * nu) * (nu * nu);
   const TableLoader<M, C> tab(p, ii, sI);
-  auto load_layer = [&](int k, double (&r)[NR]) { tab.load(k, r); };
+  const double *extw = EXT ? p.ext + (size_t)w * L * W + ii : nullptr;
+  auto load_layer = [&](int k, double (&r)[NR]) {
+    tab.load(k, r);
+    if (EXT) r[NLD] = extw[(size_t)(L - 1 - k) * W];
+  };
 
   TauColumn<INTEG> tc;
   ColumnIntens<INTEG, A> ci;
@@ -135,6 +142,7 @@ void rt_eclipse_fast(RtArgs p) {
     double e = fma(cf[2 + 2 * M + 2 * C], nu4, cf[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
 #pragma unroll
     for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
+    if (EXT) e += r[NLD];
     tc.layer(k, live, lv, e, cf[0], sW);
     // Planck exponent and the A slant-path exponents in one interleaved batch
     const double tcl = fmin(tc.tau, tcap);
@@ -636,6 +644,8 @@ inline bool order_angles_for_square(RtArgs &r) {
 // the single-wave kernel of rule 0 in its ILP-scheduled build (rt_eclipse_i0_ilp.hip);
 // false: no instantiation for this shape
 bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+// ... and with the line-by-line extinction array as input (no table, 0-2 CIA pairs)
+bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
 template <int INTEG>
 bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::string &kmode, bool force_window,
@@ -647,7 +657,21 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   // (the specialised kernels rebuild their buffer descriptor per layer, so the
   // table may be of any size; one layer's pair of planes must stay below 4 GB)
   const bool plane_ok = 2ull * a.M * a.W * 8ull < (1ull << 31);
-  if (!(a.A == 5 && !a.ext && !a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
+  if (a.ext) {
+    // line-by-line hand-off: the single-wave kernel with the extinction array as one
+    // more load per layer (rule 0, no table; anything else takes the generic kernel)
+    if (!(INTEG == kIntegTransmittance && a.A == 5 && a.M == 0 && a.C <= 2 && !a.intens_out && !a.tau_out &&
+          sh <= 55 * 1024 && kmode != "generic"))
+      return false;
+    RtArgs b = a;
+    const bool sq = allow_sq && order_angles_for_square(b);
+    b.ntiles = a.ntiles;
+    if (info) { info->kernel = "rt_eclipse_fast (line-by-line extinction)"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
+    err = hipSuccess;
+    if (launch_rt_fast_ext(b, sq, block, nblocks, sh, st, err)) return true;
+    return false;
+  }
+  if (!(a.A == 5 && !a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
   // (the producer/consumer kernel adds 9 kB of its own)
   RtArgs b = a;
   // the squared-transmittance shortcut is instantiated for the default rule only

@@ -19,4 +19,17 @@ bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t
   return false;
 }
 
+bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+#define BARTRT_FAST_EXT(CC)                                                                                           \
+  if (b.M == 0 && b.C == CC) {                                                                                        \
+    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, 0, CC, true, 0, 1, true>), dim3(nblocks), dim3(block), sh, st, b);  \
+    else hipLaunchKernelGGL((rt_eclipse_fast<5, 0, CC, false, 0, 1, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+    err = hipGetLastError();                                                                                          \
+    return true;                                                                                                      \
+  }
+  BARTRT_FAST_EXT(0) BARTRT_FAST_EXT(1) BARTRT_FAST_EXT(2)
+#undef BARTRT_FAST_EXT
+  return false;
+}
+
 }  // namespace bartrt

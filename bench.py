@@ -267,6 +267,10 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--config", default="table", choices=["table", "lbl"],
+                    help="table: the headline opacity-table workload (BASELINE config 3, the contract's line); "
+                         "lbl: BASELINE config 5, on-the-fly Voigt line-by-line (tools/lbl_bench.py's line)")
+    ap.add_argument("--wnosamp", type=int, default=1, help="--config lbl: oversampling of the line sums")
     ap.add_argument("--same-walkers", action="store_true",
                     help="diagnostic: every walker of a batch carries the batch's first profile (all table "
                          "planes shared: what the launch costs without its own HBM traffic); not a benchmark")
@@ -275,6 +279,13 @@ def main():
     ap.add_argument("--master-port", type=int, default=0,
                     help="rendezvous port of the self-launched N > 1 run (0: pick a free one)")
     a = ap.parse_args()
+
+    if a.config == "lbl":
+        # a second artefact, not the contract's line: config 5 on one GPU
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import lbl_bench
+        lbl_bench.run(["--wnosamp", str(a.wnosamp)])
+        return
 
     if a.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing here has

@@ -1,7 +1,8 @@
 """Instruction mix of an RT kernel's layer loop from the gfx950 assembly (no GPU needed).
-usage: python tools/isa_stats.py [mangled-kernel-substring] > profiles/<tag>_isa_<kernel>.txt
-Compiles csrc/rt_eclipse_i<rule>.hip (the rule is the last template argument of the name) to assembly with the build's flags, takes the largest
-basic block of the kernel (the straight-line block of four layers) and counts
+usage: python tools/isa_stats.py [--ilp] [--json out.json] [mangled-kernel-substring] > profiles/<tag>_isa_<kernel>.txt
+Compiles csrc/rt_eclipse_i<rule>.hip (the rule follows the SQ flag in the name) -- with --ilp
+csrc/rt_eclipse_i0_ilp.hip under the build's max-ILP scheduling option -- to assembly, takes
+the largest basic block of the kernel (the straight-line block of four layers) and counts
 instructions by class."""
 import collections
 import os
@@ -15,14 +16,19 @@ FP64 = ("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_min_f64", "v_max
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "rt_eclipse_fastILi5ELi4ELi1ELb1ELi0E"
-    m = re.search(r"Li(\d)E$", want)
+    ilp = "--ilp" in sys.argv
+    pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--json"]
+    want = pos[0] if pos else ("rt_eclipse_fastILi5ELi4ELi1ELb1ELi0ELi1ELb0E" if ilp
+                               else "rt_eclipse_fastILi5ELi4ELi1ELb1ELi0ELi0ELb0E")
+    m = re.search(r"Lb[01]ELi(\d)E", want)
     integ = m.group(1) if m else "0"
+    src = "rt_eclipse_i0_ilp.hip" if ilp else "rt_eclipse_i%s.hip" % integ
+    extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ilp else []
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", *extra,
                                "--cuda-device-only", "-S", "-x", "hip",
-                               os.path.join(ROOT, "bart_amd", "csrc", "rt_eclipse_i%s.hip" % integ), "-o", out],
+                               os.path.join(ROOT, "bart_amd", "csrc", src), "-o", out],
                               stderr=subprocess.DEVNULL)
         s = open(out).read()
     name = re.search(r"^(_ZN6bartrt\w*%s\w*):" % re.escape(want), s, re.M).group(1)

@@ -25,6 +25,9 @@ cp "$out/stats_transit.log" "profiles/${tag}_transit_bench.jsonl"; cp "$out/stat
 python3 tools/collect_profiles.py "${tag}_w10" "$out/stats_w10" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_calib"
 python3 tools/collect_profiles.py "${tag}_w1" "$out/stats_w1"
 python3 tools/collect_profiles.py "${tag}_w256" "$out/stats_w256"
+# instruction mix of the build (the bench line's fp64 figure is computed from it)
+python3 tools/isa_stats.py > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq.txt"
+python3 tools/isa_stats.py --ilp --json profiles/isa_latest.json > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq_ilp.txt"
 # the bench line last, so that its `traffic` is this round's PMC figure
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cp "$out/bench.json" "profiles/${tag}_bench.json"

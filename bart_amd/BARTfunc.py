@@ -96,7 +96,7 @@ class WorkerConfig:
 class Worker:
     """Initialisation of BARTfunc.py:134-299 plus a batched ``step``."""
 
-    def __init__(self, cfg: WorkerConfig, shard=None, device=None, group=None):
+    def __init__(self, cfg: WorkerConfig, shard=None, device=None, group=None, carry=None):
         self.cfg = cfg
         self.group = group      # process group of the wavenumber shards (None: the default group)
         if cfg.PTtype not in PT_NPARS:
@@ -162,6 +162,15 @@ class Worker:
             engine.step_set_extras(self.nradfit, self.ncloud, self.nray)
             if self.nray:
                 trm.set_scattering(2 if "polar" in cfg.scattering else 1, 0.0)
+        # BARTfunc.py:318-324: when the T(p) model raises ValueError the reference keeps the
+        # previous step's profile in place.  Reproduced on request (walker w of every
+        # batch is then chain w: the one-chain-per-process and the grouped main() below
+        # keep that order); by default such a walker is rejected.
+        if carry is None:
+            carry = os.environ.get("BARTRT_CARRY_PROFILE", "0") == "1"
+        self.carry = bool(carry)
+        if self.carry:
+            engine.step_set_carry(True)
         if cfg.ebalance:
             # BARTfunc.py:375-377
             e_in = (hostio.sig * self.tstar ** 4 * self.rstar ** 2 * np.pi * self.rplanet ** 2

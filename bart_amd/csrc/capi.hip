@@ -415,6 +415,14 @@ int bartrt_step_set_extras(int nrad, int ncloud, int nray) {
   });
 }
 
+int bartrt_step_set_carry(int on) {
+  NEED_ENGINE();
+  return guarded([&] {
+    step_set_carry(*g_eng, on);
+    return BARTRT_OK;
+  });
+}
+
 int bartrt_step_batch(const double *params, int nwalkers, int npars,
                       double *bandflux, int *status) {
   NEED_ENGINE();

@@ -36,6 +36,12 @@ struct StepArgs {
   int cap = 0;
   double *d_prof = nullptr, *d_spec = nullptr;
   double *d_over = nullptr;             // [cap][3] per-walker overrides for prep (unfused path)
+  // carry-over of the reference's worker (BARTfunc.py:318-324): a T(p) model that raises
+  // ValueError leaves the chain's previous temperature profile in place.  Off: such a
+  // walker is rejected.  On: walker w of a call is chain w; its last generated profile
+  // is kept here ([cap][L], zeros before the first one, like the reference's array)
+  int carry = 0;
+  double *d_prevT = nullptr;
   int *d_status = nullptr;
   ~StepArgs();
 };
@@ -46,6 +52,7 @@ void step_setup(Engine &e, const double *ptargs5, int tint_thorngren, int pttype
                 const double *nifilter, const double *istarfl, double rprs, int solution);
 void step_set_ebalance(Engine &e, int on, double e_in, double e_fac);
 void step_set_extras(Engine &e, int nrad, int ncloud, int nray);
+void step_set_carry(Engine &e, int on);
 void step_ensure(Engine &e, int n);
 // params[n][npars] -> prof[n][(S+1)][L], status[n]
 void step_profiles_dev(Engine &e, const double *d_params, int n, int npars, double *d_prof,

@@ -252,6 +252,12 @@ def step_set_extras(nrad: int, ncloud: int, nray: int) -> None:
     _check(trm.lib().bartrt_step_set_extras(int(nrad), int(ncloud), int(nray)))
 
 
+def step_set_carry(on: bool) -> None:
+    """The reference's carry-over of the previous temperature profile when the T(p)
+    model raises ValueError (BARTfunc.py:318-324); walker w of every batch = chain w."""
+    _check(trm.lib().bartrt_step_set_carry(int(bool(on))))
+
+
 def step_set_ebalance(on, e_in, e_fac):
     _check(trm.lib().bartrt_step_set_ebalance(int(bool(on)), float(e_in), float(e_fac)))
 

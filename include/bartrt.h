@@ -123,6 +123,15 @@ int bartrt_step_set_ebalance(int on, double e_in, double e_fac);
  * per walker inside the batch instead of through the engine-wide setters. */
 int bartrt_step_set_extras(int nrad, int ncloud, int nray);
 
+/* The reference's worker keeps going when its T(p) model raises ValueError: the
+ * profile array still holds the previous step's temperatures and is range-checked
+ * and used as it is (BARTfunc.py:318-330, marked FINDME there).  on = 1 reproduces
+ * that: walker w of every call is chain w, and a parameter set the model rejects
+ * is evaluated with chain w's last generated profile (zeros before the first one,
+ * i.e. rejected by the temperature bounds).  on = 0 (default): such a walker is
+ * rejected with status 1. */
+int bartrt_step_set_carry(int on);
+
 /* params[nwalkers][npars] (npars = nPT + extras + nmolfit; nPT = 5 for "line", 1 for
  * "iso") -> bandflux[nwalkers][nfilters]; rejected walkers get -1 in every
  * band (BARTfunc.py:327-330,339-344,378-383).  status[w]: 0 ok, 1 bad

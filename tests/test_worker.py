@@ -229,3 +229,77 @@ def test_worker_group_batches_the_chains(tmp_path):
         for got, want in zip(comms[r].received, lone[r]):
             assert np.array_equal(got, want)
     assert np.all(comms[2].received[1] == -1.0)
+
+
+@pytest.mark.gpu
+def test_valueerror_carries_the_previous_profile_on_request(tmp_path, monkeypatch):
+    """BARTfunc.py:318-330: when the T(p) model raises ValueError the reference worker
+    logs it and goes on with the profile array as the previous step left it -- range
+    check included.  With BARTRT_CARRY_PROFILE=1 the one-chain
+    worker reproduces that; the sequence of -1 / band-flux answers equals a numpy
+    restatement of the reference loop, including a rejected (too hot) profile that is
+    carried into the next failing step.  Without the switch such steps are rejected."""
+    from bart_amd import BARTfunc, hostio, synthcfg
+    from oracle import pyhalf, rt_oracle as orc
+    good_a = [0.5, 0.5, 1e-3, 1.0, 1500.0, -0.5]
+    good_b = [0.6, 0.4, 3e-3, 2.0, 1700.0, 0.2]
+    verr_1 = [0.05, 0.5, 1e-3, 1.0, 1500.0, 0.6]       # T0 < 0: PT_NoInversion raises
+    verr_2 = [0.5, 0.02, 1e-3, 1.0, 1500.0, -1.0]      # T1 < 0
+    hot = [0.6, 0.4, 3e-3, 2.0, 3400.0, 0.0]           # a valid model above Tmax
+    seq = [verr_1, good_a, verr_1, good_b, verr_2, hot, verr_1, good_a]
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), nwave=900, params=tuple(good_a))
+    txt = open(cfg).read().replace("PTtype = line", "PTtype = madhu_noinv")
+    open(cfg, "w").write(txt)
+    wc = BARTfunc.WorkerConfig.from_cfg(cfg)
+    # ---- numpy restatement of the reference loop (BARTfunc.py:309-399)
+    tep = hostio.TepFile(wc.tep_name)
+    rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+    rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+    species, press, _, abund = hostio.readatm(wc.atmfile)
+    o = orc.OracleEngine(wc.tconfig)
+    starfl, starwn, _, _ = hostio.readkurucz(wc.kurucz, float(tep.getvalue("Ts")[0]),
+                                             float(tep.getvalue("loggstar")[0]))
+    idx0, npts, nif, ist = [], [], [], []
+    for f in wc.filters:
+        a, b, ind = hostio.resample(o.wn, *hostio.readfilter(f), starwn, starfl)
+        idx0.append(ind[0][0]); npts.append(len(ind[0])); nif.append(a); ist.append(b)
+    sp = list(species)
+    ih2, ihe, ich4 = sp.index("H2"), sp.index("He"), sp.index("CH4")
+    ratio = abund[:, ih2] / abund[:, ihe]
+    imetals = [i for i, s in enumerate(sp) if s not in ("He", "H2", "H-", "e-")]
+    L = len(press)
+    tprofile = np.zeros(L)
+    want = []
+    for par in seq:
+        try:
+            tprofile[:] = pyhalf.pt_noinversion(np.asarray(press)[::-1], *par[:5])[::-1]
+        except ValueError:
+            pass                                        # "FINDME: what to do here?"
+        if np.any(tprofile < wc.Tmin) or np.any(tprofile > wc.Tmax):
+            want.append(-np.ones(10)); continue
+        prof = np.zeros((len(sp) + 1, L))
+        prof[0], prof[1:] = tprofile, abund.T
+        prof[1 + ich4] = abund[:, ich4] * 10.0 ** par[5]
+        q = 1.0 - prof[1:][imetals].sum(axis=0)
+        if np.any(q < 0):
+            want.append(-np.ones(10)); continue
+        prof[1 + ih2], prof[1 + ihe] = ratio * q / (1 + ratio), q / (1 + ratio)
+        want.append(pyhalf.bandflux(o.run(prof), o.wn, idx0, npts, np.concatenate(nif), np.concatenate(ist),
+                                    rp / rstar))
+    rejected = [bool(np.all(w == -1)) for w in want]
+    assert rejected == [True, False, False, False, False, True, True, False]
+    assert not np.allclose(want[1], want[2])            # a carried profile with the new abundances
+    # ---- the worker, with the switch
+    monkeypatch.setenv("BARTRT_CARRY_PROFILE", "1")
+    comm = FakeIntercomm(seq)
+    BARTfunc.main(comm, ["-c", cfg])
+    assert len(comm.received) == len(seq)
+    for got, ref, rej in zip(comm.received, want, rejected):
+        assert bool(np.all(got == -1)) == rej
+        if not rej:
+            np.testing.assert_allclose(got, ref, rtol=1e-9)
+    # ---- and without it: every ValueError step is a rejection
+    monkeypatch.setenv("BARTRT_CARRY_PROFILE", "0")
+    comm = FakeIntercomm(seq)
+    BARTfunc.main(comm, ["-c", cfg])
+    assert [bool(np.all(g == -1)) for g in comm.received] == [True, False, True, False, True, True, True, False]

@@ -139,8 +139,14 @@ sets = {
 }
 for name, (specwn, files) in sets.items():
     idx0, npts, nif, ist = [], [], [], []
-    for f in files:
+    for k, f in enumerate(files):
         fwn, ftr = w.readfilter(f)
+        # the filter curve itself: the file's two numeric columns (input data) and what
+        # the reference's readfilter makes of them, so that hostio.readfilter / resample
+        # are held to the reference on boxes without /root/reference too
+        wout["%s_filter%02d_columns" % (name, k)] = np.loadtxt(f, comments="#")
+        wout["%s_filter%02d_wn" % (name, k)] = fwn
+        wout["%s_filter%02d_tr" % (name, k)] = ftr
         a, b, ind = w.resample(specwn, fwn, ftr, starwn, starfl)
         ind = ind[0]
         assert np.all(np.diff(ind) == 1)

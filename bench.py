@@ -176,7 +176,7 @@ def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
                 usedc[k[act[w]], jj[w][act[w]] + 1] = True
             # (the same CIA plane serves every layer that brackets it: count planes, not (layer, plane))
             uniq += usedc.any(axis=0).sum() * width[c] * 8.0
-    NC, NI = 3 + 2 * M + 2 * len(cia_t), 1 + len(cia_t)
+    NC, NI = 4 + 2 * M + 2 * len(cia_t), 1 + len(cia_t)      # words of a layer record (csrc/kernels.hpp)
     fixed = nw * L * (NC + NI) * 8.0 + nw * nwave * 8.0 + nwave * 8.0   # records, spectra out, wavenumbers
     return {"effective_bytes": eff + fixed, "unique_bytes": uniq + fixed,
             "layers_walked_frac": walked_lw / (nw * L * float(nwave)),

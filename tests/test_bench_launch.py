@@ -46,3 +46,31 @@ def test_single_rank_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip())
     assert j["n_gpus"] == 1 and j["dry"] is True
+
+
+def test_launch_byte_model_counts_shared_rows_once(tmp_path):
+    """bench.py's per-launch byte model: identical walkers share every
+    row (unique bytes of one walker + the per-walker records and spectra), walkers in
+    disjoint temperature brackets share none, and a launch that stops half way down
+    moves half the table bytes; the effective bytes follow SURVEY 8d's per-spectrum
+    figure restricted to the walked layers."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from bart_amd import synth
+    L, W, nw = 40, 640, 4
+    case = synth.make_case(str(tmp_path), nlayers=L, nwave=W)          # 4 molecules, H2-H2 CIA, 27 planes
+    prof = case.profiles(temp=np.full(L, 1010.0)).ravel()
+    same = np.tile(prof, (nw, 1))
+    walked = np.full((nw, W // 64), L, np.int32)
+    m = bench.launch_byte_model(case, same, walked, 64, W)
+    table = 2 * L * 4 * W * 8                     # two planes, four molecules
+    cia = 2 * W * 8                               # one pair of CIA planes, shared by every layer
+    fixed = nw * L * (4 + 2 * 4 + 2 + 2) * 8 + nw * W * 8 + W * 8
+    assert m["unique_bytes"] == table + cia + fixed and m["layers_walked_frac"] == 1.0
+    assert m["effective_bytes"] == nw * (2 * L * W * 4 * 8 + 2 * L * W * 8) + fixed
+    apart = np.array([case.profiles(temp=np.full(L, t)).ravel() for t in (450.0, 1010.0, 1650.0, 2950.0)])
+    m2 = bench.launch_byte_model(case, apart, walked, 64, W)
+    assert m2["unique_bytes"] - fixed == nw * table + 4 * cia          # nothing shared (CIA grid: 200 K steps)
+    half = bench.launch_byte_model(case, same, walked // 2, 64, W)
+    assert half["unique_bytes"] - fixed == table // 2 + cia and half["layers_walked_frac"] == 0.5

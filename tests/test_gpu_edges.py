@@ -83,3 +83,48 @@ def test_step_with_every_walker_rejected_and_nonfinite_parameters(tmp_path):
         assert np.allclose(w.step(base)[0], good, rtol=0, atol=0)
     finally:
         w.close()
+
+
+@pytest.mark.parametrize("mode", ["generic", "mono_occ", "mono_ilp", "split", "quad", "octo"])
+def test_walked_layer_record(tmp_path, mode):
+    """bartrt_walked_begin / _end (the bench's byte model): every eclipse kernel reports,
+    per column of its own tiling, how many layers the wave walked -- all of them when
+    `toomuch` never cuts, the cloud deck's depth when there is one, and at least the
+    deepest `last` layer of the column's samples (the wave leaves once EVERY lane has
+    passed toomuch) when it does."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys, json; sys.path.insert(0, %r)\n"
+            "from bart_amd import engine, synth, transit_module as trm\n"
+            "from test_gpu_parity import walkers\n"
+            "out = {}\n"
+            "for name, tm in (('open', 1e30), ('cut', 10.0)):\n"
+            "    c = synth.make_case(%r + name, nlayers=60, nwave=300, toomuch=tm)\n"
+            "    engine.init(c.tcfg); p = walkers(c, 3, seed=12)\n"
+            "    engine.walked_begin(); engine.run_batch(p); w, wpc, kname = engine.walked_end()\n"
+            "    trm.run_transit(p[1], 300); tau, last = engine.get_tau()\n"
+            "    out[name] = dict(w=w.tolist(), wpc=wpc, kernel=kname, last=last.tolist())\n"
+            "    if name == 'open':\n"
+            "        trm.set_cloudtop(float(0.5 * (np.log10(c.press_bar[25]) + np.log10(c.press_bar[26]))))\n"
+            "        engine.walked_begin(); engine.run_batch(p); w2, _, _ = engine.walked_end(); out['deck'] = w2.tolist()\n"
+            "    trm.free_memory()\n"
+            "print('RESULT' + json.dumps(out))\n" % (root, str(tmp_path) + "/"))
+    env = dict(os.environ, BARTRT_KERNEL=mode, PYTHONPATH=os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    wpc = out["open"]["wpc"]
+    ncol = (300 + wpc - 1) // wpc
+    w = np.array(out["open"]["w"])
+    # (the quad-layer kernels' record is padded to whole workgroups: columns past the grid stay 0)
+    assert w.shape[0] == 3 and w.shape[1] >= ncol and np.all(w[:, :ncol] == 60) and np.all(w[:, ncol:] == 0), \
+        (out["open"]["kernel"], w)
+    # deck between the layers 25 and 26 from the bottom: the column ends on k = 34, 35 layers
+    assert np.all(np.array(out["deck"])[:, :ncol] == 60 - 25)
+    w = np.array(out["cut"]["w"])
+    last = np.array(out["cut"]["last"])                           # of walker 1
+    for col in range(ncol):
+        deepest = last[col * wpc:(col + 1) * wpc].max()
+        assert deepest + 1 <= w[1, col] <= min(60, deepest + 1 + 8), (col, deepest, w[1, col])
+    assert (w < 60).any()

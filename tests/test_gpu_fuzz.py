@@ -38,17 +38,23 @@ def _draw(rng, wide=False):
     return kw, geometry, nwalk, cloud
 
 
-@pytest.mark.parametrize("seed", range(72))
-def test_random_configuration(tmp_path, seed):
+def _run(tmp_path, seed, integ=0, ramp=False):
     from bart_amd import engine, synth, transit_module as trm
     from oracle import rt_oracle as orc
     from test_gpu_parity import walkers
     rng = np.random.default_rng(1000 + seed)
     kw, geometry, nwalk, cloud = _draw(rng, wide=seed >= 48)   # seeds 0-47 keep their draws
+    if ramp:   # a radius-ramp cloud somewhere in the column (and, in transit geometry, no opaque core)
+        r = np.sort(synth.make_case(str(tmp_path), write=False, **kw).radius_km)
+        lo, hi = sorted(rng.choice(len(r), 2, replace=False))
+        kw.setdefault("extra_keys", {}).update(cloudrad="%.2f %.2f" % (r[hi], r[lo]), cloudext=10 ** rng.uniform(-10, -7))
+        if geometry == "transit" and rng.random() < 0.5:
+            kw["extra_keys"]["transparent"] = 1
     c = synth.make_case(str(tmp_path), **kw)
     engine.init(c.tcfg)
     try:
-        o = orc.OracleEngine(c.tcfg)
+        trm.set_integ(integ)
+        o = orc.OracleEngine(c.tcfg, integ=integ)
         if cloud is not None:
             trm.set_cloudtop(cloud); o.set_cloudtop(cloud)
         profs = walkers(c, nwalk, seed=seed)
@@ -56,6 +62,18 @@ def test_random_configuration(tmp_path, seed):
         assert ok.all()
         ref = o.run_batch(profs)
         np.testing.assert_allclose(spec, ref, rtol=RTOL, atol=1e-300,
-                                   err_msg="%s %s walkers=%d cloud=%s" % (geometry, kw, nwalk, cloud))
+                                   err_msg="%s %s walkers=%d cloud=%s integ=%d" % (geometry, kw, nwalk, cloud, integ))
     finally:
         trm.free_memory()
+
+
+@pytest.mark.parametrize("seed", range(72))
+def test_random_configuration(tmp_path, seed):
+    _run(tmp_path, seed)
+
+
+@pytest.mark.parametrize("seed", range(100, 136))
+def test_random_configuration_rules_and_clouds(tmp_path, seed):
+    """The same draws under integration rules 1 and 2 (seed mod 3 picks the rule, 0 too)
+    and with a radius-ramp cloud / transparent core added to every second one."""
+    _run(tmp_path, seed, integ=seed % 3, ramp=seed % 2 == 1)

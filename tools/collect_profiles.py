@@ -63,7 +63,7 @@ if __name__ == "__main__":
             "fetch_calibration": {
                 "known_bytes": expected, "FETCH_SIZE_KB_reported": cal_kb, "factor": factor,
                 "method": "tools/pmc_calib.py: 1 walker, toomuch=1e30, every table byte read "
-                          "once with the kernel's own 8 B/lane coalesced loads"},
+                          "once with the kernel's own loads (16 B per lane and plane pair)"},
             "traffic_bytes_per_launch": f_kb * 1024.0 * factor + w_kb * 1024.0,
             "avg_launch_us_in_pmc_pass": f_us,
         }

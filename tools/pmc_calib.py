@@ -1,5 +1,5 @@
 """FETCH_SIZE calibration on a known byte count in the RT kernel's own access
-pattern (8 B/lane coalesced, every byte read once): ONE walker, toomuch = 1e30
+pattern (the table layout's 16-byte loads per lane, every byte read once): ONE walker, toomuch = 1e30
 (no early exit) reads exactly 2*L*M*W*8 + 2*L*W*8 bytes of table per launch.
 Run under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (MI355X_MICROARCH.md, HBM)."""
 import os

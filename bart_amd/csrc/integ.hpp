@@ -151,6 +151,55 @@ struct ColumnIntens<kIntegTrapzTau, AMAX> {
   }
 };
 
+// Flux-only accumulator of the kernels that do not return per-angle intensities
+// (single-wave, producer/consumer, quad-layer).  Rule 0 is linear in the
+// transmittances, so the angle quadrature can be taken BEFORE the layer sum:
+//   F = sum_a w_a sum_k hb_k (E_{a,k-1} - E_{a,k}) = sum_k hb_k (G_{k-1} - G_k),
+//   G_k = sum_a w_a E_{a,k}
+// -- one running sum and one previous value instead of A of each (16 VGPRs and a
+// few operations less per layer; in the quad-layer kernel one value crosses the lane
+// rows instead of A).  The other rules delegate to ColumnIntens.
+template <int INTEG, int AMAX>
+struct ColumnFlux {
+  ColumnIntens<INTEG, AMAX> ci;
+  __device__ __forceinline__ explicit ColumnFlux(const RtArgs &) {}
+  __device__ __forceinline__ void layer(const RtArgs &, int A, bool live, double lv, double tau, double Bprev,
+                                        double B, const double (&E)[AMAX]) {
+    ci.layer(A, live, lv, tau, Bprev, B, E);
+  }
+  __device__ __forceinline__ double flux(const RtArgs &p, int A, bool deck, double Bprev, int L) {
+    return ci.flux(p, A, deck, Bprev, L, nullptr);
+  }
+};
+
+// G = sum_a w_a E_a
+template <int AMAX>
+__device__ __forceinline__ double angle_sum(const RtArgs &p, const double (&E)[AMAX]) {
+  double g = p.wgt[0] * E[0];
+#pragma unroll
+  for (int a = 1; a < AMAX; a++) g = fma(p.wgt[a], E[a], g);
+  return g;
+}
+
+template <int AMAX>
+struct ColumnFlux<kIntegTransmittance, AMAX> {
+  double F = 0.0, Gprev;
+  __device__ __forceinline__ explicit ColumnFlux(const RtArgs &p) {
+    Gprev = p.wgt[0];                       // transmittances are 1 above the top layer
+#pragma unroll
+    for (int a = 1; a < AMAX; a++) Gprev += p.wgt[a];
+  }
+  __device__ __forceinline__ void layer(const RtArgs &p, int, bool, double lv, double, double Bprev, double B,
+                                        const double (&E)[AMAX]) {
+    const double G = angle_sum<AMAX>(p, E);
+    F = fma((Bprev + B) * lv, Gprev - G, F);
+    Gprev = G;
+  }
+  __device__ __forceinline__ double flux(const RtArgs &, int, bool deck, double Bprev, int) {
+    return deck ? fma(Bprev, Gprev, F) : F;
+  }
+};
+
 // Simpson weights of the panel over (x - h0 - h1, x - h1, x); zero-width halves
 // fall back to the two trapezoids.
 __device__ __forceinline__ void simpson_tau_weights(double h0, double h1, double &w0, double &w1, double &w2) {

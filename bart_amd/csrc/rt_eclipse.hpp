@@ -116,7 +116,7 @@ void rt_eclipse_fast(RtArgs p) {
   };
 
   TauColumn<INTEG> tc;
-  ColumnIntens<INTEG, A> ci;
+  ColumnFlux<INTEG, A> ci(p);
   double Bprev = 0.0;
   bool active = true;
   const int kend = p.kstop[w];
@@ -156,7 +156,7 @@ void rt_eclipse_fast(RtArgs p) {
     for (int a = 0; a < AE; a++) es[a] = ex[a];
     if (SQ) es[A - 1] = ex[0] * ex[0];
     const double B = bnum * rcp_core(ex[AE] - 1.0);
-    ci.layer(A, live, lv, tc.tau, Bprev, B, es);
+    ci.layer(p, A, live, lv, tc.tau, Bprev, B, es);
     Bprev = B;
     active = active && !(live && tc.tau > p.toomuch);
   };
@@ -181,7 +181,7 @@ void rt_eclipse_fast(RtArgs p) {
     layer(k0 + 3, b1, cfO, cfE);
     if (!__any(active)) break;
   }
-  const double F = ci.flux(p, A, p.cloud_on && active, Bprev, L, nullptr);
+  const double F = ci.flux(p, A, p.cloud_on && active, Bprev, L);
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
     p.walked_out[(size_t)w * p.ntiles + tile] = (k0 + 4 < kend + 1 ? k0 + 4 : kend + 1);
@@ -302,7 +302,7 @@ void rt_eclipse_split(RtArgs p) {
       p.walked_out[(size_t)w * p.ntiles + tile] = (4 * blk + 4 < kend + 1 ? 4 * blk + 4 : kend + 1);
   } else {
     // ---------------- consumer: transmittances and intensities ----------------
-    ColumnIntens<INTEG, A> ci;
+    ColumnFlux<INTEG, A> ci(p);
     const double tcap = tau_cap(p, A);
     for (int blk = 0; blk < nblk; blk++) {
       asm volatile("" ::: "memory");
@@ -326,14 +326,12 @@ void rt_eclipse_split(RtArgs p) {
           if (SQ) es[A - 1] = ex[0] * ex[0];
         }
         if constexpr (INTEG == kIntegTransmittance) {
-#pragma unroll
-          for (int a = 0; a < A; a++) {
-            ci.I[a] = fma(hb, ci.fprev[a] - es[a], ci.I[a]);
-            ci.fprev[a] = es[a];
-          }
+          const double G = angle_sum<A>(p, es);     // the producer's hb already carries the 1/2 and the mask
+          ci.F = fma(hb, ci.Gprev - G, ci.F);
+          ci.Gprev = G;
         } else {
           const bool live = hb >= 0.0;   // the producer's "layer counts" flag
-          ci.layer(A, live, live ? 0.5 : 0.0, tau, 0.0, live ? hb : 0.0, es);
+          ci.layer(p, A, live, live ? 0.5 : 0.0, tau, 0.0, live ? hb : 0.0, es);
         }
       }
       if (__builtin_amdgcn_readfirstlane(stop)) break;
@@ -342,7 +340,7 @@ void rt_eclipse_split(RtArgs p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const double bsurf = sEnd[lane];   // > 0: the deck was reached below toomuch
-    const double F = ci.flux(p, A, bsurf != 0.0, bsurf, L, nullptr);
+    const double F = ci.flux(p, A, bsurf != 0.0, bsurf, L);
     if (valid) p.spec[(size_t)w * W + i] = F;
   }
 }
@@ -440,9 +438,10 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   double Fs = 0.0;  // surface term of a cloud deck (one lane per wavenumber sets it)
   // carries of row 0: extinction, Planck term, transmittances of the layer just
   // above this step (row R - 1 of the previous step), and the optical depth there
-  double c_e = 0.0, c_B = 0.0, c_E[AE], c_tau = 0.0;
+  double c_e = 0.0, c_B = 0.0, c_tau = 0.0;
+  double c_G = p.wgt[0];   // rule 0: sum_a w_a E_a of the layer above (all transmittances 1 at the top)
 #pragma unroll
-  for (int a = 0; a < AE; a++) c_E[a] = 1.0;
+  for (int a = 1; a < A; a++) c_G += p.wgt[a];
   // rule 1: second carries (row R - 2 / R - 1 of the previous step for rows 0 / 1),
   // the running even-index Simpson sum of the optical depth, the index of the last
   // point of the intensity integral and the "next step's row 0 is the padded point" flag
@@ -514,24 +513,18 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       const double Bprev = q == 0 ? c_B : B_below;
       c_B = B_below;
       const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
-      double Eprev[A], E[A];
+      // rule 0 is linear in the transmittances: the angle quadrature first (ColumnFlux,
+      // integ.hpp), so ONE value crosses the lane rows instead of one per ray angle
+      double E[A];
 #pragma unroll
-      for (int a = 0; a < AE; a++) {
-        const double E_below = __shfl(ex[a], from_below);
-        Eprev[a] = q == 0 ? c_E[a] : E_below;
-        c_E[a] = E_below;
-        E[a] = ex[a];
-      }
-      if (SQ) {
-        Eprev[A - 1] = Eprev[0] * Eprev[0];
-        E[A - 1] = E[0] * E[0];
-      }
-#pragma unroll
-      for (int a = 0; a < A; a++) I[a] = fma(hb, Eprev[a] - E[a], I[a]);
-      if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) {  // deck reached below toomuch
-#pragma unroll
-        for (int a = 0; a < A; a++) Fs = fma(p.wgt[a] * B, E[a], Fs);
-      }
+      for (int a = 0; a < AE; a++) E[a] = ex[a];
+      if (SQ) E[A - 1] = E[0] * E[0];
+      const double G = angle_sum<A>(p, E);
+      const double G_below = __shfl(G, from_below);
+      const double Gprev = q == 0 ? c_G : G_below;
+      c_G = G_below;
+      I[0] = fma(hb, Gprev - G, I[0]);
+      if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) Fs = fma(B, G, Fs);  // deck reached below toomuch
     } else {
       // integrand of this lane's layer and of the one / two layers above it
       const double tau_b1 = __shfl(tau, from_below);
@@ -605,10 +598,11 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   // the rows of a wavenumber hold its layers' terms: sum them; row 0 writes
   const bool mine_counts = !SIMPSON || ((q & 1) == (nend & 1));
   double F = Fs;
+  if constexpr (INTEG == kIntegTransmittance) {
+    F += I[0];   // the lane's layers, angle quadrature already taken
+  } else {
 #pragma unroll
-  for (int a = 0; a < A; a++) {
-    const double scale = INTEG == kIntegTransmittance ? p.wgt[a] : p.wgt[a] * p.invmu[a];
-    F = fma(scale, mine_counts ? I[a] : 0.0, F);
+    for (int a = 0; a < A; a++) F = fma(p.wgt[a] * p.invmu[a], mine_counts ? I[a] : 0.0, F);
   }
   for (int o = WN; o < 64; o <<= 1) F += __shfl_xor(F, o);
   if (q == 0 && i0 + m < W) p.spec[(size_t)w * W + i0 + m] = F;

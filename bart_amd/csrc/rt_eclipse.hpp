@@ -29,13 +29,18 @@
 namespace bartrt {
 
 // Kernel choice by 64-wavenumber columns per launch (measured at W = 1e4, L = 100:
-// 157 columns per walker; microseconds per launch, quad-layer / split / single-wave):
-//   1 walker 26 / 39 / 54     2 walkers 33 / 38 / 48     4 walkers 45 / 47 / 50
-//   5 walkers 54 / 52 / 52    6 walkers 58 / 53 / 55     8 walkers 73 / 68 / 75
-//   9 walkers 81 / 80 / 80    10 walkers 90 / 85 / 84  (single-wave from here on)
+// 157 columns per walker; microseconds per launch, quad-layer / split / single-wave,
+// round 2, tools/ab_kernels.py):
+//   1 walker 19 (8 rows) / 33 / 37   2 walkers 26 (8 rows) / 43 / 38   3: 31 / 43 / 39
+//   4 walkers 39 / 45 / 41           5 walkers 48 / 47 / 44            6: 49 / 49 / 47
+//   7 walkers 59 / 57 / 62           8 walkers 62 / 61 / 63            9: 68 / 70 / 67
+//   10 walkers 76 / 76 / 71  (single-wave from here on)
+// i.e. quad-layer while the columns leave SIMDs empty, single-wave while every column
+// finds a SIMD of its own (<= 1 024), the producer/consumer pair for the first columns
+// that have to share one, single-wave beyond.
 constexpr long kQuadMaxColumns = 640;
-constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this: 1 walker 23 us, 2 walkers 30 us
-constexpr long kSplitMaxColumns = 1300;
+constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this
+constexpr long kSplitMinColumns = 1025, kSplitMaxColumns = 1300;
 constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
 
 // ---------------------------------------------------------------------------
@@ -703,7 +708,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     BARTRT_MC_LIST(BARTRT_QUAD)
 #undef BARTRT_QUAD
   }
-  if (kmode == "split" || (kmode.empty() && columns <= kSplitMaxColumns)) {
+  if (kmode == "split" || (kmode.empty() && columns >= kSplitMinColumns && columns <= kSplitMaxColumns)) {
     b.ntiles = ntiles64;
     const size_t shs = sh + sizeof(double) * (1024 + 2 + 64);
     if (info) { info->kernel = "rt_eclipse_split"; info->wn_per_column = 64; info->ncolumns = b.ntiles; }

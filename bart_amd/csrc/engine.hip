@@ -512,7 +512,11 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   }
   // one wave per workgroup at every batch size (measured against 128 and 256 lanes:
   // 2-5 % faster from 64 walkers up, finer turnover of the SIMDs' wave slots)
-  const int block = 64;
+  static const int block = [] {
+    const char *e = std::getenv("BARTRT_BLOCK");   // A/B runs: 64 (default), 128 or 256 lanes per workgroup
+    const int b = e ? std::atoi(e) : 64;
+    return (b == 128 || b == 256) ? b : 64;
+  }();
   r.ntiles = (r.W + block - 1) / block;
   r.rtop = d_rtop; r.ds = d_ds;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;

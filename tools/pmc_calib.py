@@ -1,6 +1,8 @@
 """FETCH_SIZE calibration on a known byte count in the RT kernel's own access
 pattern (the table layout's 16-byte loads per lane, every byte read once): ONE walker, toomuch = 1e30
-(no early exit) reads exactly 2*L*M*W*8 + 2*L*W*8 bytes of table per launch.
+(no early exit) brings 2*L*M*W*8 bytes of the opacity grid in from HBM (every layer's two planes,
+each once) + the few distinct CIA pair planes its temperatures bracket (the other layers re-read
+them from L2) + its records, and writes one spectrum.
 Run under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (MI355X_MICROARCH.md, HBM)."""
 import os
 import sys
@@ -19,5 +21,10 @@ engine.init(case.tcfg)
 prof = case.profiles().ravel()[None, :]
 for _ in range(5):
     engine.run_batch(prof)
-print("expected table bytes per launch:", 2 * 100 * 4 * 10000 * 8 + 2 * 100 * 10000 * 8)
+L, M, W = 100, 4, 10000
+t = case.temp0
+ct = np.arange(400.0, 3000.1, 200.0)                      # the synthetic H2-H2 file's temperatures (bart_amd/synth.py)
+pairs = np.unique(np.clip(np.searchsorted(ct, np.clip(t, ct[0], ct[-1]), side="right") - 1, 0, len(ct) - 2))
+expected = 2 * L * M * W * 8 + len(pairs) * W * 16 + L * (4 + 2 * M + 2 + 2) * 8 + W * 8
+print("expected HBM bytes per launch:", expected)
 trm.free_memory()

@@ -285,6 +285,14 @@ int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext, int nl
   });
 }
 
+int bartrt_voigt(const double *x, const double *y, double *k, long n) {
+  if (n < 0 || (n > 0 && (!x || !y || !k))) return fail(BARTRT_EINVAL, "bartrt_voigt: bad arguments");
+  return guarded([&] {
+    lbl_voigt_probe(x, y, k, n);
+    return BARTRT_OK;
+  });
+}
+
 int bartrt_timing_begin(void) {
   NEED_ENGINE();
   g_eng->timing = true;

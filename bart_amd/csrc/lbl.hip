@@ -42,60 +42,83 @@ __device__ __forceinline__ double add_rounded(double a, double b) {
 // Re w(x + i y), x >= 0, y > 0.  Contraction is switched off inside and every
 // fused multiply-add is written out: the function is inlined into kernels with
 // different surroundings, and which products the compiler fuses must not depend
-// on them (a layer state can be summed by either accumulation kernel).
+// on them (a layer state can be summed by either accumulation kernel).  Which
+// branch a point takes depends on (x, y) alone, never on the other lanes.
+//
+// Both approximations are polynomials with REAL coefficients in a complex
+// argument (t = 1/z^2, resp. Weideman's Z).  Those are evaluated by synthetic
+// division by the argument's real quadratic  u^2 - 2 Re(u) u + |u|^2  (Knuth,
+// TAOCP 4.6.4): two real FMAs per coefficient instead of the five operations of a
+// complex Horner step; the remainder a u + b is the value.
 __device__ inline double voigt_k(double x, double y) {
 #pragma clang fp contract(off)
-  const double r2 = fma(x, x, y * y);
-  if (r2 >= 225.0) {
-    // far wings (almost every line-point pair of a pressure-broadened layer):
-    // asymptotic series w = i/(sqrt(pi) z) (1 + 1/(2 z^2) + 3/(4 z^4) + ...),
-    // 2 / 3 / 5 terms for |z| >= 100 / 30 / 15 (<= 1.3e-11 / 9e-11 / 1.7e-11)
+  const double x2 = x * x, y2 = y * y;
+  const double r2 = x2 + y2;
+  if (r2 >= 64.0) {
+    // |z| >= 8: asymptotic series  w = i/(sqrt(pi) z) * s(1/z^2),
+    // s(t) = sum_k (2k-1)!!/2^k t^k  -- three terms for |z| >= 100 (<= 1.4e-11: almost
+    // every line-point pair of a pressure-broadened layer), eleven below (<= 2.6e-12 at
+    // |z| = 8; the Laplace continued fraction with eight levels that stood here gave
+    // 1.7e-12 at eight reciprocals)
     const double inv = rcp_core(r2), inv2 = inv * inv;  // reciprocal + Newton: no IEEE divide per pair
-    const double tr = fma(x, x, -(y * y)) * inv2, ti = -2.0 * x * y * inv2;  // t = 1/z^2
-    double hr, hi;
-    if (r2 >= 1.0e4) { hr = 0.75; hi = 0.0; }
-    else {
-      if (r2 >= 900.0) { hr = 15.0 / 8.0; hi = 0.0; }
-      else {
-        hr = fma(945.0 / 32.0, tr, 105.0 / 16.0); hi = (945.0 / 32.0) * ti;
-        const double ar = fma(hr, tr, -hi * ti) + 15.0 / 8.0, ai = fma(hr, ti, hi * tr);
-        hr = ar; hi = ai;
+    const double tr = (x2 - y2) * inv2, ti = (-2.0 * x) * y * inv2;  // t = 1/z^2
+    double sr, si;
+    if (r2 >= 1.0e4) {
+      const double ur = fma(0.75, tr, 0.5), ui = 0.75 * ti;    // u = 1/2 + 3/4 t ; s = 1 + t u
+      sr = fma(tr, ur, fma(-ti, ui, 1.0));
+      si = fma(tr, ui, ti * ur);
+    } else {
+      const double p = tr + tr, q = fma(tr, tr, ti * ti);
+      double a = 639383.8623046875, b = 67303.564453125;       // c_10, c_9
+#pragma unroll
+      for (int k = 8; k >= 0; k--) {
+        constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625};
+        const double an = fma(p, a, b);
+        b = fma(-q, a, c[k]);
+        a = an;
       }
-      const double ar = fma(hr, tr, -hi * ti) + 0.75, ai = fma(hr, ti, hi * tr);
-      hr = ar; hi = ai;
+      sr = fma(a, tr, b);
+      si = a * ti;
     }
-    // h = c0 + t h ; s = 1 + t h
-    double ar = fma(hr, tr, -hi * ti) + 0.5, ai = fma(hr, ti, hi * tr);
-    const double sr = fma(ar, tr, -ai * ti) + 1.0, si = fma(ar, ti, ai * tr);
     // Re[i s / z] = (y s_r - x s_i) / |z|^2
     return kInvSqrtPi * fma(y, sr, -(x * si)) * inv;
   }
-  if (r2 >= 64.0) {
-    // Laplace continued fraction, 8 levels (8 <= |z| < 15, <= 1.7e-12)
-    const int K = 8;
-    double fr = x, fi = y;
-    for (int k = K; k >= 1; k--) {
-      const double s = (0.5 * k) * rcp_core(fma(fr, fr, fi * fi));
-      const double nr = fma(-s, fr, x), ni = fma(s, fi, y);
-      fr = nr; fi = ni;
-    }
-    return kInvSqrtPi * fi * rcp_core(fma(fr, fr, fi * fi));
-  }
   // Weideman N = 40: Z = ((L - y) + i x) / ((L + y) - i x)
   const double ar = kWeidL - y, br = kWeidL + y;
-  const double den = rcp_core(fma(br, br, x * x));
-  const double Zr = fma(ar, br, -(x * x)) * den, Zi = fma(x, br, ar * x) * den;
-  double pr = kWeidA[0], pi = 0.0;
+  const double den = rcp_core(fma(br, br, x2));
+  const double Zr = fma(ar, br, -x2) * den, Zi = fma(x, br, ar * x) * den;
+  const double p = Zr + Zr, q = fma(Zr, Zr, Zi * Zi);
+  double a = kWeidA[0], b = kWeidA[1];
 #pragma unroll 8
-  for (int k = 1; k < kWeidN; k++) {
-    const double t = fma(pr, Zr, -pi * Zi) + kWeidA[k];
-    pi = fma(pr, Zi, pi * Zr);
-    pr = t;
+  for (int k = 2; k < kWeidN; k++) {
+    const double an = fma(p, a, b);
+    b = fma(-q, a, kWeidA[k]);
+    a = an;
   }
+  const double pr = fma(a, Zr, b), pi = a * Zi;
   // 1/(L - iz) = (br + i x) den ; its square
   const double qr = br * den, qi = x * den;
   const double q2r = fma(qr, qr, -(qi * qi)), q2i = 2.0 * qr * qi;
   return fma(2.0, fma(pr, q2r, -(pi * q2i)), kInvSqrtPi * qr);
+}
+
+// Diagnostics (bartrt_voigt): the kernels' Voigt function on n (x, y) pairs.
+__global__ void voigt_probe(const double *x, const double *y, double *k, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) k[i] = voigt_k(x[i], y[i]);
+}
+
+void lbl_voigt_probe(const double *x, const double *y, double *k, long n) {
+  if (n <= 0) return;
+  double *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(double) * 3 * n));
+  HIPCHK(hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + n, y, sizeof(double) * n, hipMemcpyHostToDevice));
+  voigt_probe<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d, d + n, d + 2 * n, n);
+  hipError_t err = hipDeviceSynchronize();
+  if (err == hipSuccess) err = hipMemcpy(k, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIPCHK(err);
 }
 
 struct StateArgs {

@@ -78,4 +78,7 @@ void lbl_rt_eclipse(Engine &e, const double *d_prof, int nwalkers, const RtArgs 
 // opacity file (molecule order = TLI database order).
 void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<double> &tgrid);
 
+// Diagnostics: Re w(x + i y) as the accumulation kernels evaluate it (host arrays).
+void lbl_voigt_probe(const double *x, const double *y, double *k, long n);
+
 }  // namespace bartrt

@@ -89,6 +89,15 @@ def lbl_extinction(profile: np.ndarray) -> np.ndarray:
     return ext
 
 
+def voigt(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """Re w(x + i y) as the line-by-line kernels evaluate it (diagnostics; no engine needed)."""
+    x, y = np.broadcast_arrays(np.asarray(x, np.double), np.asarray(y, np.double))
+    xs, ys = np.ascontiguousarray(x).ravel(), np.ascontiguousarray(y).ravel()
+    k = np.empty_like(xs)
+    _check(trm.lib().bartrt_voigt(_ptr(xs), _ptr(ys), _ptr(k), xs.size))
+    return k.reshape(x.shape)
+
+
 # ---- device-resident (torch tensors own the memory) ----------------------
 def _stream_ptr(stream=None):
     import torch

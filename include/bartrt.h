@@ -193,6 +193,11 @@ int bartrt_get_intensity(double *intens, int nangles, int nwave);
 int bartrt_get_lbl_extinction(const double *prof, int nprof, double *ext,
                               int nlayers, int nwave);
 
+/* Diagnostics, no engine needed: the line-by-line kernels' Voigt function
+ * K(x, y) = Re w(x + i y) (x >= 0: distance from the line centre in Doppler widths
+ * / sqrt(ln 2); y > 0: Lorentz / Doppler width ratio) on n host (x, y) pairs. */
+int bartrt_voigt(const double *x, const double *y, double *k, long n);
+
 /* HIP-event timing of the RT kernel launches (bench.py's roofline leg).
  * begin resets; end returns accumulated device ms and launch count. */
 int bartrt_timing_begin(void);

@@ -2,8 +2,10 @@
 extinction, spectra and the generated opacity grid against the oracle on GPU.
 
 Tolerance: the device evaluates the Faddeeva function with a rational
-approximation good to 4e-9 (|z| < 8) / 2e-12 (continued fraction beyond); the
-oracle uses scipy's wofz.  1e-7 relative on sums of positive terms."""
+approximation (|z| < 8: absolute error <= 1e-14 of the line-centre value, 1e-9
+relative wherever the function is above 1e-6) / an asymptotic series (|z| >= 8: 3e-12; three terms from |z| = 100: 1.4e-11);
+the oracle uses scipy's wofz.  1e-7 relative on sums of positive terms;
+test_voigt_function_against_wofz holds the function itself."""
 import numpy as np
 import pytest
 
@@ -48,6 +50,39 @@ def test_isolated_line_integrates_to_its_strength(tmp_path):
     integ = np.sum(0.5 * (ext[1:] + ext[:-1]) * np.diff(o.wn))
     assert abs(integ / S - 1) < 2e-3
     assert ext.argmax() == 2000
+
+
+@pytest.mark.gpu
+def test_voigt_function_against_wofz():
+    """The kernels' K(x, y) over the (x, y) plane the line-by-line path visits -- Doppler
+    cores to pressure-broadened wings -- against scipy's Faddeeva function: every branch
+    boundary (|z| = 8, 100), both sides."""
+    from scipy.special import wofz
+    from bart_amd import engine
+    rng = np.random.default_rng(7)
+    n = 400000
+    x = np.concatenate([rng.uniform(0, 9, n), 10 ** rng.uniform(0.9, 4, n), np.zeros(1000),
+                        np.nextafter(8.0, [0.0, 9.0]), np.nextafter(100.0, [0.0, 200.0])])
+    y = 10 ** rng.uniform(-9, 3.5, x.size)
+    y[-4:] = 1e-6
+    k = engine.voigt(x, y)
+    ref = wofz(x + 1j * y).real
+    r2 = x * x + y * y
+    far = r2 >= 64.0
+    assert np.all(np.isfinite(k)) and np.all(k > 0)
+    # |z| >= 8: relative (asymptotic series: 3e-12 at |z| = 8 with eleven terms, 1.4e-11 at
+    # |z| = 100 with three; the omitted exp(-z^2) is < 2e-28)
+    assert np.max(np.abs(k[far] / ref[far] - 1)) < 2e-11
+    mid = far & (r2 < 1e4)
+    assert np.max(np.abs(k[mid] / ref[mid] - 1)) < 5e-12
+    # |z| < 8: absolute against the line-centre value 1, and relative wherever it is above 1e-6
+    near = ~far
+    assert np.max(np.abs(k[near] - ref[near])) < 1e-14
+    big = near & (ref > 1e-6)
+    assert np.max(np.abs(k[big] / ref[big] - 1)) < 1e-9
+    # broadcasting / empty input
+    assert engine.voigt(np.zeros(0), np.zeros(0)).size == 0
+    assert engine.voigt(1.0, np.array([0.5, 2.0])).shape == (2,)
 
 
 @pytest.mark.gpu

@@ -39,6 +39,18 @@ __device__ __forceinline__ double add_rounded(double a, double b) {
   return a + b;
 }
 
+// |z| >= 100 (almost every line-point pair of a pressure-broadened layer): three terms
+// of voigt_k's asymptotic series, written out in real arithmetic with 1/z = c - i s --
+//   sqrt(pi) K = s [1 + (3 c^2 - s^2)/2 + 3/4 (5 c^4 - 10 c^2 s^2 + s^4)]   (<= 1.4e-11)
+__device__ __forceinline__ double voigt_far(double x, double y, double r2) {
+#pragma clang fp contract(off)
+  const double inv = rcp_core(r2);                      // reciprocal + Newton: no IEEE divide per pair
+  const double c = x * inv, s = y * inv, C = c * c, S = s * s;
+  const double p1 = fma(1.5, C, -0.5 * S);
+  const double p2 = fma(C, fma(5.0, C, -10.0 * S), S * S);
+  return kInvSqrtPi * s * (fma(0.75, p2, p1) + 1.0);
+}
+
 // Re w(x + i y), x >= 0, y > 0.  Contraction is switched off inside and every
 // fused multiply-add is written out: the function is inlined into kernels with
 // different surroundings, and which products the compiler fuses must not depend
@@ -54,32 +66,23 @@ __device__ inline double voigt_k(double x, double y) {
 #pragma clang fp contract(off)
   const double x2 = x * x, y2 = y * y;
   const double r2 = x2 + y2;
+  if (r2 >= 1.0e4) return voigt_far(x, y, r2);
   if (r2 >= 64.0) {
-    // |z| >= 8: asymptotic series  w = i/(sqrt(pi) z) * s(1/z^2),
-    // s(t) = sum_k (2k-1)!!/2^k t^k  -- three terms for |z| >= 100 (<= 1.4e-11: almost
-    // every line-point pair of a pressure-broadened layer), eleven below (<= 2.6e-12 at
-    // |z| = 8; the Laplace continued fraction with eight levels that stood here gave
-    // 1.7e-12 at eight reciprocals)
-    const double inv = rcp_core(r2), inv2 = inv * inv;  // reciprocal + Newton: no IEEE divide per pair
+    // 8 <= |z| < 100: asymptotic series  w = i/(sqrt(pi) z) * s(1/z^2),
+    // s(t) = sum_k (2k-1)!!/2^k t^k, eleven terms (<= 2.6e-12 at |z| = 8; the Laplace
+    // continued fraction with eight levels that stood here gave 1.7e-12 at eight reciprocals)
+    const double inv = rcp_core(r2), inv2 = inv * inv;
     const double tr = (x2 - y2) * inv2, ti = (-2.0 * x) * y * inv2;  // t = 1/z^2
-    double sr, si;
-    if (r2 >= 1.0e4) {
-      const double ur = fma(0.75, tr, 0.5), ui = 0.75 * ti;    // u = 1/2 + 3/4 t ; s = 1 + t u
-      sr = fma(tr, ur, fma(-ti, ui, 1.0));
-      si = fma(tr, ui, ti * ur);
-    } else {
-      const double p = tr + tr, q = fma(tr, tr, ti * ti);
-      double a = 639383.8623046875, b = 67303.564453125;       // c_10, c_9
+    const double p = tr + tr, q = fma(tr, tr, ti * ti);
+    double a = 639383.8623046875, b = 67303.564453125;         // c_10, c_9
 #pragma unroll
-      for (int k = 8; k >= 0; k--) {
-        constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625};
-        const double an = fma(p, a, b);
-        b = fma(-q, a, c[k]);
-        a = an;
-      }
-      sr = fma(a, tr, b);
-      si = a * ti;
+    for (int k = 8; k >= 0; k--) {
+      constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625};
+      const double an = fma(p, a, b);
+      b = fma(-q, a, c[k]);
+      a = an;
     }
+    const double sr = fma(a, tr, b), si = a * ti;
     // Re[i s / z] = (y s_r - x s_i) / |z|^2
     return kInvSqrtPi * fma(y, sr, -(x * si)) * inv;
   }
@@ -89,7 +92,7 @@ __device__ inline double voigt_k(double x, double y) {
   const double Zr = fma(ar, br, -x2) * den, Zi = fma(x, br, ar * x) * den;
   const double p = Zr + Zr, q = fma(Zr, Zr, Zi * Zi);
   double a = kWeidA[0], b = kWeidA[1];
-#pragma unroll 8
+#pragma unroll
   for (int k = 2; k < kWeidN; k++) {
     const double an = fma(p, a, b);
     b = fma(-q, a, kWeidA[k]);
@@ -130,6 +133,7 @@ struct StateArgs {
   const double *diam;    // [S] cm
   const double *tgrid;   // table mode temperatures
   double *state;         // [nstate][2 + 3*niso]: T, oversampling factor dv, then (dopfac, alphaL, scale) per isotope
+  int *dvmax;            // largest dv of the launch (sizes lbl_accumulate_fine's LDS), or null
 };
 
 // One workgroup per state, lanes over isotopes.
@@ -183,6 +187,7 @@ __global__ void lbl_states(StateArgs a, LblDev d) {
       }
       out[0] = T;
       out[1] = (double)dv;
+      if (a.dvmax && dv > 1) atomicMax(a.dvmax, dv);
     }
   }
   if (!mine) return;
@@ -337,13 +342,14 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
         s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
       }
       __syncthreads();
-      for (int t = 0; t < cnt; t++) {
+      // product rounded on its own (no fma into the sum): the pair kernel stores
+      // the same product before adding it, and a state may change owner between
+      // two tilings of the grid -- the bits must not
+      auto one = [&](int t) {
         const double dv = fabs(nu - s_nu0[t]);
-        // product rounded on its own (no fma into the sum): the pair kernel stores
-        // the same product before adding it, and a state may change owner between
-        // two tilings of the grid -- the bits must not
         if (dv <= s_cut[t]) acc = add_rounded(acc, mul_rounded(s_amp[t], voigt_k(dv * s_xs[t], s_y[t])));
-      }
+      };
+      for (int t = 0; t < cnt; t++) one(t);
       __syncthreads();
     }
   }
@@ -444,7 +450,10 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
       }
       wave_sync();
       // ---- C
-      for (int t = 0; t < 64; t++) {
+      // (only the round's lines that reach a point: a third of a typical list is kept
+      // at all, and a wave's 64 points see fewer still)
+      for (unsigned long long live = __ballot(n > 0); live; live &= live - 1) {
+        const int t = __builtin_ctzll(live);
         const unsigned k = (unsigned)(lane - ws.first[t]);
         if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc = add_rounded(acc, ws.val[ws.off[t] + k]);
       }
@@ -463,83 +472,106 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
 // the dv fine points centred on the output point, an even dv takes dv + 1 with the
 // two ends at half weight; the first / last point of the full grid use the half of the
 // window that lies on the grid, normalised by its own weights.  On its fine grid every
-// state is broad (dv is chosen so that a half-width spans two fine points or more, and
-// a line is cut at nwidth half-widths), so the lane = point form of lbl_accumulate
-// keeps all lanes busy.  One workgroup per (256 output points, state): sub-tiles of
-// about 1 024 fine points, walked by the 256 lanes in up to nine passes whose sums
-// stay in registers while the window of the line list is staged through LDS once per
-// sub-tile; then the fine values meet in LDS and one lane per output point reduces
-// them in ascending order.
-constexpr int kFinePasses = 9;           // (wnosamp <= 2 160: one output point spans 2 161 fine points)
-__global__ __launch_bounds__(256) void lbl_accumulate_fine(LblDev d, AccArgs a) {
-  __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
-  __shared__ double s_fine[256 * kFinePasses];
-  __shared__ int s_wcount[4];
+// state is broad: dv is chosen so that a half-width spans two fine points or more, and
+// a line is cut at nwidth half-widths -- 80 fine points and up.
+// Line-major: ONE wave per sub-tile of about kFineTarget fine points, whose sums live
+// in LDS; the wave stages 64 lines at a time (lane = line: strength, cut, and the
+// line's index ranges on the fine grid), then takes the kept lines one after the other
+// with lane = fine point of THAT line: first both wings packed into one run of lanes,
+// then the core.  (Round 2's first form, lane = point looping over the lines, left the
+// lanes beyond a line's cut idle and, where a wave straddles |z| = 8, ran both branches
+// of the Voigt function for all of them: 67 against 55 ms on config 5.  Here the lanes
+// of a step are consecutive points of one line, on one side of |z| = 8 up to the
+// rounding of the range ends -- the branch itself stays per point.)  Every fine point
+// adds its lines in list order, whatever the tiling.  No workgroup barrier anywhere;
+// smaller sub-tiles (more resident waves) measured faster than larger ones (512: 55 ms,
+// 1 024: 56, 2 048: 63, 4 096: 92).
+constexpr int kFineTarget = 512;
+__global__ __launch_bounds__(64) void lbl_accumulate_fine(LblDev d, AccArgs a, int nfmax) {
+  extern __shared__ double s_dyn[];
+  double *s_fine = s_dyn;                                           // [nfmax]
+  double *s_nu0 = s_dyn + nfmax, *s_amp = s_nu0 + 64, *s_xs = s_amp + 64, *s_y = s_xs + 64, *s_cut = s_y + 64;
+  int *s_rng = reinterpret_cast<int *>(s_cut + 64);                 // [64][4]: first point, core first / last, last point
   const int st = blockIdx.y;
-  const int tile0 = blockIdx.x * 256;
+  const int tile0 = blockIdx.x * 64;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
   if (!(sv[1] > 1.0)) return;             // evaluated on the output points: the other two kernels
   const int dv = (int)sv[1], h = dv / 2;
-  const double invT = 1.0 / sv[0], step = d.wndelt / dv;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double invT = 1.0 / sv[0], step = d.wndelt / dv, inv_step = dv / d.wndelt;
+  const int lane = threadIdx.x;
   const long kmax = (long)(d.wfull - 1) * dv;            // last fine point of the full grid
-  const int tile_end = min(tile0 + 256, a.W);
-  // output points per sub-tile: about 1 024 fine points (at most 2 * h + 1 <= 2 161 when dv > 1 024)
-  const int TO = min(256, max(1, 1024 / dv));
+  const int tile_end = min(tile0 + 64, a.W);
+  const int TO = min(64, max(1, kFineTarget / dv));      // output points per sub-tile
   const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
   for (int o0 = tile0; o0 < tile_end; o0 += TO) {
     const int o1 = min(o0 + TO, tile_end);               // output points [o0, o1)
     const long c0 = (long)(d.i_off + o0) * dv, c1 = (long)(d.i_off + o1 - 1) * dv;
     const long fa = max(c0 - h, 0L), fb = min(c1 + h, kmax);
-    const int nf = (int)(fb - fa + 1);
+    const int nf = (int)(fb - fa + 1);                   // <= max(kFineTarget, dv) + 1 <= nfmax
+    for (int p = lane; p < nf; p += 64) s_fine[p] = 0.0;
     // fine point k of the full grid: wn_first + k * step, product and sum rounded one
     // after the other (a fused multiply-add would move points that sit exactly on a
     // line's cut to the other side of it)
     const double nu_a = add_rounded(d.wn_first, mul_rounded((double)fa, step));
     const double nu_b = add_rounded(d.wn_first, mul_rounded((double)fb, step));
-    double acc[kFinePasses], nu[kFinePasses];
-#pragma unroll
-    for (int ps = 0; ps < kFinePasses; ps++) {
-      acc[ps] = 0.0;
-      nu[ps] = add_rounded(d.wn_first, mul_rounded((double)(fa + ps * 256 + threadIdx.x), step));
-    }
+    wave_sync();
     for (int g = g_lo; g < g_hi; g++) {
       long j0, j1;
       double cmax;
       line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
       const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
-      for (long base = j0; base < j1; base += 256) {
-        const long j = base + threadIdx.x;
+      for (long base = j0; base < j1; base += 64) {
+        const long j = base + lane;
         LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
         if (j < j1) r = stage_line(d, sv, invT, thresh, j);
-        const unsigned long long keep = __ballot(r.cut >= 0.0);
-        if (lane == 0) s_wcount[wave] = __popcll(keep);
-        __syncthreads();
-        int pos = __popcll(keep & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; w++) pos += s_wcount[w];
-        const int cnt = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        int r0 = 0, r1 = 0, r2 = -1, r3 = -1;
         if (r.cut >= 0.0) {
-          s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < kFinePasses; ps++) {
-          if (ps * 256 >= nf) break;                     // uniform
-          if (ps * 256 + (int)threadIdx.x < nf) {
-            for (int t = 0; t < cnt; t++) {
-              const double dx = fabs(nu[ps] - s_nu0[t]);
-              if (dx <= s_cut[t]) acc[ps] = add_rounded(acc[ps], mul_rounded(s_amp[t], voigt_k(dx * s_xs[t], s_y[t])));
+          // the line's points of this sub-tile, one point of slack either side (the exact
+          // |nu - nu0| <= cut test is per point)
+          const double ctr = (r.nu0 - d.wn_first) * inv_step, wd = r.cut * inv_step;
+          long lo = (long)floor(ctr - wd) - 1, hi = (long)ceil(ctr + wd) + 1;
+          lo = max(lo, fa); hi = min(hi, fb);
+          if (lo > hi) r.cut = -1.0;      // out of this sub-tile's reach
+          else {
+            long a0 = hi + 1, a1 = hi;    // core [a0, a1]: the points with |z| < 8, none if y >= 8
+            if (r.y < 8.0) {
+              const double d8 = sqrt(64.0 - r.y * r.y) / r.xs * inv_step;
+              a0 = (long)ceil(ctr - d8); a1 = (long)floor(ctr + d8);
+              a0 = min(max(a0, lo), hi + 1); a1 = max(min(a1, hi), a0 - 1);
             }
+            r0 = (int)(lo - fa); r1 = (int)(a0 - fa); r2 = (int)(a1 - fa); r3 = (int)(hi - fa);
           }
         }
-        __syncthreads();
+        const unsigned long long keep = __ballot(r.cut >= 0.0);
+        const int cnt = __popcll(keep);
+        if (cnt == 0) continue;
+        if (r.cut >= 0.0) {
+          const int pos = __popcll(keep & ((1ull << lane) - 1ull));   // list order
+          s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
+          s_rng[4 * pos] = r0; s_rng[4 * pos + 1] = r1; s_rng[4 * pos + 2] = r2; s_rng[4 * pos + 3] = r3;
+        }
+        wave_sync();
+        for (int t = 0; t < cnt; t++) {
+          const double l_nu0 = s_nu0[t], l_amp = s_amp[t], l_xs = s_xs[t], l_y = s_y[t], l_cut = s_cut[t];
+          const int klo = __builtin_amdgcn_readfirstlane(s_rng[4 * t]);
+          const int kc0 = __builtin_amdgcn_readfirstlane(s_rng[4 * t + 1]);
+          const int kc1 = __builtin_amdgcn_readfirstlane(s_rng[4 * t + 2]);
+          const int khi = __builtin_amdgcn_readfirstlane(s_rng[4 * t + 3]);
+          auto point = [&](int k) {
+            const double nu = add_rounded(d.wn_first, mul_rounded((double)(fa + k), step));
+            const double dx = fabs(nu - l_nu0);
+            if (dx <= l_cut) s_fine[k] = add_rounded(s_fine[k], mul_rounded(l_amp, voigt_k(dx * l_xs, l_y)));
+          };
+          const int nl = kc0 - klo, nw = nl + (khi - kc1);
+          for (int b = lane; b < nw; b += 64) point(b < nl ? klo + b : kc1 + 1 + (b - nl));
+          for (int k = kc0 + lane; k <= kc1; k += 64) point(k);
+        }
+        wave_sync();
       }
     }
-#pragma unroll
-    for (int ps = 0; ps < kFinePasses; ps++) s_fine[ps * 256 + threadIdx.x] = acc[ps];
-    __syncthreads();
-    if ((int)threadIdx.x < o1 - o0) {
-      const int o = o0 + threadIdx.x;
+    wave_sync();
+    if (lane < o1 - o0) {
+      const int o = o0 + lane;
       const long c = (long)(d.i_off + o) * dv;
       const long lo = max(c - h, 0L), hi = min(c + h, kmax);
       const bool even = (dv & 1) == 0;
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate_fine(LblDev d, AccArgs a) 
       if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + o] = v;
       else a.out[(size_t)st * a.W + o] = v;
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -673,7 +705,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
 Lbl::~Lbl() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_nu0); fr(d_elow); fr(d_gf); fr(d_ztab); fr(d_ztemp); fr(d_liso);
-  fr(d_state); fr(d_smax); fr(d_ext); fr(d_bucket);
+  fr(d_state); fr(d_smax); fr(d_ext); fr(d_bucket); fr(d_dvmax);
 }
 
 template <class T>
@@ -807,6 +839,7 @@ static void ensure_states(Engine &e, long nstate, bool need_ext) {
     p = nullptr;
     HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double)));
   };
+  if (!b->d_dvmax) HIPCHK(hipMalloc(&b->d_dvmax, sizeof(int)));
   long cap = std::max(nstate, b->cap_state);
   re(b->d_state, (size_t)cap * (2 + 3 * b->dev.niso));
   re(b->d_smax, (size_t)cap * b->dev.ngroup);
@@ -820,6 +853,8 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
   sa.L = e.L; sa.S = e.S; sa.iH2 = e.iH2; sa.iHe = e.iHe;
   sa.press = e.d_press; sa.mass = e.d_mass; sa.diam = e.d_diam;
   sa.state = b->d_state;
+  sa.dvmax = b->d_dvmax;
+  HIPCHK(hipMemsetAsync(b->d_dvmax, 0, sizeof(int), st));
   hipLaunchKernelGGL(lbl_states, dim3(sa.nstate), dim3(64), 0, st, sa, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(b->d_smax, 0, sizeof(double) * (size_t)sa.nstate * d.ngroup, st));
@@ -833,10 +868,19 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
                      0, st, d, aa);
   hipLaunchKernelGGL(lbl_accumulate_pairs, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
                      0, st, d, aa);
-  if (d.osamp > 1)   // the states evaluated on a finer grid (each state is owned by one of the three)
-    hipLaunchKernelGGL(lbl_accumulate_fine, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
-                       0, st, d, aa);
   HIPCHK(hipGetLastError());
+  if (d.osamp > 1) {   // the states evaluated on a finer grid (each state is owned by one of the three)
+    int dvmax = 0;     // decided on the device (lbl_states); the other two kernels run meanwhile
+    HIPCHK(hipMemcpyAsync(&dvmax, b->d_dvmax, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (dvmax > 1) {
+      const int nfmax = std::max(kFineTarget, dvmax) + 1;
+      const size_t sh = sizeof(double) * ((size_t)nfmax + 5 * 64) + sizeof(int) * 4 * 64;
+      hipLaunchKernelGGL(lbl_accumulate_fine, dim3((aa.W + 63) / 64, sa.nstate, aa.per_group ? d.ngroup : 1),
+                         dim3(64), sh, st, d, aa, nfmax);
+    }
+    HIPCHK(hipGetLastError());
+  }
 }
 
 void lbl_extinction(Engine &e, const double *d_prof, int nwalkers, hipStream_t st) {

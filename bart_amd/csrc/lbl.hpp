@@ -58,6 +58,7 @@ struct Lbl {
   double *d_state = nullptr;     // [nstate][3*niso + 2]
   double *d_smax = nullptr;      // [nstate][ngroup]
   double *d_ext = nullptr;       // [nstate][W] (extinction mode)
+  int *d_dvmax = nullptr;        // largest oversampling factor among the states of a call
   long cap_state = 0;
   ~Lbl();
 };

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void lbl_smax(LblDev d, const double *state, d
 
 struct AccArgs {
   int W, nstate, per_group;   // per_group: out[state][g][W] else out[state][W] summed over groups
+  int pair_reach;             // states whose widest cut spans at most this many points go to lbl_accumulate_pairs
   const double *wn;
   const double *state, *smax;
   double *out;
@@ -272,7 +273,6 @@ __device__ __forceinline__ void line_window(const LblDev &d, const double *sv, i
 // Widest cut of any isotope at this state / smallest point spacing of the tile:
 // how many points a line can reach on either side.  Decides which of the two
 // accumulation kernels owns the state (both are launched over all states).
-constexpr int kPairReach = 7;
 __device__ __forceinline__ bool narrow_state(const LblDev &d, const AccArgs &a, const double *sv, int tile0) {
   const int ilast = min(tile0 + 255, a.W - 1);
   if (ilast <= tile0) return false;
@@ -280,7 +280,7 @@ __device__ __forceinline__ bool narrow_state(const LblDev &d, const AccArgs &a, 
   double cany = 0.0;
   for (int k = 0; k < d.niso; k++)
     cany = fmax(cany, d.nwidth * fmax(sv[3 + 3 * k], (a.wn[ilast] + 1.0) * sv[2 + 3 * k] * 1.011));
-  return cany <= kPairReach * dnu;
+  return cany <= a.pair_reach * dnu;
 }
 
 // One line's staged record, or cut < 0 for a line below the strength threshold.
@@ -359,25 +359,33 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
   }
 }
 
-// Narrow states (Doppler cores: every cut reaches at most kPairReach points).
+// Narrow and moderately broad states (every cut reaches at most kPairReach points).
 // With lane = point a step would evaluate the Voigt function -- and the core of
 // a Doppler line is its costly branch, a 40-term rational -- with the few lanes
 // a line reaches and the rest of the wave idle, and a workgroup-wide staging
 // loop would leave three of four waves waiting at its barriers (a chunk of the
 // sorted list overlaps one wave's points).  Here every wave works alone on its 64
-// points, no workgroup barrier, 64 lines per round:
+// points, no workgroup barrier, up to 64 lines per round:
 //   A  lane = line: stage it, find its range of the wave's points (binary
-//      search), prefix sum of the range lengths -> pair offsets
+//      search), prefix sum of the range lengths -> pair offsets; the round takes
+//      the leading lines whose pairs fit the LDS buffer (kPairCap)
 //   B  lane = (line, point) pair, 64 pairs per pass, all lanes busy: the pair's
-//      contribution goes to an LDS buffer in pair order
-//   C  lane = point: adds its pairs in line order (fixed summation order, no atomics)
-constexpr int kPairsPerLine = 2 * kPairReach + 3;   // incl. one point of slack either side
+//      contribution goes to the buffer in pair order
+//   C  lane = point: adds its pairs in line order (fixed summation order, no
+//      atomics), looping over the round's lines that reach any point at all, their
+//      ranges broadcast from the registers of their phase-A lanes
+// Ownership: states whose widest cut spans at most kPairReach points (measured on
+// config 5, the 80 layers above 3 bar: 7: 4.5 ms, 12: 4.0, 20: 3.9, 31: 3.5, 48: 3.5 --
+// with lane = point a line of 2 * 31 points still leaves half of a wave's lanes idle).
+constexpr int kPairReach = 31;
+constexpr int kPairCap = 256;                       // pairs per round (LDS buffer)
 
 struct PairScratch {                        // per wave
   double wnu[64];                           // the wave's points
   double nu0[64], amp[64], xs[64], y[64], cut[64];   // the round's lines
-  double val[64 * kPairsPerLine];           // pair contributions of the round
-  int off[65], first[64];                   // pair offset and first point of each line
+  double val[kPairCap];                     // pair contributions of the round
+  int off[64], first[64];                   // pair offset and first point of each line
+  unsigned char line[kPairCap];             // the line (lane of phase A) a pair belongs to
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -410,7 +418,8 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
     double cmax;
     line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
     const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
-    for (long base = j0; base < j1; base += 64) {
+    const int nmax = 2 * a.pair_reach + 3;   // points of a line incl. one of slack either side (<= kPairCap)
+    for (long base = j0; base < j1;) {
       // ---- A
       const long j = base + lane;
       LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
         if (c > b) {
           // one point of slack either side: the exact |nu - nu0| <= cut test is per pair
           first = b > 0 ? b - 1 : 0;
-          n = min((c < 64 ? c + 1 : 64) - first, kPairsPerLine);
+          n = min((c < 64 ? c + 1 : 64) - first, nmax);
         }
       }
       int incl = n;  // inclusive prefix sum over the lanes
@@ -434,28 +443,36 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
         const int v = __shfl_up(incl, o);
         if (lane >= o) incl += v;
       }
-      const int total = __shfl(incl, 63);
+      // the round takes the leading lines whose pairs fit the buffer (at least one: a
+      // line has at most nmax <= kPairCap); the others are staged again by the next round
+      const unsigned long long fit = __ballot(incl <= kPairCap);
+      const int m = ~fit ? __builtin_ctzll(~fit) : 64;
+      if (lane >= m) n = 0;
+      const int total = __builtin_amdgcn_readlane(incl, m - 1);
+      base += m;
       if (total == 0) continue;
       ws.nu0[lane] = r.nu0; ws.amp[lane] = r.amp; ws.xs[lane] = r.xs; ws.y[lane] = r.y; ws.cut[lane] = r.cut;
-      ws.off[lane] = incl - n;
+      const int offv = incl - n;
+      ws.off[lane] = offv;
       ws.first[lane] = first;
-      if (lane == 63) ws.off[64] = total;
+      for (int k = 0; k < n; k++) ws.line[offv + k] = (unsigned char)lane;
       wave_sync();
       // ---- B
       for (int p = lane; p < total; p += 64) {
-        int x = 0, y = 64;  // line of pair p: last t with off[t] <= p
-        while (y - x > 1) { const int m = (x + y) >> 1; if (ws.off[m] <= p) x = m; else y = m; }
+        const int x = ws.line[p];
         const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
         ws.val[p] = dv <= ws.cut[x] ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
       }
       wave_sync();
       // ---- C
       // (only the round's lines that reach a point: a third of a typical list is kept
-      // at all, and a wave's 64 points see fewer still)
+      // at all, and a wave's 64 points see fewer still; a line's range comes from the
+      // registers of its phase-A lane, so a point no line reaches reads nothing from LDS)
       for (unsigned long long live = __ballot(n > 0); live; live &= live - 1) {
         const int t = __builtin_ctzll(live);
-        const unsigned k = (unsigned)(lane - ws.first[t]);
-        if (k < (unsigned)(ws.off[t + 1] - ws.off[t])) acc = add_rounded(acc, ws.val[ws.off[t] + k]);
+        const unsigned k = (unsigned)(lane - __builtin_amdgcn_readlane(first, t));
+        if (k < (unsigned)__builtin_amdgcn_readlane(n, t))
+          acc = add_rounded(acc, ws.val[__builtin_amdgcn_readlane(offv, t) + k]);
       }
       wave_sync();
     }
@@ -863,6 +880,7 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
                      b->d_smax, sa.nstate);
   HIPCHK(hipGetLastError());
   aa.W = e.W(); aa.nstate = sa.nstate; aa.wn = e.d_wn; aa.state = b->d_state; aa.smax = b->d_smax;
+  aa.pair_reach = kPairReach;
   const int ntile = (aa.W + 255) / 256;
   hipLaunchKernelGGL(lbl_accumulate, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
                      0, st, d, aa);

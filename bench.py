@@ -115,15 +115,19 @@ def cpu_baseline(case, profs, seconds_target=12.0):
                       f"one walker per thread, {dt:.1f} s wall"}
 
 
+RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "prep.hpp", "engine.hpp", "rt_eclipse_i0.hip",
+              "rt_eclipse_i0_ilp.hip", "kernels.hip", "engine.hip")
+
+
 def source_id():
-    """Short hash of the kernel sources: ties committed profiler figures (PMC traffic,
-    instruction mix) to the build they were taken on; bench.py reports them only when
-    the sources are unchanged."""
-    import glob
+    """Short hash of the sources the eclipse RT kernel, its launch and its inputs are built
+    from: ties committed profiler figures (PMC traffic, instruction mix) to the build they
+    were taken on; bench.py reports them only when these sources are unchanged."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "bart_amd", "csrc", "*.h*"))):
-        h.update(open(f, "rb").read())
+    for f in RT_SOURCES:
+        h.update(open(os.path.join(ROOT, "bart_amd", "csrc", f), "rb").read())
+    h.update(open(os.path.join(ROOT, "bart_amd", "build.py"), "rb").read())   # compiler flags
     return h.hexdigest()[:12]
 
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
       e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[1];
     }
     tc.layer(k, active, active ? 0.5 : 0.0, e, c[0], sW);
-    const double B = bnum * rcp_core(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
+    const double B = bnum * rcp_n1(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
     double E[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {

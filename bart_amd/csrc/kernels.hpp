@@ -224,13 +224,21 @@ __device__ __forceinline__ double exp_core(double x) {
   return exp_scale(p, t);
 }
 
-// 1/d for normal, positive d: hardware estimate + two Newton steps.
+// 1/d for normal, positive d: hardware estimate + two Newton steps.  Measured on gfx950
+// over 4e6 arguments between 1e-300 and 1e300: v_rcp_f64 alone 4.6e-8, one step 2.2e-15,
+// two steps 1.1e-16 relative.
 __device__ __forceinline__ double rcp_core(double d) {
   double y = __builtin_amdgcn_rcp(d);
   double e = fma(-d, y, 1.0);
   y = fma(y, e, y);
   e = fma(-d, y, 1.0);
   return fma(y, e, y);
+}
+// One Newton step (2.2e-15): the Planck function and the Voigt approximations, whose
+// own errors are 1e-13 and up.
+__device__ __forceinline__ double rcp_n1(double d) {
+  const double y = __builtin_amdgcn_rcp(d);
+  return fma(y, fma(-d, y, 1.0), y);
 }
 
 // exp() of the RT kernels (Planck exponent and slant transmittances): same

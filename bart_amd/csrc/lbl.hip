@@ -44,7 +44,7 @@ __device__ __forceinline__ double add_rounded(double a, double b) {
 //   sqrt(pi) K = s [1 + (3 c^2 - s^2)/2 + 3/4 (5 c^4 - 10 c^2 s^2 + s^4)]   (<= 1.4e-11)
 __device__ __forceinline__ double voigt_far(double x, double y, double r2) {
 #pragma clang fp contract(off)
-  const double inv = rcp_core(r2);                      // reciprocal + Newton: no IEEE divide per pair
+  const double inv = rcp_n1(r2);                      // reciprocal + Newton: no IEEE divide per pair
   const double c = x * inv, s = y * inv, C = c * c, S = s * s;
   const double p1 = fma(1.5, C, -0.5 * S);
   const double p2 = fma(C, fma(5.0, C, -10.0 * S), S * S);
@@ -71,7 +71,7 @@ __device__ inline double voigt_k(double x, double y) {
     // 8 <= |z| < 100: asymptotic series  w = i/(sqrt(pi) z) * s(1/z^2),
     // s(t) = sum_k (2k-1)!!/2^k t^k, eleven terms (<= 2.6e-12 at |z| = 8; the Laplace
     // continued fraction with eight levels that stood here gave 1.7e-12 at eight reciprocals)
-    const double inv = rcp_core(r2), inv2 = inv * inv;
+    const double inv = rcp_n1(r2), inv2 = inv * inv;
     const double tr = (x2 - y2) * inv2, ti = (-2.0 * x) * y * inv2;  // t = 1/z^2
     const double p = tr + tr, q = fma(tr, tr, ti * ti);
     double a = 639383.8623046875, b = 67303.564453125;         // c_10, c_9

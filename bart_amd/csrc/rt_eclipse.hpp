@@ -160,7 +160,7 @@ void rt_eclipse_fast(RtArgs p) {
 #pragma unroll
     for (int a = 0; a < AE; a++) es[a] = ex[a];
     if (SQ) es[A - 1] = ex[0] * ex[0];
-    const double B = bnum * rcp_core(ex[AE] - 1.0);
+    const double B = bnum * rcp_n1(ex[AE] - 1.0);
     ci.layer(p, A, live, lv, tc.tau, Bprev, B, es);
     Bprev = B;
     active = active && !(live && tc.tau > p.toomuch);
@@ -264,7 +264,7 @@ void rt_eclipse_split(RtArgs p) {
 #pragma unroll
       for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
       tc.layer(k, live, lv, e, cf[0], sW);
-      const double B = bnum * rcp_core(exp_rt(fmin(cf[1] * nu, 700.0)) - 1.0);
+      const double B = bnum * rcp_n1(exp_rt(fmin(cf[1] * nu, 700.0)) - 1.0);
       double *slot = sX + (k & 7) * 128;   // half (k/4)&1, layer k&3
       slot[lane] = tc.tau;
       slot[64 + lane] = INTEG == kIntegTransmittance ? (Bprev + B) * lv : (live ? B : -1.0);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 #pragma unroll
     for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
     exp_rt_n<AE + 1>(xs, ex);
-    const double B = bnum * rcp_core(ex[AE] - 1.0);
+    const double B = bnum * rcp_n1(ex[AE] - 1.0);
     if constexpr (INTEG == kIntegTransmittance) {
       // the layer above: row q - 1, or the carry for row 0
       const double B_below = __shfl(B, from_below);

@@ -31,5 +31,5 @@ python3 tools/isa_stats.py --ilp --json profiles/isa_latest.json > "profiles/${t
 # the bench line last, so that its `traffic` is this round's PMC figure
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cp "$out/bench.json" "profiles/${tag}_bench.json"
-mkdir -p "$out/profiles" && cp profiles/${tag}_* profiles/pmc_latest.json "$out/profiles/" 2>/dev/null
+mkdir -p "$out/profiles" && cp profiles/${tag}_* profiles/pmc_latest.json profiles/isa_latest.json "$out/profiles/" 2>/dev/null
 tail -c 600 "$out/bench.json"

@@ -365,15 +365,21 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
 // a line reaches and the rest of the wave idle, and a workgroup-wide staging
 // loop would leave three of four waves waiting at its barriers (a chunk of the
 // sorted list overlaps one wave's points).  Here every wave works alone on its 64
-// points, no workgroup barrier, up to 64 lines per round:
-//   A  lane = line: stage it, find its range of the wave's points (binary
-//      search), prefix sum of the range lengths -> pair offsets; the round takes
-//      the leading lines whose pairs fit the LDS buffer (kPairCap)
+// points, no workgroup barrier:
+//   A1 lane = line, 64 lines of the window at a time: stage it; the lines above the
+//      strength threshold whose cut reaches the wave's span join a queue in LDS
+//   A2 (the queue holds 64 lines, or the window is exhausted) lane = queued line: its
+//      range of the wave's points (binary search), prefix sum of the range lengths ->
+//      pair offsets; the round takes the leading lines whose pairs fit the LDS buffer
+//      (kPairCap), the rest stay queued
 //   B  lane = (line, point) pair, 64 pairs per pass, all lanes busy: the pair's
 //      contribution goes to the buffer in pair order
 //   C  lane = point: adds its pairs in line order (fixed summation order, no
 //      atomics), looping over the round's lines that reach any point at all, their
-//      ranges broadcast from the registers of their phase-A lanes
+//      ranges broadcast from the registers of their A2 lanes
+// (A lane = point gather over each point's own window of the sorted list was costed and
+// dropped: the wave runs the longest of its 64 windows, about four times the mean for
+// Doppler cores.)
 // Ownership: states whose widest cut spans at most kPairReach points (measured on
 // config 5, the 80 layers above 3 bar: 7: 4.5 ms, 12: 4.0, 20: 3.9, 31: 3.5, 48: 3.5 --
 // with lane = point a line of 2 * 31 points still leaves half of a wave's lanes idle).
@@ -382,10 +388,10 @@ constexpr int kPairCap = 256;                       // pairs per round (LDS buff
 
 struct PairScratch {                        // per wave
   double wnu[64];                           // the wave's points
-  double nu0[64], amp[64], xs[64], y[64], cut[64];   // the round's lines
+  double nu0[128], amp[128], xs[128], y[128], cut[128];   // queue of kept lines that reach the wave, list order
   double val[kPairCap];                     // pair contributions of the round
-  int off[64], first[64];                   // pair offset and first point of each line
-  unsigned char line[kPairCap];             // the line (lane of phase A) a pair belongs to
+  int off[64], first[64];                   // pair offset and first point of each line of the round
+  unsigned char line[kPairCap];             // the line (queue slot) a pair belongs to
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -412,21 +418,17 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
   wave_sync();
   const double nu_a = a.wn[w0], nu_b = a.wn[min(w0 + 63, a.W - 1)];
   const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
+  const int nmax = 2 * a.pair_reach + 3;   // points of a line incl. one of slack either side (<= kPairCap)
   double acc = 0.0;
-  for (int g = g_lo; g < g_hi; g++) {
-    long j0, j1;
-    double cmax;
-    line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
-    const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
-    const int nmax = 2 * a.pair_reach + 3;   // points of a line incl. one of slack either side (<= kPairCap)
-    for (long base = j0; base < j1;) {
-      // ---- A
-      const long j = base + lane;
-      LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
-      if (j < j1) r = stage_line(d, sv, invT, thresh, j);
+  int pending = 0;                         // queued lines (wave-uniform)
+  // Rounds B / C over the head of the queue: while it holds 64 lines (all of it when flushing)
+  auto rounds = [&](bool flush) {
+    while (pending >= 64 || (flush && pending > 0)) {
+      const int nq = min(pending, 64);
+      // ---- A2  lane = queued line: its range of the wave's points
       int first = 0, n = 0;
-      if (r.cut >= 0.0) {
-        const double lo = r.nu0 - r.cut, hi = r.nu0 + r.cut;
+      if (lane < nq) {
+        const double lo = ws.nu0[lane] - ws.cut[lane], hi = ws.nu0[lane] + ws.cut[lane];
         int b = 0, e = 64;  // b -> first point >= lo
         while (b < e) { const int m = (b + e) >> 1; if (ws.wnu[m] < lo) b = m + 1; else e = m; }
         int c = b;          // c -> first point > hi
@@ -444,39 +446,70 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
         if (lane >= o) incl += v;
       }
       // the round takes the leading lines whose pairs fit the buffer (at least one: a
-      // line has at most nmax <= kPairCap); the others are staged again by the next round
+      // line has at most nmax <= kPairCap); the others stay at the head of the queue
       const unsigned long long fit = __ballot(incl <= kPairCap);
-      const int m = ~fit ? __builtin_ctzll(~fit) : 64;
+      const int m = min(~fit ? __builtin_ctzll(~fit) : 64, nq);
       if (lane >= m) n = 0;
       const int total = __builtin_amdgcn_readlane(incl, m - 1);
-      base += m;
-      if (total == 0) continue;
-      ws.nu0[lane] = r.nu0; ws.amp[lane] = r.amp; ws.xs[lane] = r.xs; ws.y[lane] = r.y; ws.cut[lane] = r.cut;
       const int offv = incl - n;
-      ws.off[lane] = offv;
-      ws.first[lane] = first;
-      for (int k = 0; k < n; k++) ws.line[offv + k] = (unsigned char)lane;
-      wave_sync();
-      // ---- B
-      for (int p = lane; p < total; p += 64) {
-        const int x = ws.line[p];
-        const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
-        ws.val[p] = dv <= ws.cut[x] ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
+      if (total > 0) {
+        ws.off[lane] = offv;
+        ws.first[lane] = first;
+        for (int k = 0; k < n; k++) ws.line[offv + k] = (unsigned char)lane;
+        wave_sync();
+        // ---- B
+        for (int p = lane; p < total; p += 64) {
+          const int x = ws.line[p];
+          const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
+          ws.val[p] = dv <= ws.cut[x] ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
+        }
+        wave_sync();
+        // ---- C  (a line's range comes from the registers of its A2 lane, so a point no
+        // line reaches reads nothing from LDS)
+        for (unsigned long long live = __ballot(n > 0); live; live &= live - 1) {
+          const int t = __builtin_ctzll(live);
+          const unsigned k = (unsigned)(lane - __builtin_amdgcn_readlane(first, t));
+          if (k < (unsigned)__builtin_amdgcn_readlane(n, t))
+            acc = add_rounded(acc, ws.val[__builtin_amdgcn_readlane(offv, t) + k]);
+        }
       }
+      // the queue moves up by the m lines taken
+      const int rem = pending - m;
+      double q0[5], q1[5];
+      const bool h0 = lane < rem, h1 = lane + 64 < rem;
+      if (h0) { q0[0] = ws.nu0[m + lane]; q0[1] = ws.amp[m + lane]; q0[2] = ws.xs[m + lane]; q0[3] = ws.y[m + lane]; q0[4] = ws.cut[m + lane]; }
+      if (h1) { q1[0] = ws.nu0[m + 64 + lane]; q1[1] = ws.amp[m + 64 + lane]; q1[2] = ws.xs[m + 64 + lane]; q1[3] = ws.y[m + 64 + lane]; q1[4] = ws.cut[m + 64 + lane]; }
       wave_sync();
-      // ---- C
-      // (only the round's lines that reach a point: a third of a typical list is kept
-      // at all, and a wave's 64 points see fewer still; a line's range comes from the
-      // registers of its phase-A lane, so a point no line reaches reads nothing from LDS)
-      for (unsigned long long live = __ballot(n > 0); live; live &= live - 1) {
-        const int t = __builtin_ctzll(live);
-        const unsigned k = (unsigned)(lane - __builtin_amdgcn_readlane(first, t));
-        if (k < (unsigned)__builtin_amdgcn_readlane(n, t))
-          acc = add_rounded(acc, ws.val[__builtin_amdgcn_readlane(offv, t) + k]);
+      if (h0) { ws.nu0[lane] = q0[0]; ws.amp[lane] = q0[1]; ws.xs[lane] = q0[2]; ws.y[lane] = q0[3]; ws.cut[lane] = q0[4]; }
+      if (h1) { ws.nu0[64 + lane] = q1[0]; ws.amp[64 + lane] = q1[1]; ws.xs[64 + lane] = q1[2]; ws.y[64 + lane] = q1[3]; ws.cut[64 + lane] = q1[4]; }
+      wave_sync();
+      pending = rem;
+    }
+  };
+  for (int g = g_lo; g < g_hi; g++) {
+    long j0, j1;
+    double cmax;
+    line_window(d, sv, g, nu_a, nu_b, j0, j1, cmax);
+    const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
+    for (long base = j0; base < j1; base += 64) {
+      // ---- A1  lane = line: stage it; the lines above the strength threshold whose cut
+      // reaches the wave's span join the queue (at most 63 wait there)
+      const long j = base + lane;
+      LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
+      if (j < j1) r = stage_line(d, sv, invT, thresh, j);
+      const bool in = r.cut >= 0.0 && r.nu0 + r.cut >= nu_a && r.nu0 - r.cut <= nu_b;
+      const unsigned long long keep = __ballot(in);
+      if (!keep) continue;
+      if (in) {
+        const int pos = pending + __popcll(keep & ((1ull << lane) - 1ull));
+        ws.nu0[pos] = r.nu0; ws.amp[pos] = r.amp; ws.xs[pos] = r.xs; ws.y[pos] = r.y; ws.cut[pos] = r.cut;
       }
+      pending += __popcll(keep);
       wave_sync();
+      rounds(false);
     }
   }
+  rounds(true);
   if (i < a.W) {
     if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + i] = acc;
     else a.out[(size_t)st * a.W + i] = acc;

@@ -217,9 +217,11 @@ class GatherPipeline:
         return self._done
 
     def _issue(self, b):
-        _, fin = allgather_blocks(self.local[b].view(self.G * self.n, self.wl), self.pg, total=self.total,
-                                  async_op=True, out=self.recv[b])
-        self.pending[b] = (fin, self.filled)
+        k = self.filled                  # a partly filled bucket (drain) sends its filled steps only
+        world = self.recv[b].shape[0] // (self.G * self.n)
+        _, fin = allgather_blocks(self.local[b][:k].view(k * self.n, self.wl), self.pg, total=self.total,
+                                  async_op=True, out=self.recv[b][:world * k * self.n])
+        self.pending[b] = (fin, k)
         self.filled = 0
 
     def _finish(self, b):
@@ -227,13 +229,13 @@ class GatherPipeline:
             return None
         fin, k = self.pending[b]
         self.pending[b] = None
-        return fin().view(self.G, self.n, self.total)[:k]
+        return fin().view(k, self.n, self.total)
 
     def drain(self, last_step):
         """After the last submit(last_step): returns the remaining buckets in step order."""
         b = (last_step // self.G) & 1
         if self.filled:
-            self._issue(b)               # a partly filled bucket travels whole; only its filled steps are returned
+            self._issue(b)
         outs = [self._finish(1 - b), self._finish(b)]
         return [o for o in outs if o is not None]
 

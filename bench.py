@@ -266,8 +266,9 @@ def main():
     ap.add_argument("--sweep", default="64,256,1024",
                     help="extra batch sizes reported under batch_sweep (N=1 only; '' = none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--gather-steps", type=int, default=8,
-                    help="N > 1: steps per all-gather bucket (fewer, larger collectives)")
+    ap.add_argument("--gather-steps", type=int, default=4,
+                    help="N > 1: steps per all-gather bucket (fewer, larger collectives; the last bucket's "
+                         "collective is the one nothing overlaps, so a bucket should stay a small part of the run)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)

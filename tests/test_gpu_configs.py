@@ -93,3 +93,42 @@ def test_line_by_line_transit_geometry(tmp_path):
         assert 0.01 < spec.min() < spec.max() < 0.03 and spec.std() > 0
     finally:
         trm.free_memory()
+
+
+def test_every_whitelisted_transit_key_is_accepted(tmp_path):
+    """A transit cfg as code/makecfg.py:36-104 writes it: every key of `known_args` that a
+    BART cfg may carry, `shareOpacity` with no value, both comment styles, wavelength-based
+    sampling.  The keys DESIGN.md section 7 lists as sampling / diagnostic controls of the CPU
+    engine change nothing; the spectrum equals the bare configuration's bit for bit."""
+    from bart_amd import engine, synth, transit_module as trm
+    bare = synth.make_case(str(tmp_path / "bare"), nwave=300, nlayers=30)
+    noeffect = {"radlow": "0", "radhigh": "100", "raddelt": "1", "radfct": "1e5", "allowq": "0.01",
+                "tauiso": "0", "outtau": "0", "taulevel": "1", "modlevel": "1", "verb": "11",
+                "savefiles": "no", "orbpars": "0.05 90 0 0 0 0", "orbparsfct": "1 1 1 1 1 1",
+                "wnfct": "1.0", "shareOpacity": ""}
+    full = synth.make_case(str(tmp_path / "full"), nwave=300, nlayers=30, extra_keys=noeffect)
+    text = open(full.tcfg).read()
+    for k in noeffect:
+        assert ("\n" + k) in ("\n" + text), k
+    with open(full.tcfg, "a") as f:
+        f.write("; a comment line of the other style\n#another\n\n")
+    spectra = []
+    for c in (bare, full):
+        engine.init(c.tcfg)
+        try:
+            spectra.append(trm.run_transit(c.profiles().ravel(), trm.get_no_samples()))
+        finally:
+            trm.free_memory()
+    assert np.array_equal(spectra[0], spectra[1]) and spectra[0].min() > 0
+    # wavelength-based sampling (examples/demo/transit_demo.cfg:17-24) gives the same grid
+    lines = [l for l in open(bare.tcfg).read().split("\n") if l.split(" ")[0] not in ("wnlow", "wnhigh")]
+    wn = bare.wn
+    lines += ["wllow %.17g" % (1e4 / wn[-1]), "wlhigh %.17g" % (1e4 / wn[0]), "wlfct 1e-4"]
+    wl_cfg = str(tmp_path / "wl.cfg")
+    open(wl_cfg, "w").write("\n".join(lines) + "\n")
+    engine.init(wl_cfg)
+    try:
+        assert trm.get_no_samples() == len(wn)
+        np.testing.assert_allclose(trm.get_waveno_arr(len(wn)), wn, rtol=1e-12)
+    finally:
+        trm.free_memory()

@@ -1,0 +1,127 @@
+"""The reference's own per-step loop as the expected value: tests/golden/worker_golden.npz
+holds what code/BARTfunc.py `main(comm)` -- imported from the reference and run unmodified by
+tests/golden/make_worker_golden.py, with stand-ins for mpi4py, MC3's helpers and the RT
+engine (the CPU oracle) -- built and returned on synthetic inputs: the profile arrays it
+handed to run_transit, the setter calls, the band fluxes and -1 rows it gathered, the order
+of its MPI calls.
+
+CPU: the numpy restatement the device kernels are held to (oracle/pyhalf.py) reproduces
+them (rows a3, a4, a8 of SURVEY.md 8 pinned to the reference's code path, not to a
+restatement of it).  GPU: the product's worker returns the same band fluxes with the HIP
+engine in the oracle's place."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "worker_golden.npz"))
+CASES = ["eclipse_ch4", "eclipse_4mol_cloud_ray", "transit_2mol", "direct_ch4"]
+
+
+def _rebuild(name, tmp_path):
+    from bart_amd import synthcfg
+    spec = json.loads(str(G[name + "_kw"]))
+    kw = dict(spec["kw"])
+    for k in ("opmol", "molfit", "params"):
+        kw[k] = tuple(kw[k])
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), **kw)
+    with open(cfg, "a") as f:
+        for k, v in spec["extra"].items():
+            f.write("%s = %s\n" % (k, v))
+    sol = kw.get("solution", "eclipse")
+    lay = dict(nPT=5, nrad=int(sol == "transit"), ncloud=int("cloudtop" in spec["extra"]),
+               nray=int("scattering" in spec["extra"]), solution=sol)
+    return case, cfg, lay
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_restated_step_equals_the_reference_loop(name, tmp_path):
+    from bart_amd import BARTfunc, hostio
+    from oracle import pyhalf, rt_oracle as orc
+    case, cfg, lay = _rebuild(name, tmp_path)
+    wc = BARTfunc.WorkerConfig.from_cfg(cfg)
+    tep = hostio.TepFile(wc.tep_name)
+    rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+    rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+    mp = float(tep.getvalue("Mp")[0]) * hostio.Mjup
+    ptargs = [rstar, float(tep.getvalue("Ts")[0]), wc.tint, float(tep.getvalue("a")[0]) * hostio.AU,
+              100.0 * hostio.G_NEWTON * mp / rp ** 2]
+    species, press, _, abund = hostio.readatm(wc.atmfile)
+    o = orc.OracleEngine(wc.tconfig)
+    idx0, npts, nif, ist = [], [], [], []
+    if lay["solution"] != "direct":
+        starfl, starwn, _, _ = hostio.readkurucz(wc.kurucz, ptargs[1], float(tep.getvalue("loggstar")[0]))
+    for f in wc.filters:
+        fwn, ftr = hostio.readfilter(f)
+        a, b, ind = hostio.resample(o.wn, fwn, ftr, *((starwn, starfl) if lay["solution"] != "direct" else (fwn, ftr)))
+        idx0.append(ind[0][0]); npts.append(len(ind[0])); nif.append(a); ist.append(b)
+    pars, band, acc = G[name + "_params"], G[name + "_band"], list(G[name + "_accepted"])
+    nextra = lay["nrad"] + lay["ncloud"] + lay["nray"]
+    calls, j = [], 0
+    assert 0 < len(acc) < len(pars)
+    for i, par in enumerate(pars):
+        core = np.concatenate([par[:5], par[5 + nextra:]])
+        prof, st = pyhalf.step_profiles(core, press, abund, species, wc.molfit, ptargs, wc.Tmin, wc.Tmax)
+        rejected = bool(np.all(band[i] == -1.0))
+        assert (st != 0) == rejected == (i not in acc), (i, st)
+        if rejected:
+            continue
+        # the profile array the reference handed to run_transit: abundances to the bit
+        # (same operations), temperatures to the accuracy pyhalf's T(p) is pinned at
+        ref_prof = G[name + "_profiles"][j].reshape(prof.shape)
+        np.testing.assert_array_equal(prof[1:], ref_prof[1:])
+        np.testing.assert_allclose(prof[0], ref_prof[0], rtol=1e-13)
+        # setters in the reference's order (BARTfunc.py:350-360), then the engine, then the bands
+        if lay["nrad"]:
+            o.set_radius(par[5]); calls.append(("set_radius", j, par[5], 0.0))
+        if lay["ncloud"]:
+            o.set_cloudtop(par[5 + lay["nrad"]]); calls.append(("set_cloudtop", j, par[5 + lay["nrad"]], 0.0))
+        if lay["nray"]:
+            o.set_scattering(1, par[5 + lay["nrad"] + lay["ncloud"]])
+            calls.append(("set_scattering", j, 1.0, par[5 + lay["nrad"] + lay["ncloud"]]))
+        spec = o.run(prof)
+        np.testing.assert_allclose(spec, G[name + "_spectra"][j], rtol=1e-11)
+        sol = "eclipse" if lay["solution"] == "eclipse" else "direct"    # transit bands are plain filter means too
+        got = pyhalf.bandflux(spec, o.wn, idx0, npts, np.concatenate(nif),
+                              np.concatenate(ist) if ist[0] is not None else None, rp / rstar, sol)
+        np.testing.assert_allclose(got, band[i], rtol=1e-11)
+        j += 1
+    assert j == len(acc)
+    names = [c for c in G[name + "_call_names"] if c != "free_memory"]
+    assert names == [c[0] for c in calls]
+    if calls:
+        np.testing.assert_array_equal(G[name + "_calls"], np.array([[c[1], c[2], c[3]] for c in calls]))
+    # MC3's protocol as the reference speaks it: one broadcast, scatter / gather per step,
+    # the scatter that brings the end flag, disconnect
+    assert list(G[name + "_log"]) == ["bcast"] + ["scatter", "gather"] * len(pars) + ["scatter", "disconnect"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_worker_equals_the_reference_loop(name, tmp_path):
+    """The product's worker (HIP engine) on the same inputs and parameter vectors: the band
+    fluxes the reference's loop gathered -- 1e-9 on the accepted steps (the spectra inside the
+    golden run are the CPU oracle's), the -1 rows where it rejected -- one walker at a time as
+    the reference runs, and all steps as one batch; and the MPI calls in the same order."""
+    from bart_amd import BARTfunc
+    from test_worker import FakeIntercomm
+    case, cfg, lay = _rebuild(name, tmp_path)
+    pars, band = G[name + "_params"], G[name + "_band"]
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        batch = w.step(pars)
+        single = np.array([w.step(p)[0] for p in pars])
+    finally:
+        w.close()
+    rej = np.all(band == -1.0, axis=1)
+    for got in (batch, single):
+        assert np.array_equal(got[rej], band[rej])
+        np.testing.assert_allclose(got[~rej], band[~rej], rtol=1e-9)
+    comm = FakeIntercomm(list(pars))
+    BARTfunc.main(comm, ["BARTfunc.py", "-c", cfg])
+    got = np.array(comm.received)
+    assert np.array_equal(got[rej], band[rej])
+    np.testing.assert_allclose(got[~rej], band[~rej], rtol=1e-9)
+    log = [x for x in comm.log if x != "barrier"]
+    assert log == [x for x in G[name + "_log"] if x != "disconnect"] and comm.disconnected

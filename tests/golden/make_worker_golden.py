@@ -237,6 +237,36 @@ def main():
         out[name + "_call_names"] = np.array([c[0] for c in trm.calls])
         out[name + "_log"] = np.array(master.log)
         print(name, "steps", len(pars), "accepted", len(accepted), "band0", band[accepted[0]][:3])
+    # ------------------------------------------------------------ the transit cfg as makecfg writes it
+    # code/makecfg.py makeTransit(cfile, tepfile, shareOpacity): BART cfg + TEP -> the file
+    # `transit -c` reads.  Its text is stored with the input directory replaced by @DIR@.
+    import makecfg
+    d = tempfile.mkdtemp(prefix="wg_cfg_")
+    case, cfg = synthcfg.make_worker_case(d, nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",),
+                                          nfilters=3, cia=2)
+    tkeys = dict(case.keys)
+    bart = os.path.join(d, "BART_full.cfg")
+    with open(bart, "w") as f:
+        f.write("".join(l for l in open(cfg) if l.split("=")[0].strip() not in ("tconfig", "solution")))
+        f.write("tconfig = %s\n" % os.path.join(d, "made_transit.cfg"))
+        f.write("molfile = %s\n" % tkeys["molfile"])
+        f.write("csfile = " + "\n         ".join(str(tkeys["csfile"]).split(",")) + "\n")
+        f.write("linedb = %s\n         %s\n" % (os.path.join(d, "a.tli"), os.path.join(d, "b.tli")))
+        f.write("opacityfile = %s\n" % tkeys["opacityfile"])
+        for k in ("wnlow", "wnhigh", "wndelt", "wnfct", "wnosamp", "tlow", "thigh", "tempdelt", "toomuch",
+                  "refpress", "nwidth"):
+            f.write("%s = %s\n" % (k, tkeys[k]))
+        f.write("raygrid = %s\n" % " ".join(str(x) for x in tkeys["raygrid"]))
+        f.write("solution = direct\nverb = 11\nsavefiles = no\nallowq = 0.01\n")
+        f.write("outspec = %s\n" % os.path.join(d, "out_spectrum.dat"))
+        f.write("# keys makeTransit does not know must not reach the file:\nburnin = 10\nwalk = snooker\n")
+    tepf = os.path.join(d, "planet.tep")
+    makecfg.makeTransit(bart, tepf, True)
+    text = open(os.path.join(d, "made_transit.cfg")).read().replace(d, "@DIR@")
+    out["makecfg_transit_text"] = np.array(text)
+    out["makecfg_case_kw"] = np.array(json.dumps(dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=["CH4"],
+                                                      molfit=["CH4"], nfilters=3, cia=2)))
+    print(text)
     np.savez_compressed(os.path.join(HERE, "worker_golden.npz"), **out)
     print("written", os.path.join(HERE, "worker_golden.npz"))
 

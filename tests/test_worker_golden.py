@@ -125,3 +125,48 @@ def test_worker_equals_the_reference_loop(name, tmp_path):
     np.testing.assert_allclose(got[~rej], band[~rej], rtol=1e-9)
     log = [x for x in comm.log if x != "barrier"]
     assert log == [x for x in G[name + "_log"] if x != "disconnect"] and comm.disconnected
+
+
+def _makecfg_case(tmp_path):
+    from bart_amd import synthcfg
+    kw = json.loads(str(G["makecfg_case_kw"]))
+    for k in ("opmol", "molfit"):
+        kw[k] = tuple(kw[k])
+    case, _ = synthcfg.make_worker_case(str(tmp_path), **kw)
+    tcfg = os.path.join(str(tmp_path), "made_transit.cfg")
+    open(tcfg, "w").write(str(G["makecfg_transit_text"]).replace("@DIR@", str(tmp_path)))
+    return case, tcfg
+
+
+def test_transit_cfg_written_by_makecfg_is_read(tmp_path):
+    """The text code/makecfg.py `makeTransit` wrote for a BART cfg (two csfile lines joined
+    by a comma, one `linedb` line per TLI, refradius / gsurf from the TEP file, `direct`
+    mapped to eclipse, a bare `shareOpacity`, none of the sampler's keys), through the
+    oracle's reader; the engine's reader sees the same file in the GPU test below."""
+    from oracle import rt_oracle as orc
+    case, tcfg = _makecfg_case(tmp_path)
+    k = orc.read_tcfg(tcfg)
+    d = str(tmp_path)
+    assert k["csfile"] == "%s/CIA_H2H2.dat,%s/CIA_H2He.dat" % (d, d)
+    assert k["linedb"] == "%s/a.tli,%s/b.tli" % (d, d)
+    assert k["solution"] == "eclipse" and k["refradius"] == "96514.20" and k["gsurf"] == "897.7"
+    assert "shareOpacity" in k and "burnin" not in k and "walk" not in k and "params" not in k
+    o = orc.OracleEngine(tcfg)
+    assert len(o.wn) == 200 and o.wn[0] == 2500.0 and o.wn[-1] == 2699.0
+
+
+@pytest.mark.gpu
+def test_engine_runs_the_cfg_makecfg_wrote(tmp_path):
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    case, tcfg = _makecfg_case(tmp_path)
+    prof = case.profiles()
+    engine.init(tcfg)
+    try:
+        n = trm.get_no_samples()
+        assert n == 200
+        spec = trm.run_transit(prof.ravel(), n)
+    finally:
+        trm.free_memory()
+    ref = orc.OracleEngine(tcfg).run(prof)
+    np.testing.assert_allclose(spec, ref, rtol=1e-10)

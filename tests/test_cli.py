@@ -110,3 +110,51 @@ def test_c_host_on_the_c_abi(tmp_path):
         assert np.array_equal(trm.run_transit(prof.ravel(), 500), got[:, 1])
     finally:
         trm.free_memory()
+
+
+REF_CODE = "/root/reference/code"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CODE), reason="reference code not on this box")
+def test_reference_readers_on_product_files():
+    """The reference's OWN readers -- code/readtransit.py `readspectrum` (bestFit.py:578-586
+    reads the best-fit spectrum with it) and code/cf.py `readTauDat` (the contribution
+    functions' input) -- imported and run on files the product's `transit` executable wrote on
+    an MI355X (tests/golden/cli_outputs/, tools/make_cli_fixture.py), against the same
+    quantities taken from the library's API in the same run (expected.npz).  matplotlib
+    (imported by both modules for their plots) is stubbed where it is not installed."""
+    import sys
+    import types
+    G = os.path.join(ROOT, "tests", "golden", "cli_outputs")
+    exp = np.load(os.path.join(G, "expected.npz"))
+    np.float, np.int = float, int                        # cf.py:89 uses np.float
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        mpl = types.ModuleType("matplotlib")
+        mpl.use = lambda *a, **k: None
+        for sub in ("pyplot", "gridspec"):
+            m = types.ModuleType("matplotlib." + sub)
+            setattr(mpl, sub, m)
+            sys.modules["matplotlib." + sub] = m
+        sys.modules["matplotlib"] = mpl
+    sys.path.insert(0, REF_CODE)
+    try:
+        import cf
+        import readtransit
+        wn, spec = readtransit.readspectrum(os.path.join(G, "spec.dat"), wn=True)
+        tau, wns = cf.readTauDat(os.path.join(G, "tau.dat"), int(exp["nlayers"]))
+        _, inten = readtransit.readspectrum(os.path.join(G, "intens.dat"), wn=True)
+    finally:
+        sys.path.remove(REF_CODE)
+    np.testing.assert_allclose(wn, exp["wn"], rtol=1e-8)
+    np.testing.assert_allclose(spec, exp["spectrum"], rtol=2e-9)          # 9 significant digits on file
+    assert tau.shape == (int(exp["nlayers"]), len(exp["wn"]))
+    np.testing.assert_allclose(wns, exp["wn"], rtol=1e-8)
+    np.testing.assert_allclose(tau.T, exp["tau"], rtol=2e-9, atol=1e-300)
+    assert inten.shape == spec.shape and np.all(inten > 0)
+    # and the restated parsing rules the GPU tests use agree with the reference's readers
+    wn2, spec2 = read_spectrum(os.path.join(G, "spec.dat"))
+    tau2, wns2 = read_tau_dat(os.path.join(G, "tau.dat"), int(exp["nlayers"]))
+    assert np.array_equal(wn2, wn) and np.array_equal(spec2, spec)
+    assert np.array_equal(tau2, tau) and np.array_equal(wns2, wns)

@@ -194,6 +194,20 @@ CASES = {
                          extra={}),
     "direct_ch4": dict(kw=dict(nwave=260, wnlow=2600.0, nlayers=24, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                                solution="direct", params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={}),
+    # PT_NoInversion raises ValueError for some draws; the loop logs it and goes on with the
+    # temperature array as the previous step left it (BARTfunc.py:318-330)
+    "eclipse_madhu_valueerror": dict(
+        kw=dict(nwave=300, wnlow=2500.0, nlayers=26, opmol=("CH4",), molfit=("CH4",), nfilters=4,
+                params=(0.5, 0.5, 1e-3, 1.0, 1500.0, -0.5)),
+        extra={}, pttype="madhu_noinv",
+        seq=[[0.05, 0.5, 1e-3, 1.0, 1500.0, 0.6],     # T0 < 0 on the very first step: the zeros stay
+             [0.5, 0.5, 1e-3, 1.0, 1500.0, -0.5],
+             [0.05, 0.5, 1e-3, 1.0, 1500.0, 0.6],     # carried profile, new abundance
+             [0.6, 0.4, 3e-3, 2.0, 1700.0, 0.2],
+             [0.5, 0.02, 1e-3, 1.0, 1500.0, -1.0],    # T1 < 0
+             [0.6, 0.4, 3e-3, 2.0, 3400.0, 0.0],      # a valid model above Tmax: rejected ...
+             [0.05, 0.5, 1e-3, 1.0, 1500.0, 0.6],     # ... and carried into this failing step
+             [0.5, 0.5, 1e-3, 1.0, 1500.0, -0.5]]),
 }
 
 
@@ -213,12 +227,18 @@ def main():
             with open(cfg, "a") as f:
                 for k, v in spec["extra"].items():
                     f.write("%s = %s\n" % (k, v))
+        if "pttype" in spec:
+            text = open(cfg).read().replace("PTtype = line", "PTtype = " + spec["pttype"])
+            open(cfg, "w").write(text)
         base = np.array(spec["kw"]["params"], float)
         nPT = 5
-        lo = np.where(np.abs(base) > 1e3, base * 0.98, base - 0.6)
-        hi = np.where(np.abs(base) > 1e3, base * 1.02, base + 0.6)
-        lo[3], hi[3] = 0.0, 1.0
-        pars = param_sets(rng, base, lo, hi, 5, nPT)
+        if "seq" in spec:
+            pars = [np.array(q, float) for q in spec["seq"]]
+        else:
+            lo = np.where(np.abs(base) > 1e3, base * 0.98, base - 0.6)
+            hi = np.where(np.abs(base) > 1e3, base * 1.02, base + 0.6)
+            lo[3], hi[3] = 0.0, 1.0
+            pars = param_sets(rng, base, lo, hi, 5, nPT)
         trm.eng, trm.calls, trm.profiles, trm.spectra = None, [], [], []
         master = Master(pars)
         sys.argv = ["BARTfunc.py", "-c", cfg]
@@ -226,8 +246,10 @@ def main():
         band = np.array(master.gathered)
         assert len(band) == len(pars) and master.log[-1] == "disconnect"
         accepted = np.array([i for i, b in enumerate(band) if not np.all(b == -1.0)])
-        assert len(accepted) == len(trm.profiles) == len(pars) - 3     # hot, cold and heavy are rejected
-        out[name + "_kw"] = np.array(json.dumps({"kw": kw, "extra": spec["extra"]}))
+        assert len(accepted) == len(trm.profiles)
+        if "seq" not in spec:
+            assert len(accepted) == len(pars) - 3                       # hot, cold and heavy are rejected
+        out[name + "_kw"] = np.array(json.dumps({"kw": kw, "extra": spec["extra"], "pttype": spec.get("pttype", "line")}))
         out[name + "_params"] = np.array(pars)
         out[name + "_band"] = band
         out[name + "_accepted"] = accepted

@@ -29,6 +29,9 @@ def _rebuild(name, tmp_path):
     with open(cfg, "a") as f:
         for k, v in spec["extra"].items():
             f.write("%s = %s\n" % (k, v))
+    if spec.get("pttype", "line") != "line":
+        text = open(cfg).read().replace("PTtype = line", "PTtype = " + spec["pttype"])
+        open(cfg, "w").write(text)
     sol = kw.get("solution", "eclipse")
     lay = dict(nPT=5, nrad=int(sol == "transit"), ncloud=int("cloudtop" in spec["extra"]),
                nray=int("scattering" in spec["extra"]), solution=sol)
@@ -170,3 +173,84 @@ def test_engine_runs_the_cfg_makecfg_wrote(tmp_path):
         trm.free_memory()
     ref = orc.OracleEngine(tcfg).run(prof)
     np.testing.assert_allclose(spec, ref, rtol=1e-10)
+
+
+CARRY = "eclipse_madhu_valueerror"
+
+
+def test_valueerror_steps_of_the_reference_loop(tmp_path):
+    """BARTfunc.py:318-330 as the reference ran it: PT_NoInversion raises ValueError on four of
+    the eight steps, the loop goes on with the temperature array the previous step left (zeros
+    on the very first step -> rejected; a too-hot rejected profile carried into the next
+    failing step -> rejected again; otherwise the old temperatures with the NEW abundances).
+    The restated loop reproduces its profile arrays and band fluxes."""
+    from bart_amd import BARTfunc, hostio
+    from oracle import pyhalf, rt_oracle as orc
+    case, cfg, lay = _rebuild(CARRY, tmp_path)
+    wc = BARTfunc.WorkerConfig.from_cfg(cfg)
+    assert wc.PTtype == "madhu_noinv"
+    tep = hostio.TepFile(wc.tep_name)
+    rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+    rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+    species, press, _, abund = hostio.readatm(wc.atmfile)
+    o = orc.OracleEngine(wc.tconfig)
+    starfl, starwn, _, _ = hostio.readkurucz(wc.kurucz, float(tep.getvalue("Ts")[0]),
+                                             float(tep.getvalue("loggstar")[0]))
+    idx0, npts, nif, ist = [], [], [], []
+    for f in wc.filters:
+        a, b, ind = hostio.resample(o.wn, *hostio.readfilter(f), starwn, starfl)
+        idx0.append(ind[0][0]); npts.append(len(ind[0])); nif.append(a); ist.append(b)
+    sp = list(species)
+    ih2, ihe, ich4 = sp.index("H2"), sp.index("He"), sp.index("CH4")
+    ratio = abund[:, ih2] / abund[:, ihe]
+    imetals = [i for i, x in enumerate(sp) if x not in ("He", "H2", "H-", "e-")]
+    pars, band = G[CARRY + "_params"], G[CARRY + "_band"]
+    assert [bool(np.all(b == -1)) for b in band] == [True, False, False, False, False, True, True, False]
+    tprofile, j = np.zeros(len(press)), 0
+    for i, par in enumerate(pars):
+        try:
+            tprofile[:] = pyhalf.pt_noinversion(np.asarray(press)[::-1], *par[:5])[::-1]
+        except ValueError:
+            pass
+        if np.any(tprofile < wc.Tmin) or np.any(tprofile > wc.Tmax):
+            assert np.all(band[i] == -1)
+            continue
+        prof = np.zeros((len(sp) + 1, len(press)))
+        prof[0], prof[1:] = tprofile, abund.T
+        prof[1 + ich4] = abund[:, ich4] * 10.0 ** par[5]
+        q = 1.0 - prof[1:][imetals].sum(axis=0)
+        assert not np.any(q < 0)
+        prof[1 + ih2], prof[1 + ihe] = ratio * q / (1 + ratio), q / (1 + ratio)
+        ref_prof = G[CARRY + "_profiles"][j].reshape(prof.shape)
+        np.testing.assert_array_equal(prof[1:], ref_prof[1:])
+        np.testing.assert_allclose(prof[0], ref_prof[0], rtol=1e-13)
+        got = pyhalf.bandflux(o.run(prof), o.wn, idx0, npts, np.concatenate(nif), np.concatenate(ist), rp / rstar)
+        np.testing.assert_allclose(got, band[i], rtol=1e-11)
+        j += 1
+    assert j == len(G[CARRY + "_accepted"]) == 5
+    assert not np.allclose(band[1], band[2])               # the carried profile met a new abundance
+
+
+@pytest.mark.gpu
+def test_worker_carries_the_profile_like_the_reference_loop(tmp_path, monkeypatch):
+    """The product's one-chain worker with BARTRT_CARRY_PROFILE=1 (bartrt_step_set_carry): the
+    -1 / band-flux sequence the reference's loop returned on the ValueError case; without the
+    switch those steps are rejected."""
+    from bart_amd import BARTfunc
+    from test_worker import FakeIntercomm
+    case, cfg, lay = _rebuild(CARRY, tmp_path)
+    pars, band = G[CARRY + "_params"], G[CARRY + "_band"]
+    rej = np.all(band == -1.0, axis=1)
+    monkeypatch.setenv("BARTRT_CARRY_PROFILE", "1")
+    comm = FakeIntercomm(list(pars))
+    BARTfunc.main(comm, ["-c", cfg])
+    got = np.array(comm.received)
+    assert np.array_equal(got[rej], band[rej])
+    np.testing.assert_allclose(got[~rej], band[~rej], rtol=1e-9)
+    monkeypatch.delenv("BARTRT_CARRY_PROFILE")
+    comm = FakeIntercomm(list(pars))
+    BARTfunc.main(comm, ["-c", cfg])
+    got = np.array(comm.received)
+    raises = [0, 2, 4, 6]                                   # the steps whose model raises
+    assert np.all(got[raises] == -1.0)
+    np.testing.assert_allclose(got[[1, 3, 7]], band[[1, 3, 7]], rtol=1e-9)

@@ -41,12 +41,14 @@ def write_filters(outdir: str, wl_lo_um: float, wl_hi_um: float, n: int = 10, np
 
 def make_worker_case(outdir: str, nwave=2501, wnlow=2500.0, opmol=("CH4",), molfit=("CH4",),
                      params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5), nfilters=10, solution="eclipse",
-                     ebalance=False, **case_kw):
+                     ebalance=False, tep=None, **case_kw):
     """Engine inputs (synth.make_case) + TEP + filters + star + MCMC cfg.
-    Defaults mirror examples/demo/BART_eclipse.cfg (CH4, 2-4 um, 10 filters)."""
+    Defaults mirror examples/demo/BART_eclipse.cfg (CH4, 2-4 um, 10 filters);
+    `tep`: the TEP file's values (default HD209458B above)."""
     case = synth.make_case(outdir, nwave=nwave, wnlow=wnlow, opmol=opmol, **case_kw)
+    tep_values = tep
     tep = os.path.join(outdir, "planet.tep")
-    write_tep(tep)
+    write_tep(tep, tep_values)
     star = os.path.join(outdir, "star.pck")
     synth.blackbody_kurucz(star)
     wl_hi = 1e4 / (case.wn[0] + 2.0)

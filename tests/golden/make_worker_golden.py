@@ -194,6 +194,12 @@ CASES = {
                          extra={}),
     "direct_ch4": dict(kw=dict(nwave=260, wnlow=2600.0, nlayers=24, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                                solution="direct", params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={}),
+    # energy balance (BARTfunc.py:365-382): a self-luminous planet (tint 800 K) on a wide orbit --
+    # the TEP file's semi-major axis is chosen by the generator so that some of the steps emit
+    # more than they receive
+    "eclipse_ebalance": dict(kw=dict(nwave=420, wnlow=1500.0, wndelt=4.0, nlayers=26, opmol=("CH4",), molfit=("CH4",),
+                                     nfilters=3, ebalance=True, params=(-3.5, 0.0, 1.0, 0.0, 0.98, -0.5)),
+                             extra={"tint": "800.0"}, sma_scan=(0.3, 0.35, 0.38, 0.4, 0.42, 0.45, 0.5, 0.6)),
     # PT_NoInversion raises ValueError for some draws; the loop logs it and goes on with the
     # temperature array as the previous step left it (BARTfunc.py:318-330)
     "eclipse_madhu_valueerror": dict(
@@ -232,7 +238,30 @@ def main():
             open(cfg, "w").write(text)
         base = np.array(spec["kw"]["params"], float)
         nPT = 5
-        if "seq" in spec:
+        if "sma_scan" in spec:
+            # parameter draws that stay inside [Tmin, Tmax]; the orbit decides who fails the balance
+            pars = [base] + [base + rng.normal(0, [0.3, 0.2, 0.2, 0.05, 0.05, 0.3]) for _ in range(7)]
+            for q in pars:
+                q[3] = min(max(q[3], 0.0), 1.0)
+            chosen = None
+            for sma in spec["sma_scan"]:
+                tepv = dict(synthcfg.HD209458B, a=sma)
+                synthcfg.write_tep(os.path.join(d, "planet.tep"), tepv)
+                trm.eng, trm.calls, trm.profiles, trm.spectra = None, [], [], []
+                master = Master(pars)
+                sys.argv = ["BARTfunc.py", "-c", cfg]
+                ref_worker.main(master)
+                nrej = int(sum(np.all(b == -1.0) for b in master.gathered))
+                print("  sma", sma, "rejected", nrej, "of", len(pars), "run_transit calls", len(trm.profiles))
+                if 0 < nrej < len(pars) and len(trm.profiles) == len(pars):
+                    # every step reached the engine; the balance rejected some: keep the most even split
+                    if chosen is None or abs(nrej - len(pars) / 2) < chosen[1]:
+                        chosen = (sma, abs(nrej - len(pars) / 2))
+            assert chosen is not None
+            tepv = dict(synthcfg.HD209458B, a=chosen[0])
+            synthcfg.write_tep(os.path.join(d, "planet.tep"), tepv)
+            kw["tep"] = tepv
+        elif "seq" in spec:
             pars = [np.array(q, float) for q in spec["seq"]]
         else:
             lo = np.where(np.abs(base) > 1e3, base * 0.98, base - 0.6)
@@ -246,8 +275,11 @@ def main():
         band = np.array(master.gathered)
         assert len(band) == len(pars) and master.log[-1] == "disconnect"
         accepted = np.array([i for i, b in enumerate(band) if not np.all(b == -1.0)])
-        assert len(accepted) == len(trm.profiles)
-        if "seq" not in spec:
+        if "sma_scan" in spec:
+            assert len(trm.profiles) == len(pars) > len(accepted) > 0     # rejected AFTER the engine ran
+        else:
+            assert len(accepted) == len(trm.profiles)
+        if "seq" not in spec and "sma_scan" not in spec:
             assert len(accepted) == len(pars) - 3                       # hot, cold and heavy are rejected
         out[name + "_kw"] = np.array(json.dumps({"kw": kw, "extra": spec["extra"], "pttype": spec.get("pttype", "line")}))
         out[name + "_params"] = np.array(pars)

@@ -25,7 +25,7 @@ def _rebuild(name, tmp_path):
     kw = dict(spec["kw"])
     for k in ("opmol", "molfit", "params"):
         kw[k] = tuple(kw[k])
-    case, cfg = synthcfg.make_worker_case(str(tmp_path), **kw)
+    case, cfg = synthcfg.make_worker_case(str(tmp_path), **kw)      # (kw may carry the TEP file's values)
     with open(cfg, "a") as f:
         for k, v in spec["extra"].items():
             f.write("%s = %s\n" % (k, v))
@@ -254,3 +254,73 @@ def test_worker_carries_the_profile_like_the_reference_loop(tmp_path, monkeypatc
     raises = [0, 2, 4, 6]                                   # the steps whose model raises
     assert np.all(got[raises] == -1.0)
     np.testing.assert_allclose(got[[1, 3, 7]], band[[1, 3, 7]], rtol=1e-9)
+
+
+EBAL = "eclipse_ebalance"
+
+
+def _ebalance_expected(tmp_path):
+    """The restated step with the energy-balance branch of BARTfunc.py:365-382."""
+    from bart_amd import BARTfunc, hostio
+    from oracle import pyhalf, rt_oracle as orc
+    case, cfg, lay = _rebuild(EBAL, tmp_path)
+    wc = BARTfunc.WorkerConfig.from_cfg(cfg)
+    assert wc.ebalance and wc.tint == 800.0
+    tep = hostio.TepFile(wc.tep_name)
+    tstar = float(tep.getvalue("Ts")[0])
+    rstar = float(tep.getvalue("Rs")[0]) * hostio.Rsun
+    sma = float(tep.getvalue("a")[0]) * hostio.AU
+    rp = float(tep.getvalue("Rp")[0]) * hostio.Rjup
+    mp = float(tep.getvalue("Mp")[0]) * hostio.Mjup
+    ptargs = [rstar, tstar, wc.tint, sma, 100.0 * hostio.G_NEWTON * mp / rp ** 2]
+    species, press, _, abund = hostio.readatm(wc.atmfile)
+    o = orc.OracleEngine(wc.tconfig)
+    starfl, starwn, _, _ = hostio.readkurucz(wc.kurucz, tstar, float(tep.getvalue("loggstar")[0]))
+    idx0, npts, nif, ist = [], [], [], []
+    for f in wc.filters:
+        a, b, ind = hostio.resample(o.wn, *hostio.readfilter(f), starwn, starfl)
+        idx0.append(ind[0][0]); npts.append(len(ind[0])); nif.append(a); ist.append(b)
+    e_in = hostio.sig * tstar ** 4 * rstar ** 2 * np.pi * rp ** 2 / sma ** 2 * 1e7
+    want, margin = [], []
+    for i, par in enumerate(G[EBAL + "_params"]):
+        prof, st = pyhalf.step_profiles(par, press, abund, species, wc.molfit, ptargs, wc.Tmin, wc.Tmax)
+        assert st == 0                                       # every step reaches the engine
+        ref_prof = G[EBAL + "_profiles"][i].reshape(prof.shape)
+        np.testing.assert_array_equal(prof[1:], ref_prof[1:])
+        np.testing.assert_allclose(prof[0], ref_prof[0], rtol=1e-13)
+        spec = o.run(prof)
+        e_out = pyhalf.energy_out(spec, o.wn, rp)
+        margin.append(abs(e_out / e_in - 1))
+        want.append(-np.ones(len(idx0)) if e_out > e_in else
+                    pyhalf.bandflux(spec, o.wn, idx0, npts, np.concatenate(nif), np.concatenate(ist), rp / rstar))
+    return cfg, np.array(want), min(margin)
+
+
+def test_energy_balance_steps_of_the_reference_loop(tmp_path):
+    """Five of the eight steps emit more in the modelled band than the planet receives and
+    are answered with -1 AFTER the engine ran (the loop made eight run_transit calls)."""
+    cfg, want, margin = _ebalance_expected(tmp_path)
+    band = G[EBAL + "_band"]
+    rej = np.all(band == -1.0, axis=1)
+    assert rej.sum() == 5 and len(G[EBAL + "_profiles"]) == 8 and margin > 1e-6
+    assert np.array_equal(np.all(want == -1.0, axis=1), rej)
+    np.testing.assert_allclose(want[~rej], band[~rej], rtol=1e-11)
+
+
+@pytest.mark.gpu
+def test_worker_energy_balance_like_the_reference_loop(tmp_path):
+    from bart_amd import BARTfunc
+    from test_worker import FakeIntercomm
+    case, cfg, lay = _rebuild(EBAL, tmp_path)
+    pars, band = G[EBAL + "_params"], G[EBAL + "_band"]
+    rej = np.all(band == -1.0, axis=1)
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        batch = w.step(pars)
+    finally:
+        w.close()
+    comm = FakeIntercomm(list(pars))
+    BARTfunc.main(comm, ["-c", cfg])
+    for got in (batch, np.array(comm.received)):
+        assert np.array_equal(got[rej], band[rej])
+        np.testing.assert_allclose(got[~rej], band[~rej], rtol=1e-9)

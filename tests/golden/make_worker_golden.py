@@ -194,6 +194,25 @@ CASES = {
                          extra={}),
     "direct_ch4": dict(kw=dict(nwave=260, wnlow=2600.0, nlayers=24, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                                solution="direct", params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={}),
+    # the other temperature models through the loop (nPT = 1, 6, 3, 8 parameters in front of the molecule's)
+    "pt_iso": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
+                           params=(1500.0, -0.5)), extra={}, pttype="iso",
+                   seq=[[1500.0, -0.5], [900.0, 0.3], [350.0, 0.0], [2999.0, -1.0], [3100.0, 0.0]]),
+    "pt_madhu_inv": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
+                                 params=(0.4, 0.3, 0.005, 0.1, 2.0, 1600.0, -0.5)), extra={}, pttype="madhu_inv",
+                         seq=[[0.4, 0.3, 0.005, 0.1, 2.0, 1600.0, -0.5], [0.55, 0.45, 0.002, 0.3, 5.0, 1550.0, 0.2],
+                              [0.3, 0.2, 0.008, 0.05, 1.0, 1650.0, -1.0], [0.4, 0.3, 0.005, 0.1, 2.0, 3300.0, 0.0]]),
+    "pt_adiabatic": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
+                                 params=(2800.0, 1.4, 2.5, -0.5)), extra={}, pttype="adiabatic",
+                         seq=[[2800.0, 1.4, 2.5, -0.5], [2500.0, 1.2, 2.3, 0.2], [2900.0, 1.3, 3.0, -1.0],
+                              [1500.0, 1.4, 0.0, 0.0]]),
+    "pt_piette": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
+                              params=(1500.0, 100.0, 100.0, 100.0, 100.0, 100.0, 100.0, 100.0, -0.5)), extra={},
+                      pttype="piette",
+                      seq=[[1500.0, 100.0, 100.0, 100.0, 100.0, 100.0, 100.0, 100.0, -0.5],
+                           [1300.0, 250.0, 30.0, 120.0, 10.0, 80.0, 200.0, 5.0, 0.3],
+                           [1900.0, 20.0, 280.0, 60.0, 150.0, 0.0, 90.0, 40.0, -1.0],
+                           [1200.0, 300.0, 300.0, 300.0, 300.0, 300.0, 300.0, 300.0, 0.0]]),
     # energy balance (BARTfunc.py:365-382): a self-luminous planet (tint 800 K) on a wide orbit --
     # the TEP file's semi-major axis is chosen by the generator so that some of the steps emit
     # more than they receive

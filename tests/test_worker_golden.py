@@ -16,7 +16,9 @@ import numpy as np
 import pytest
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "worker_golden.npz"))
-CASES = ["eclipse_ch4", "eclipse_4mol_cloud_ray", "transit_2mol", "direct_ch4"]
+CASES = ["eclipse_ch4", "eclipse_4mol_cloud_ray", "transit_2mol", "direct_ch4",
+         "pt_iso", "pt_madhu_inv", "pt_adiabatic", "pt_piette"]          # the loop's six temperature models
+NPT = {"line": 5, "iso": 1, "madhu_noinv": 5, "madhu_inv": 6, "adiabatic": 3, "piette": 8}
 
 
 def _rebuild(name, tmp_path):
@@ -33,8 +35,8 @@ def _rebuild(name, tmp_path):
         text = open(cfg).read().replace("PTtype = line", "PTtype = " + spec["pttype"])
         open(cfg, "w").write(text)
     sol = kw.get("solution", "eclipse")
-    lay = dict(nPT=5, nrad=int(sol == "transit"), ncloud=int("cloudtop" in spec["extra"]),
-               nray=int("scattering" in spec["extra"]), solution=sol)
+    lay = dict(nPT=NPT[spec.get("pttype", "line")], nrad=int(sol == "transit"), ncloud=int("cloudtop" in spec["extra"]),
+               nray=int("scattering" in spec["extra"]), solution=sol, pttype=spec.get("pttype", "line"))
     return case, cfg, lay
 
 
@@ -62,10 +64,12 @@ def test_restated_step_equals_the_reference_loop(name, tmp_path):
     pars, band, acc = G[name + "_params"], G[name + "_band"], list(G[name + "_accepted"])
     nextra = lay["nrad"] + lay["ncloud"] + lay["nray"]
     calls, j = [], 0
-    assert 0 < len(acc) < len(pars)
+    n = lay["nPT"]
+    assert 0 < len(acc) < len(pars) and wc.PTtype == lay["pttype"]
     for i, par in enumerate(pars):
-        core = np.concatenate([par[:5], par[5 + nextra:]])
-        prof, st = pyhalf.step_profiles(core, press, abund, species, wc.molfit, ptargs, wc.Tmin, wc.Tmax)
+        core = np.concatenate([par[:n], par[n + nextra:]])
+        prof, st = pyhalf.step_profiles(core, press, abund, species, wc.molfit, ptargs if lay["pttype"] == "line" else (),
+                                        wc.Tmin, wc.Tmax, pttype=lay["pttype"])
         rejected = bool(np.all(band[i] == -1.0))
         assert (st != 0) == rejected == (i not in acc), (i, st)
         if rejected:
@@ -77,12 +81,12 @@ def test_restated_step_equals_the_reference_loop(name, tmp_path):
         np.testing.assert_allclose(prof[0], ref_prof[0], rtol=1e-13)
         # setters in the reference's order (BARTfunc.py:350-360), then the engine, then the bands
         if lay["nrad"]:
-            o.set_radius(par[5]); calls.append(("set_radius", j, par[5], 0.0))
+            o.set_radius(par[n]); calls.append(("set_radius", j, par[n], 0.0))
         if lay["ncloud"]:
-            o.set_cloudtop(par[5 + lay["nrad"]]); calls.append(("set_cloudtop", j, par[5 + lay["nrad"]], 0.0))
+            o.set_cloudtop(par[n + lay["nrad"]]); calls.append(("set_cloudtop", j, par[n + lay["nrad"]], 0.0))
         if lay["nray"]:
-            o.set_scattering(1, par[5 + lay["nrad"] + lay["ncloud"]])
-            calls.append(("set_scattering", j, 1.0, par[5 + lay["nrad"] + lay["ncloud"]]))
+            o.set_scattering(1, par[n + lay["nrad"] + lay["ncloud"]])
+            calls.append(("set_scattering", j, 1.0, par[n + lay["nrad"] + lay["ncloud"]]))
         spec = o.run(prof)
         np.testing.assert_allclose(spec, G[name + "_spectra"][j], rtol=1e-11)
         sol = "eclipse" if lay["solution"] == "eclipse" else "direct"    # transit bands are plain filter means too

@@ -194,6 +194,9 @@ CASES = {
                          extra={}),
     "direct_ch4": dict(kw=dict(nwave=260, wnlow=2600.0, nlayers=24, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                                solution="direct", params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={}),
+    # internal temperature from the Thorngren et al. relation instead of the `tint` constant (PT.py PT_line)
+    "eclipse_thorngren": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
+                                      params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={"tint_type": "thorngren"}),
     # the other temperature models through the loop (nPT = 1, 6, 3, 8 parameters in front of the molecule's)
     "pt_iso": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                            params=(1500.0, -0.5)), extra={}, pttype="iso",
@@ -241,8 +244,9 @@ def main():
     install(trm)
     import BARTfunc as ref_worker          # the reference's code/BARTfunc.py, as it is
     out = {}
-    rng = np.random.default_rng(20260110)
+    import zlib
     for name, spec in CASES.items():
+        rng = np.random.default_rng([20260110, zlib.crc32(name.encode())])   # a case's draws do not depend on the others
         d = tempfile.mkdtemp(prefix="wg_")
         kw = dict(spec["kw"])
         if kw.get("solution") == "transit":

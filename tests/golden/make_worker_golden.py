@@ -194,6 +194,9 @@ CASES = {
                          extra={}),
     "direct_ch4": dict(kw=dict(nwave=260, wnlow=2600.0, nlayers=24, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                                solution="direct", params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={}),
+    # `scattering = polar`: the parameter slot is consumed, the engine gets flag 2 (BARTfunc.py:356-360)
+    "eclipse_polar": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
+                                  params=(-2.0, 0.0, 1.0, 0.0, 0.98, 0.0, -0.5)), extra={"scattering": "polar"}),
     # internal temperature from the Thorngren et al. relation instead of the `tint` constant (PT.py PT_line)
     "eclipse_thorngren": dict(kw=dict(nwave=200, wnlow=2500.0, nlayers=20, opmol=("CH4",), molfit=("CH4",), nfilters=3,
                                       params=(-2.0, 0.0, 1.0, 0.0, 0.98, -0.5)), extra={"tint_type": "thorngren"}),

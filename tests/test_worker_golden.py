@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "worker_golden.npz"))
-CASES = ["eclipse_ch4", "eclipse_4mol_cloud_ray", "transit_2mol", "direct_ch4", "eclipse_thorngren",
+CASES = ["eclipse_ch4", "eclipse_4mol_cloud_ray", "transit_2mol", "direct_ch4", "eclipse_thorngren", "eclipse_polar",
          "pt_iso", "pt_madhu_inv", "pt_adiabatic", "pt_piette"]          # the loop's six temperature models
 NPT = {"line": 5, "iso": 1, "madhu_noinv": 5, "madhu_inv": 6, "adiabatic": 3, "piette": 8}
 
@@ -84,7 +84,9 @@ def test_restated_step_equals_the_reference_loop(name, tmp_path):
             o.set_radius(par[n]); calls.append(("set_radius", j, par[n], 0.0))
         if lay["ncloud"]:
             o.set_cloudtop(par[n + lay["nrad"]]); calls.append(("set_cloudtop", j, par[n + lay["nrad"]], 0.0))
-        if lay["nray"]:
+        if lay["nray"] and "polar" in wc.scattering:
+            o.set_scattering(2, 0.0); calls.append(("set_scattering", j, 2.0, 0.0))
+        elif lay["nray"]:
             o.set_scattering(1, par[n + lay["nrad"] + lay["ncloud"]])
             calls.append(("set_scattering", j, 1.0, par[n + lay["nrad"] + lay["ncloud"]]))
         spec = o.run(prof)

@@ -7,7 +7,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 log="$out/misc_bench.log"
 : > "$log"
-for t in step_bench worker_step_latency retrieval_rate latency_demo opacity_gen_bench; do
+for t in step_bench worker_step_latency retrieval_rate latency_demo opacity_gen_bench pcie_rate; do
   echo "== $t" >> "$log"
   timeout 600 python3 tools/$t.py 2>/dev/null | grep '^{' >> "$log"
 done

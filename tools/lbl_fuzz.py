@@ -33,7 +33,7 @@ def run_case(s):
     kw = draw(rng)
     kw["pbottom"] = min(kw["pbottom"], 300.0)
     rule = "full" if (kw["wnosamp"] in (2, 6) and rng.integers(0, 2)) else "divisor"
-    nsh = int(rng.integers(2, 5))
+    nsh = min(int(rng.integers(2, 5)), kw["nwave"])       # a shard without samples is refused by the engine
     prev = os.environ.get("BARTRT_OSAMP_RULE")
     os.environ["BARTRT_OSAMP_RULE"] = rule
     try:

@@ -293,9 +293,14 @@ int bartrt_voigt(const double *x, const double *y, double *k, long n) {
   });
 }
 
-int bartrt_timing_begin(void) {
+int bartrt_timing_begin(void) { return bartrt_timing_begin_sampled(1); }
+
+int bartrt_timing_begin_sampled(int stride) {
   NEED_ENGINE();
+  if (stride < 1) return fail(BARTRT_EINVAL, "timing_begin_sampled: stride must be >= 1");
   g_eng->timing = true;
+  g_eng->timing_stride = stride;
+  g_eng->timing_seen = 0;
   g_eng->ev_used = 0;
   return BARTRT_OK;
 }

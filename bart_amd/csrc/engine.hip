@@ -521,7 +521,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.rtop = d_rtop; r.ds = d_ds;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
   r.transparent = transparent ? 1 : 0;
-  if (timing) {
+  const bool timed = timing && (timing_seen++ % timing_stride == 0);
+  if (timed) {
     while ((int)ev.size() < ev_used + 2) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
@@ -546,7 +547,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   if (lbl_fused) lbl_rt_eclipse(*this, d_prof_in, n, r, st);
   else if (solution == 1) HIPCHK(launch_transit(r, st));
   else HIPCHK(launch_rt(r, block, st, want_walked ? &walked_info : nullptr));
-  if (timing) {
+  if (timed) {
     HIPCHK(hipEventRecord(ev[ev_used + 1], st));
     ev_used += 2;
   }

@@ -80,6 +80,8 @@ struct Engine {
   RtLaunchInfo walked_info{};
   // timing of RT launches
   bool timing = false;
+  int timing_stride = 1;     // events bracket every timing_stride-th launch (a pair of event
+  long timing_seen = 0;      // records costs the stream ~5 us: bench.py samples)
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
   // per-step converters

@@ -317,8 +317,9 @@ def step_batch_sharded(d_params, nfilters, group=None, stream=None):
     return band, status, spec
 
 
-def timing_begin():
-    _check(trm.lib().bartrt_timing_begin())
+def timing_begin(stride: int = 1):
+    """HIP events around every `stride`-th RT launch until timing_end()."""
+    _check(trm.lib().bartrt_timing_begin_sampled(int(stride)))
 
 
 def timing_end():

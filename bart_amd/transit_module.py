@@ -83,6 +83,7 @@ def lib():
         L.bartrt_get_lbl_extinction.argtypes = [p, i, p, i, i]
         L.bartrt_voigt.argtypes = [p, p, p, C.c_long]
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
+        L.bartrt_timing_begin_sampled.argtypes = [i]
         L.bartrt_set_integ.argtypes = [i]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
         L.bartrt_algorithmic_bytes.argtypes = [i]

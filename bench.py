@@ -234,7 +234,7 @@ class StubEngine:
         d_spec.copy_(self.expected(d_prof, self.lo, self.hi))
         return d_spec
 
-    def timing_begin(self):
+    def timing_begin(self, stride=1):
         pass
 
     def timing_end(self):
@@ -266,6 +266,9 @@ def main():
     ap.add_argument("--sweep", default="64,256,1024",
                     help="extra batch sizes reported under batch_sweep (N=1 only; '' = none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP events bracket every n-th RT launch of the timed region (a pair of event records "
+                         "costs the stream about 5 us, 7 %% of a ten-walker step; 1 = every launch)")
     ap.add_argument("--gather-steps", type=int, default=4,
                     help="N > 1: steps per all-gather bucket (fewer, larger collectives; the last bucket's "
                          "collective is the one nothing overlaps, so a bucket should stay a small part of the run)")
@@ -394,7 +397,7 @@ def main():
             dist.barrier()
         sync()
         if record:
-            engine.timing_begin()
+            engine.timing_begin(a.event_stride)
         t0 = time.perf_counter()
         for i in range(steps):
             o = step(i)
@@ -519,7 +522,7 @@ def main():
                 "unique_bytes_per_launch": uniq,
                 "effective_bytes_per_launch": eff,
                 "layers_walked_frac": wfrac,
-                "kernel": kname, "launches": nlaunch, "avg_launch_ms": per_launch_s * 1e3,
+                "kernel": kname, "launches": nlaunch, "event_stride": a.event_stride, "avg_launch_ms": per_launch_s * 1e3,
                 # SURVEY 8d's per-spectrum figure x walkers: no credit for rows shared between the
                 # walkers of a launch or for layers below the cut, so it is NOT bounded by the HBM
                 # peak (the shared rows are served by L2) -- kept as a labelled throughput figure

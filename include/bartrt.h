@@ -201,6 +201,10 @@ int bartrt_voigt(const double *x, const double *y, double *k, long n);
 /* HIP-event timing of the RT kernel launches (bench.py's roofline leg).
  * begin resets; end returns accumulated device ms and launch count. */
 int bartrt_timing_begin(void);
+/* the same with events around every stride-th launch only: a pair of event records costs
+ * the stream about 5 us, 7 % of a ten-walker step; end returns the sampled launches' sum
+ * and their count */
+int bartrt_timing_begin_sampled(int stride);
 int bartrt_timing_end(double *kernel_ms, int *nlaunch);
 /* Diagnostics for the byte model of bench.py: between begin and end every eclipse
  * launch records how many layers each wave walked before all its lanes passed

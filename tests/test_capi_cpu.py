@@ -137,3 +137,13 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("PT oracle", ""), os.path.join(dirpath, f)
+
+
+def test_generated_coefficient_tables_are_reproducible():
+    """csrc/voigt_coef.hpp is what tools/gen_voigt_coef.py produces (Weideman's FFT recipe)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_voigt_coef.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max |recipe - header| = 0.0" in r.stdout

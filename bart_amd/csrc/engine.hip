@@ -521,14 +521,19 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.rtop = d_rtop; r.ds = d_ds;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
   r.transparent = transparent ? 1 : 0;
+  // Timing: the RT kernel's own dispatch stamps the two events (BARTRT_RT_LAUNCH) -- no marker
+  // packets in the stream; only the fused line-by-line path (several kernels) is bracketed
+  // by event records.
   const bool timed = timing && (timing_seen++ % timing_stride == 0);
+  r.ev_start = r.ev_stop = nullptr;
   if (timed) {
     while ((int)ev.size() < ev_used + 2) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
       ev.push_back(e);
     }
-    HIPCHK(hipEventRecord(ev[ev_used], st));
+    if (lbl_fused) HIPCHK(hipEventRecord(ev[ev_used], st));
+    else { r.ev_start = ev[ev_used]; r.ev_stop = ev[ev_used + 1]; }
   }
   r.walked_out = nullptr;
   if (want_walked && solution == 0 && !lbl_fused) {
@@ -548,7 +553,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   else if (solution == 1) HIPCHK(launch_transit(r, st));
   else HIPCHK(launch_rt(r, block, st, want_walked ? &walked_info : nullptr));
   if (timed) {
-    HIPCHK(hipEventRecord(ev[ev_used + 1], st));
+    if (lbl_fused) HIPCHK(hipEventRecord(ev[ev_used + 1], st));
     ev_used += 2;
   }
 }

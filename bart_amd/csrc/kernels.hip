@@ -194,7 +194,7 @@ static hipError_t launch_rt_t(const RtArgs &a, int block, int nblocks, hipStream
     if (e != hipSuccess) return e;
     allowed = sh;
   }
-  hipLaunchKernelGGL((rt_eclipse<AT, -1, -1, INTEG>), dim3(nblocks), dim3(block), sh, st, a);
+  BARTRT_RT_LAUNCH((rt_eclipse<AT, -1, -1, INTEG>), dim3(nblocks), dim3(block), sh, st, a);
   return hipGetLastError();
 }
 

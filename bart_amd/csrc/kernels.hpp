@@ -1,11 +1,17 @@
 // Device-side argument blocks shared by the kernels and the host engine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 // (molecules, CIA pairs) the specialised kernels are instantiated for
 #define BARTRT_MC_LIST(X) \
   X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) \
   X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2) X(7, 1) X(7, 2) X(8, 1) X(8, 2)
+
+// Every launch of an RT kernel goes through this: the kernel's own dispatch carries the timing
+// events of RtArgs (null: a plain launch).
+#define BARTRT_RT_LAUNCH(kernel, grid, block, sh, st, args) \
+  hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(sh), st, (args).ev_start, (args).ev_stop, 0, args)
 
 namespace bartrt {
 
@@ -180,6 +186,9 @@ struct RtArgs {
   const double *rtop, *ds;
   double inv_starrad2;
   int transparent;         // transit geometry: no opaque core below the last chord (cfg `transparent`)
+  // host side only (BARTRT_RT_LAUNCH): events the dispatch of the RT kernel itself stamps with its
+  // start and end, or null -- timing without marker packets in the stream (bartrt_timing_*)
+  hipEvent_t ev_start, ev_stop;
 };
 
 // What launch_rt launched (diagnostics; the byte model of bench.py)

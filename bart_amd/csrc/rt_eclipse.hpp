@@ -696,11 +696,11 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
 #define BARTRT_QUAD(MM, CC)                                                                                          \
   if (a.M == MM && a.C == CC) {                                                                                      \
     if (octo) {                                                                                                      \
-      if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, SQOK, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
-      else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, SQOK, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
     } else {                                                                                                         \
-      if (sq) hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, SQOK, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
-      else hipLaunchKernelGGL((rt_eclipse_quad<5, MM, CC, false, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, SQOK, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
     }                                                                                                                \
     err = hipGetLastError();                                                                                         \
     return true;                                                                                                     \
@@ -714,8 +714,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     if (info) { info->kernel = "rt_eclipse_split"; info->wn_per_column = 64; info->ncolumns = b.ntiles; }
 #define BARTRT_SPLIT(MM, CC)                                                                                       \
   if (a.M == MM && a.C == CC) {                                                                                    \
-    if (sq) hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC, SQOK, INTEG>), dim3(nb64), dim3(128), shs, st, b);     \
-    else hipLaunchKernelGGL((rt_eclipse_split<5, MM, CC, false, INTEG>), dim3(nb64), dim3(128), shs, st, b);       \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_split<5, MM, CC, SQOK, INTEG>), dim3(nb64), dim3(128), shs, st, b);     \
+    else BARTRT_RT_LAUNCH((rt_eclipse_split<5, MM, CC, false, INTEG>), dim3(nb64), dim3(128), shs, st, b);       \
     err = hipGetLastError();                                                                                       \
     return true;                                                                                                   \
   }
@@ -730,8 +730,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
 #define BARTRT_FAST(MM, CC)                                                                                        \
   if (a.M == MM && a.C == CC) {                                                                                    \
-    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks), dim3(block), sh, st, b);  \
-    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, false, INTEG>), dim3(nblocks), dim3(block), sh, st, b);    \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks), dim3(block), sh, st, b);  \
+    else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, INTEG>), dim3(nblocks), dim3(block), sh, st, b);    \
     err = hipGetLastError();                                                                                       \
     return true;                                                                                                   \
   }

@@ -9,8 +9,8 @@ namespace bartrt {
 bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
 #define BARTRT_FAST_ILP(MM, CC)                                                                                    \
   if (b.M == MM && b.C == CC) {                                                                                    \
-    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, true, 0, 1>), dim3(nblocks), dim3(block), sh, st, b);   \
-    else hipLaunchKernelGGL((rt_eclipse_fast<5, MM, CC, false, 0, 1>), dim3(nblocks), dim3(block), sh, st, b);     \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, true, 0, 1>), dim3(nblocks), dim3(block), sh, st, b);   \
+    else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, 0, 1>), dim3(nblocks), dim3(block), sh, st, b);     \
     err = hipGetLastError();                                                                                       \
     return true;                                                                                                   \
   }
@@ -22,8 +22,8 @@ bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t
 bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
 #define BARTRT_FAST_EXT(CC)                                                                                           \
   if (b.M == 0 && b.C == CC) {                                                                                        \
-    if (sq) hipLaunchKernelGGL((rt_eclipse_fast<5, 0, CC, true, 0, 1, true>), dim3(nblocks), dim3(block), sh, st, b);  \
-    else hipLaunchKernelGGL((rt_eclipse_fast<5, 0, CC, false, 0, 1, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, 0, CC, true, 0, 1, true>), dim3(nblocks), dim3(block), sh, st, b);  \
+    else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, 0, CC, false, 0, 1, true>), dim3(nblocks), dim3(block), sh, st, b);    \
     err = hipGetLastError();                                                                                          \
     return true;                                                                                                      \
   }

@@ -307,9 +307,9 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
 #define BARTRT_TRANSIT(MM, CC)                                                              \
   if (a.M == MM && a.C == CC) {                                                             \
     if (a.L <= 16 * kMfmaTiles)                                                             \
-      hipLaunchKernelGGL((rt_transit_mfma<MM, CC, kMfmaTiles>), dim3(nb), dim3(256), shm, st, b); \
+      BARTRT_RT_LAUNCH((rt_transit_mfma<MM, CC, kMfmaTiles>), dim3(nb), dim3(256), shm, st, b); \
     else                                                                                    \
-      hipLaunchKernelGGL((rt_transit_mfma<MM, CC, kMfmaTilesDeep>), dim3(nb), dim3(256), shm, st, b); \
+      BARTRT_RT_LAUNCH((rt_transit_mfma<MM, CC, kMfmaTilesDeep>), dim3(nb), dim3(256), shm, st, b); \
     return hipGetLastError();                                                               \
   }
     BARTRT_MC_LIST(BARTRT_TRANSIT)
@@ -319,11 +319,11 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   if (sh <= 160 * 1024) {
     hipError_t e = allow_lds(rt_transit<true>, sh, allowed);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rt_transit<true>, dim3(nblocks), dim3(64), sh, st, a);
+    BARTRT_RT_LAUNCH(rt_transit<true>, dim3(nblocks), dim3(64), sh, st, a);
   } else {
     hipError_t e = allow_lds(rt_transit<false>, sh_pairs, allowed_pairs);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rt_transit<false>, dim3(nblocks), dim3(64), sh_pairs, st, a);
+    BARTRT_RT_LAUNCH(rt_transit<false>, dim3(nblocks), dim3(64), sh_pairs, st, a);
   }
   return hipGetLastError();
 }

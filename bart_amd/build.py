@@ -10,15 +10,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
-SOURCES = ["rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "lbl.hip",
+SOURCES = ["rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
            "transit_geom.hip",
            "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "io.cpp"]   # longest first
-HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
+HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
 
 
 # per-file compiler options (see the comment on rt_eclipse_fast in csrc/rt_eclipse.hpp)
-EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               "rt_eclipse_i1_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc() -> str:

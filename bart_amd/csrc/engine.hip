@@ -386,6 +386,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     double sl = std::sin(lo_a * kPI / 180.0), sh = std::sin(hi_a * kPI / 180.0);
     r.wgt[a] = kPI * (sh * sh - sl * sl);
     r.invmu[a] = 1.0 / std::cos(angles[a] * kPI / 180.0);
+    r.wq[a] = r.wgt[a] * r.invmu[a];
   }
   if (!have_table && cfg_has(cfg, "linedb")) {
     lbl_init(*this, cfg["linedb"]);

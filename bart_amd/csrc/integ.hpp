@@ -151,26 +151,20 @@ struct ColumnIntens<kIntegTrapzTau, AMAX> {
   }
 };
 
-// Flux-only accumulator of the kernels that do not return per-angle intensities
-// (single-wave, producer/consumer, quad-layer).  Rule 0 is linear in the
-// transmittances, so the angle quadrature can be taken BEFORE the layer sum:
-//   F = sum_a w_a sum_k hb_k (E_{a,k-1} - E_{a,k}) = sum_k hb_k (G_{k-1} - G_k),
-//   G_k = sum_a w_a E_{a,k}
+// Flux-only accumulators of the kernels that do not return per-angle intensities
+// (single-wave, producer/consumer, quad-layer).  Every rule is linear in the
+// transmittances E_{a,k} = exp(-tau_k / mu_a) with weights that do not depend on the
+// ray angle, so the angle quadrature is taken BEFORE the layer sum:
+//   rule 0   F = sum_a w_a sum_k hb_k (E_{a,k-1} - E_{a,k}) = sum_k hb_k (G_{k-1} - G_k),
+//            G_k = sum_a w_a E_{a,k};
+//   rules 1 / 2   I_a = (1/mu_a) sum_k W_k(tau) B_k E_{a,k}  (W_k: the Simpson-hybrid or
+//            trapezoid weights of the tau grid)  =>  F = sum_k W_k Y_k,
+//            Y_k = B_k sum_a (w_a / mu_a) E_{a,k}   (RtArgs::wq = w_a / mu_a)
 // -- one running sum and one previous value instead of A of each (16 VGPRs and a
 // few operations less per layer; in the quad-layer kernel one value crosses the lane
-// rows instead of A).  The other rules delegate to ColumnIntens.
+// rows instead of A).
 template <int INTEG, int AMAX>
-struct ColumnFlux {
-  ColumnIntens<INTEG, AMAX> ci;
-  __device__ __forceinline__ explicit ColumnFlux(const RtArgs &) {}
-  __device__ __forceinline__ void layer(const RtArgs &, int A, bool live, double lv, double tau, double Bprev,
-                                        double B, const double (&E)[AMAX]) {
-    ci.layer(A, live, lv, tau, Bprev, B, E);
-  }
-  __device__ __forceinline__ double flux(const RtArgs &p, int A, bool deck, double Bprev, int L) {
-    return ci.flux(p, A, deck, Bprev, L, nullptr);
-  }
-};
+struct ColumnFlux;
 
 // G = sum_a w_a E_a
 template <int AMAX>
@@ -270,6 +264,81 @@ struct ColumnIntens<kIntegSimpson, AMAX> {
       if (out) out[a] = Ia;
     }
     return F;
+  }
+};
+
+// sum_a (w_a / mu_a) E_a
+template <int AMAX>
+__device__ __forceinline__ double angle_sum_q(const RtArgs &p, const double (&E)[AMAX]) {
+  double g = p.wq[0] * E[0];
+#pragma unroll
+  for (int a = 1; a < AMAX; a++) g = fma(p.wq[a], E[a], g);
+  return g;
+}
+
+// Rule 2, angle quadrature first: plain trapezoid of Y in tau.
+template <int AMAX>
+struct ColumnFlux<kIntegTrapzTau, AMAX> {
+  double F = 0.0, y1 = 0.0, x1 = 0.0, ydeck = 0.0;
+  __device__ __forceinline__ explicit ColumnFlux(const RtArgs &) {}
+  __device__ __forceinline__ void layer(const RtArgs &p, int, bool live, double lv, double tau, double, double B,
+                                        const double (&E)[AMAX]) {
+    const double y = B * angle_sum_q<AMAX>(p, E);
+    F = fma(y1 + y, (tau - x1) * lv, F);
+    y1 = live ? y : y1;
+    x1 = live ? tau : x1;
+    if (p.cloud_on) {   // wave-uniform: the surface term wants sum_a w_a B E_a of the last layer
+      const double yd = B * angle_sum<AMAX>(p, E);
+      ydeck = live ? yd : ydeck;
+    }
+  }
+  __device__ __forceinline__ double flux(const RtArgs &, int, bool deck, double, int) {
+    return deck ? F + ydeck : F;
+  }
+};
+
+// Rule 1, angle quadrature first, with the scalar restatement's case analysis (zero-width
+// panels, padded point) spelled out per point: the accumulator of the producer / consumer
+// kernel and of the careful path rt_eclipse_simpson falls back to.  The tuned walk of the
+// single-wave kernel is in rt_eclipse_s1.hpp.
+template <int AMAX>
+struct ColumnFlux<kIntegSimpson, AMAX> {
+  // points so far (n), the last two abscissae and integrands, the running sums of the
+  // panels that end on an even / odd point index (P1 starts with the trapezoid of the
+  // first interval)
+  double P0 = 0.0, P1 = 0.0, y1 = 0.0, y2 = 0.0, x1 = 0.0, x2 = 0.0, ydeck = 0.0;
+  int n = 0;
+  __device__ __forceinline__ explicit ColumnFlux(const RtArgs &) {}
+  __device__ __forceinline__ void point(bool live, double x, double y) {
+    const double h0 = x1 - x2, h1 = x - x1;
+    double w0, w1, w2;
+    simpson_tau_weights(h0, h1, w0, w1, w2);
+    const bool second = n == 1, odd = (n & 1) != 0;
+    w0 = second ? 0.0 : w0;          // the second point closes the first interval: a trapezoid into P1
+    w1 = second ? 0.5 * h1 : w1;
+    w2 = second ? 0.5 * h1 : w2;
+    const double c = fma(w0, y2, fma(w1, y1, w2 * y));
+    P0 += (live && n >= 2 && !odd) ? c : 0.0;
+    P1 += (live && n >= 1 && odd) ? c : 0.0;
+    y2 = live ? y1 : y2;
+    y1 = live ? y : y1;
+    x2 = live ? x1 : x2;
+    x1 = live ? x : x1;
+    n += live ? 1 : 0;
+  }
+  __device__ __forceinline__ void layer(const RtArgs &p, int, bool live, double, double tau, double, double B,
+                                        const double (&E)[AMAX]) {
+    point(live, tau, B * angle_sum_q<AMAX>(p, E));
+    if (p.cloud_on) {
+      const double yd = B * angle_sum<AMAX>(p, E);
+      ydeck = live ? yd : ydeck;
+    }
+  }
+  __device__ __forceinline__ double flux(const RtArgs &, int, bool deck, double, int L) {
+    // one padded point (integrand 0, one unit of tau further) while a layer exists below
+    point(!deck && n < L, x1 + 1.0, 0.0);
+    const double F = ((n - 1) & 1) ? P1 : P0;   // parity of the last point's index
+    return deck ? F + ydeck : F;
   }
 };
 

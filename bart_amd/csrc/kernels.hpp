@@ -177,6 +177,7 @@ struct RtArgs {
   double toomuch;
   double invmu[kMaxAngles];
   double wgt[kMaxAngles];  // pi (sin^2 hi - sin^2 lo)
+  double wq[kMaxAngles];   // wgt[a] * invmu[a]: the angle quadrature of rules 1 / 2 taken before the layer sum
   double *spec;            // [nw][W]
   double *tau_out;         // optional [W][L] (single walker), may be null
   int *last_out;           // optional [W]

@@ -54,10 +54,11 @@ __device__ inline void block_to_work(int b, int nwalkers, int &tile, int &walker
   tile = (j / nwalkers) * 8 + xcd;
 }
 
-// LDS beyond the layer records: rule 1 keeps the Simpson weights of the radius grid
+// LDS beyond the layer records: rule 1 keeps the Simpson weights of the radius grid (three
+// words per layer in the producer / consumer and quad-layer kernels, four in rt_eclipse_simpson)
 template <int INTEG>
 __host__ __device__ inline size_t integ_lds_doubles(int L) {
-  return INTEG == kIntegSimpson ? simpson_lds_doubles(L) : 0;
+  return INTEG == kIntegSimpson ? 4 * (size_t)(L + kSimpsonPad) : 0;
 }
 
 // Specialised kernel: compile-time angle / molecule / CIA counts, scalar row
@@ -377,7 +378,6 @@ void rt_eclipse_split(RtArgs p) {
 // rows' radius panels plus, on odd rows, the trapezoid of the last interval.
 template <int AT, int MT, int CT, bool SQ, int R, int INTEG>
 __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
-  static_assert(!(SQ && INTEG != kIntegTransmittance), "the squared-transmittance shortcut is built for rule 0 only");
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
@@ -437,9 +437,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   const int from_below = (lane + 64 - WN) & 63;       // row q - 1 (the last row for row 0)
   const int from_below2 = (lane + 64 - 2 * WN) & 63;  // row q - 2 (rule 1)
 
-  double I[A];
-#pragma unroll
-  for (int a = 0; a < A; a++) I[a] = 0.0;
+  double I = 0.0;   // this lane's layers' terms, angle quadrature taken (ColumnFlux, integ.hpp)
   double Fs = 0.0;  // surface term of a cloud deck (one lane per wavenumber sets it)
   // carries of row 0: extinction, Planck term, transmittances of the layer just
   // above this step (row R - 1 of the previous step), and the optical depth there
@@ -450,9 +448,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   // rule 1: second carries (row R - 2 / R - 1 of the previous step for rows 0 / 1),
   // the running even-index Simpson sum of the optical depth, the index of the last
   // point of the intensity integral and the "next step's row 0 is the padded point" flag
-  double c2_e = 0.0, c2_tau = 0.0, c_y[A], c2_y[A], c_S = 0.0;
-#pragma unroll
-  for (int a = 0; a < A; a++) { c_y[a] = 0.0; c2_y[a] = 0.0; }
+  double c2_e = 0.0, c2_tau = 0.0, c_y = 0.0, c2_y = 0.0, c_S = 0.0;
   int nend = kend;
   bool pad_next = false;
   bool active = true;  // no layer above this step passed `toomuch` (per wavenumber, all rows agree)
@@ -512,6 +508,10 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
     for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
     exp_rt_n<AE + 1>(xs, ex);
     const double B = bnum * rcp_n1(ex[AE] - 1.0);
+    double E[A];
+#pragma unroll
+    for (int a = 0; a < AE; a++) E[a] = ex[a];
+    if (SQ) E[A - 1] = E[0] * E[0];
     if constexpr (INTEG == kIntegTransmittance) {
       // the layer above: row q - 1, or the carry for row 0
       const double B_below = __shfl(B, from_below);
@@ -520,43 +520,30 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
       // rule 0 is linear in the transmittances: the angle quadrature first (ColumnFlux,
       // integ.hpp), so ONE value crosses the lane rows instead of one per ray angle
-      double E[A];
-#pragma unroll
-      for (int a = 0; a < AE; a++) E[a] = ex[a];
-      if (SQ) E[A - 1] = E[0] * E[0];
       const double G = angle_sum<A>(p, E);
       const double G_below = __shfl(G, from_below);
       const double Gprev = q == 0 ? c_G : G_below;
       c_G = G_below;
-      I[0] = fma(hb, Gprev - G, I[0]);
+      I = fma(hb, Gprev - G, I);
       if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) Fs = fma(B, G, Fs);  // deck reached below toomuch
     } else {
-      // integrand of this lane's layer and of the one / two layers above it
+      // rules 1 / 2 are linear in Y = B sum_a (w_a / mu_a) E_a with angle-independent
+      // weights (integ.hpp): ONE integrand per layer crosses the lane rows
       const double tau_b1 = __shfl(tau, from_below);
       const double tau1 = q == 0 ? tau_above_step : tau_b1;
-      double y[A], y1[A];
-#pragma unroll
-      for (int a = 0; a < A; a++) {
-        y[a] = B * ex[a];
-        const double yb = __shfl(y[a], from_below);
-        y1[a] = q == 0 ? c_y[a] : yb;
-        c_y[a] = yb;
-      }
+      const double y = B * angle_sum_q<A>(p, E);
+      const double yb = __shfl(y, from_below);
+      const double y1 = q == 0 ? c_y : yb;
+      c_y = yb;
       if constexpr (INTEG == kIntegTrapzTau) {
-        const double h = (tau - tau1) * (live ? 0.5 : 0.0);
-#pragma unroll
-        for (int a = 0; a < A; a++) I[a] = fma(y1[a] + y[a], h, I[a]);
+        I = fma(y1 + y, (tau - tau1) * (live ? 0.5 : 0.0), I);
       } else {
         const double tau_b2 = __shfl(tau, from_below2);
         const double tau2 = q < 2 ? c2_tau : tau_b2;
         c2_tau = tau_b2;
-        double y2[A];
-#pragma unroll
-        for (int a = 0; a < A; a++) {
-          const double yb2 = __shfl(y[a], from_below2);
-          y2[a] = q < 2 ? c2_y[a] : yb2;
-          c2_y[a] = yb2;
-        }
+        const double yb2 = __shfl(y, from_below2);
+        const double y2 = q < 2 ? c2_y : yb2;
+        c2_y = yb2;
         // the cut: the first row of this wavenumber that passed toomuch
         const unsigned long long mine = over & col_bits;
         const int f = mine ? (int)(__ffsll((long long)mine) - 1) / WN : -1;
@@ -571,16 +558,11 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
         simpson_tau_weights(tau1 - tau2, x - tau1, w0, w1, w2);
         if (j == 1) { w0 = 0.0; w1 = 0.5 * (x - tau1); w2 = w1; }  // the first interval: a trapezoid
         const bool counts = (live || pad) && j >= 1;
-#pragma unroll
-        for (int a = 0; a < A; a++) {
-          const double cterm = fma(w0, y2[a], fma(w1, y1[a], w2 * (pad ? 0.0 : y[a])));
-          I[a] += counts ? cterm : 0.0;
-        }
+        const double cterm = fma(w0, y2, fma(w1, y1, w2 * (pad ? 0.0 : y)));
+        I += counts ? cterm : 0.0;
       }
-      if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) {  // deck reached below toomuch
-#pragma unroll
-        for (int a = 0; a < A; a++) Fs = fma(p.wgt[a], y[a], Fs);
-      }
+      if (p.cloud_on && j == kend && live && !(tau > p.toomuch))   // deck reached below toomuch
+        Fs = fma(B, angle_sum<A>(p, E), Fs);
     }
     active = active && (over & col_bits) == 0ull;
   };
@@ -602,13 +584,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   }
   // the rows of a wavenumber hold its layers' terms: sum them; row 0 writes
   const bool mine_counts = !SIMPSON || ((q & 1) == (nend & 1));
-  double F = Fs;
-  if constexpr (INTEG == kIntegTransmittance) {
-    F += I[0];   // the lane's layers, angle quadrature already taken
-  } else {
-#pragma unroll
-    for (int a = 0; a < A; a++) F = fma(p.wgt[a] * p.invmu[a], mine_counts ? I[a] : 0.0, F);
-  }
+  double F = Fs + (mine_counts ? I : 0.0);   // the lane's layers, angle quadrature already taken
   for (int o = WN; o < 64; o <<= 1) F += __shfl_xor(F, o);
   if (q == 0 && i0 + m < W) p.spec[(size_t)w * W + i0 + m] = F;
   if (p.walked_out && lane == 0) {
@@ -616,6 +592,10 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
     p.walked_out[(size_t)w * (4 * p.ntiles) + tile * 4 + (threadIdx.x >> 6)] = layers;
   }
 }
+
+}  // namespace bartrt
+#include "rt_eclipse_s1.hpp"   // rule 1's single-wave kernel
+namespace bartrt {
 
 // If one ray angle has exactly half the cosine of another (0 and 60 degrees of
 // the usual raygrid 0 20 40 60 80), put that pair first and last: the SQ kernels
@@ -627,6 +607,7 @@ inline bool order_angles_for_square(RtArgs &r) {
       auto swap_angles = [&](int x, int y) {
         std::swap(r.invmu[x], r.invmu[y]);
         std::swap(r.wgt[x], r.wgt[y]);
+        std::swap(r.wq[x], r.wq[y]);
       };
       swap_angles(0, i);
       if (j == 0) j = i;  // the doubled angle sat in slot 0 and moved to i
@@ -658,8 +639,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   const bool plane_ok = 2ull * a.M * a.W * 8ull < (1ull << 31);
   if (a.ext) {
     // line-by-line hand-off: the single-wave kernel with the extinction array as one
-    // more load per layer (rule 0, no table; anything else takes the generic kernel)
-    if (!(INTEG == kIntegTransmittance && a.A == 5 && a.M == 0 && a.C <= 2 && !a.intens_out && !a.tau_out &&
+    // more load per layer (rules 0 and 1, no table; anything else takes the generic kernel)
+    if (!(INTEG != kIntegTrapzTau && a.A == 5 && a.M == 0 && a.C <= 2 && !a.intens_out && !a.tau_out &&
           sh <= 55 * 1024 && kmode != "generic"))
       return false;
     RtArgs b = a;
@@ -667,14 +648,15 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     b.ntiles = a.ntiles;
     if (info) { info->kernel = "rt_eclipse_fast (line-by-line extinction)"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
     err = hipSuccess;
-    if (launch_rt_fast_ext(b, sq, block, nblocks, sh, st, err)) return true;
+    if (INTEG == kIntegSimpson ? launch_rt_simpson_ext(b, sq, block, nblocks, sh, st, err)
+                               : launch_rt_fast_ext(b, sq, block, nblocks, sh, st, err))
+      return true;
     return false;
   }
   if (!(a.A == 5 && !a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
   // (the producer/consumer kernel adds 9 kB of its own)
   RtArgs b = a;
-  // the squared-transmittance shortcut is instantiated for the default rule only
-  const bool sq = INTEG == kIntegTransmittance && allow_sq && order_angles_for_square(b);
+  const bool sq = allow_sq && order_angles_for_square(b);
   // too few single-wave columns to load the 1 024 SIMDs evenly -> several
   // waves per 64 wavenumbers: four 16-wavenumber waves that take four layers at
   // a time (quad-layer), or a producer / consumer pair
@@ -687,7 +669,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   b.window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
   const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, octo ? 8 : 4));
   err = hipSuccess;
-  constexpr bool SQOK = INTEG == kIntegTransmittance;
+  constexpr bool SQOK = true;   // exp(-2 tau / mu) = exp(-tau / mu)^2 under every rule
   if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
     // the smallest launches take eight layers per step (8 wavenumbers per wave)
     b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;
@@ -724,10 +706,19 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
   b.ntiles = a.ntiles;
   if (info) { info->kernel = "rt_eclipse_fast"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
-  if (INTEG == kIntegTransmittance && kmode != "mono_occ" && (kmode == "mono_ilp" || columns < kIlpMaxColumns)) {
-    if (info) info->kernel = "rt_eclipse_fast (ILP-scheduled build)";
-    if (launch_rt_fast_ilp(b, sq, block, nblocks, sh, st, err)) return true;
-  }
+  [[maybe_unused]] const bool ilp = kmode != "mono_occ" && (kmode == "mono_ilp" || columns < kIlpMaxColumns);
+  if constexpr (INTEG == kIntegSimpson) {
+    // rule 1 has its own single-wave kernel (rt_eclipse_s1.hpp), built under the ILP schedule
+    // only: that build is the faster one at every batch size (10 walkers 73 against 80 us,
+    // 64: 333 / 375, 256: 1 138 / 1 220 -- the default schedule needs 182 registers for two
+    // resident waves, or drops the record read-ahead for three and waits on LDS instead)
+    if (info) info->kernel = "rt_eclipse_simpson (ILP-scheduled build)";
+    if (launch_rt_simpson_ilp(b, sq, block, nblocks, sh, st, err)) return true;
+  } else {
+    if (INTEG == kIntegTransmittance && ilp) {
+      if (info) info->kernel = "rt_eclipse_fast (ILP-scheduled build)";
+      if (launch_rt_fast_ilp(b, sq, block, nblocks, sh, st, err)) return true;
+    }
 #define BARTRT_FAST(MM, CC)                                                                                        \
   if (a.M == MM && a.C == CC) {                                                                                    \
     if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks), dim3(block), sh, st, b);  \
@@ -735,8 +726,9 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     err = hipGetLastError();                                                                                       \
     return true;                                                                                                   \
   }
-  BARTRT_MC_LIST(BARTRT_FAST)
+    BARTRT_MC_LIST(BARTRT_FAST)
 #undef BARTRT_FAST
+  }
   return false;
 }
 

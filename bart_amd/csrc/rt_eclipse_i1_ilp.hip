@@ -1,0 +1,36 @@
+// The single-wave eclipse kernel of integration rule 1 (rt_eclipse_simpson, rt_eclipse_s1.hpp)
+// compiled under the compiler's maximum-ILP scheduling strategy (bart_amd/build.py passes
+// -mllvm -amdgpu-sched-strategy=max-ilp for this file only; see rt_eclipse_fast in
+// rt_eclipse.hpp for what that changes and when launch_rt_spec takes this build), and its
+// line-by-line hand-off variant.
+#include "rt_eclipse.hpp"
+
+namespace bartrt {
+
+bool launch_rt_simpson_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+#define BARTRT_S1_ILP(MM, CC)                                                                                      \
+  if (b.M == MM && b.C == CC) {                                                                                    \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson<5, MM, CC, true, 1>), dim3(nblocks), dim3(block), sh, st, b);   \
+    else BARTRT_RT_LAUNCH((rt_eclipse_simpson<5, MM, CC, false, 1>), dim3(nblocks), dim3(block), sh, st, b);     \
+    err = hipGetLastError();                                                                                       \
+    return true;                                                                                                   \
+  }
+  BARTRT_MC_LIST(BARTRT_S1_ILP)
+#undef BARTRT_S1_ILP
+  return false;
+}
+
+bool launch_rt_simpson_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+#define BARTRT_S1_EXT(CC)                                                                                             \
+  if (b.M == 0 && b.C == CC) {                                                                                        \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson<5, 0, CC, true, 1, true>), dim3(nblocks), dim3(block), sh, st, b);  \
+    else BARTRT_RT_LAUNCH((rt_eclipse_simpson<5, 0, CC, false, 1, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+    err = hipGetLastError();                                                                                          \
+    return true;                                                                                                      \
+  }
+  BARTRT_S1_EXT(0) BARTRT_S1_EXT(1) BARTRT_S1_EXT(2)
+#undef BARTRT_S1_EXT
+  return false;
+}
+
+}  // namespace bartrt

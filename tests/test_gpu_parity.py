@@ -240,7 +240,12 @@ def test_cloud_deck_sweep_across_layer_steps(tmp_path, nlayers, integ):
         tops = np.concatenate([np.linspace(lp.min() - 0.5, lp.max() + 0.5, 12), lp[[0, -1, nlayers // 2]]])
         for ct in tops:
             trm.set_cloudtop(float(ct)); o.set_cloudtop(float(ct))
-            np.testing.assert_allclose(engine.run_batch(profs), o.run_batch(profs), rtol=RTOL, atol=1e-300)
+            ref = o.run_batch(profs)
+            # rule 1 on a column of a dozen layers (tau steps >> 1) is a sum of Simpson panels of
+            # both signs, thousands of times the result in places: samples where they cancel are
+            # held to 1e-12 of the spectrum's scale instead of 1e-10 of themselves
+            atol = 1e-12 * np.abs(ref).max() if integ == 1 else 1e-300
+            np.testing.assert_allclose(engine.run_batch(profs), ref, rtol=RTOL, atol=atol)
     finally:
         trm.free_memory()
 

@@ -1,7 +1,7 @@
 """Instruction mix of an RT kernel's layer loop from the gfx950 assembly (no GPU needed).
 usage: python tools/isa_stats.py [--ilp] [--json out.json] [mangled-kernel-substring] > profiles/<tag>_isa_<kernel>.txt
-Compiles csrc/rt_eclipse_i<rule>.hip (the rule follows the SQ flag in the name) -- with --ilp
-csrc/rt_eclipse_i0_ilp.hip under the build's max-ILP scheduling option -- to assembly, takes
+Compiles csrc/rt_eclipse_i<rule>.hip (the rule follows the SQ flag in the name; rt_eclipse_simpson is
+rule 1) -- with --ilp csrc/rt_eclipse_i<rule>_ilp.hip under the build's max-ILP scheduling option -- to assembly, takes
 the largest basic block of the kernel (the straight-line block of four layers) and counts
 instructions by class."""
 import collections
@@ -21,8 +21,8 @@ def main():
     want = pos[0] if pos else ("rt_eclipse_fastILi5ELi4ELi1ELb1ELi0ELi1ELb0E" if ilp
                                else "rt_eclipse_fastILi5ELi4ELi1ELb1ELi0ELi0ELb0E")
     m = re.search(r"Lb[01]ELi(\d)E", want)
-    integ = m.group(1) if m else "0"
-    src = "rt_eclipse_i0_ilp.hip" if ilp else "rt_eclipse_i%s.hip" % integ
+    integ = "1" if "simpson" in want else (m.group(1) if m else "0")   # rule 1's single-wave kernel has its own name
+    src = "rt_eclipse_i%s_ilp.hip" % integ if ilp else "rt_eclipse_i%s.hip" % integ
     extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ilp else []
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")

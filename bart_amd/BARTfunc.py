@@ -127,6 +127,7 @@ class Worker:
         engine.init(cfg.tconfig, shard=shard, device=device)
         self.nwave = trm.get_no_samples()
         self.specwn = trm.get_waveno_arr(self.nwave)
+        self.integ = trm.get_integ()     # logged by main(): runs under different rules are not to be confused
         if engine.species() != self.species or engine.nlayers() != self.nlayers:
             raise ValueError("atmfile of the MCMC configuration and 'atm' of the transit "
                              "configuration describe different atmospheres")
@@ -287,6 +288,9 @@ def main(comm, argv=None, group=None, worker_factory=None, shard_backend="nccl")
         w = make(cfg) if wrank == 0 else None   # the GPU engine lives in worker 0
     if verb and w is not None:
         print("There are {:d} layers and {:d} species.".format(w.nlayers, w.nspecies))
+        if getattr(w, "integ", None) is not None:
+            print("Integration rule of the eclipse geometry: integ {:d} ({})".format(
+                w.integ, ("transmittance", "simpson", "trapz_tau")[w.integ]))
     params = np.zeros(npars, np.double)
     nfilt = np.zeros(1, int)
     if nworkers > 1:

@@ -105,7 +105,12 @@ int bartrt_set_integ(int rule) {
   return BARTRT_OK;
 }
 
-int bartrt_get_integ(void) { NEED_ENGINE(); return g_eng->integ; }
+int bartrt_get_integ(int *rule) {
+  NEED_ENGINE();
+  if (!rule) return fail(BARTRT_EINVAL, "get_integ: null output pointer");
+  *rule = g_eng->integ;
+  return BARTRT_OK;
+}
 
 int bartrt_get_nlayers(void) { NEED_ENGINE(); return g_eng->L; }
 int bartrt_get_nspecies(void) { NEED_ENGINE(); return g_eng->S; }

@@ -142,7 +142,8 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   // engine's own key: the reference's source, which would settle the rule, is
   // absent), overridden by BARTRT_INTEG; number or name
   {
-    std::string v = cfg_has(cfg, "integ") ? cfg["integ"] : "0";
+    // default: rule 1, the integrator SURVEY.md App. A-4 recalls for the reference's engine
+    std::string v = cfg_has(cfg, "integ") ? cfg["integ"] : "1";
     if (const char *ev = std::getenv("BARTRT_INTEG")) if (*ev) v = ev;
     integ = parse_integ(v);
   }

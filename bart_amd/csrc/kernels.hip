@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
   double Bprev = 0.0;
   bool active = true;
   int last = 0;
-  const int kend = p.kstop[w];
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const bool deck_on = kstop_deck(kraw);
   int k = 0;
   for (; k <= kend; ++k) {
     const double *c = sC + k * NC;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
     if (!__any(active)) break;
   }
   double Ia[AMAX];
-  const double F = ci.flux(p, A, p.cloud_on && active, Bprev, L, Ia);
+  const double F = ci.flux(p, A, deck_on && active, Bprev, L, Ia);
   if (p.intens_out && valid) {
     for (int a = 0; a < A; a++) p.intens_out[(size_t)a * W + i] = Ia[a];
   }

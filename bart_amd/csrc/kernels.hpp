@@ -52,6 +52,14 @@ __host__ __device__ inline size_t chord_table_index(int L, int k, int j) {
 // pointer per layer): [0] start of the (layer, lower temperature) plane of the
 // opacity grid, [1+c] start of the (lower, upper) pair plane of CIA table c.
 using idx_t = long long;
+
+// kstop[w] = the deepest layer of walker w's column; bit 30 set: that layer is the top of an
+// opaque cloud deck (it emits as a surface).  A cloud-top pressure below the bottom layer
+// leaves the column as it is: no deck (the bit is per walker: the walkers of a batch may
+// carry their own cloud tops, bartrt_step_set_extras).
+constexpr int kDeckBit = 1 << 30;
+__host__ __device__ inline int kstop_layer(int raw) { return raw & ~kDeckBit; }
+__host__ __device__ inline bool kstop_deck(int raw) { return (raw & kDeckBit) != 0; }
 __host__ __device__ inline int idx_stride(int C) { return 1 + C; }
 
 // Cooperative copy of two arrays of 8-byte words from global memory into LDS.
@@ -149,7 +157,7 @@ struct PrepArgs {
   // outputs
   double *coef;            // [nw][L][coef_stride]
   idx_t *idx;              // [nw][L][idx_stride]
-  int *kstop;              // [nw] deepest layer index k to integrate to
+  int *kstop;              // [nw] deepest layer index k to integrate to (| kDeckBit: see kstop_layer)
   unsigned char *ok;       // [nw]
   double *rad_out;         // optional [nw][L] hydrostatic radii, cm, atm layer order
   // transit geometry only (null otherwise): radii top -> bottom and the chord
@@ -171,8 +179,8 @@ struct RtArgs {
   const double *wn;        // [W]
   const double *coef;
   const idx_t *idx;
-  const int *kstop;
-  int cloud_on;            // kstop marks a cloud deck (adds surface emission)
+  const int *kstop;        // per walker: last layer to integrate to, | kDeckBit when it is a cloud deck
+  int cloud_on;            // some walker of the launch may carry a deck (wave-uniform hint; the deck itself is per walker)
   int integ;               // integration rule of the eclipse geometry (integ.hpp: 0 / 1 / 2)
   double toomuch;
   double invmu[kMaxAngles];

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
   for (int a = 0; a < kMaxAngles; a++) { I[a] = 0.0; fprev[a] = 1.0; }
   double tau = 0.0, eprev = 0.0, Bprev = 0.0;
   bool active = true;
-  const int kend = p.kstop[w];
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
   for (int k = 0; k <= kend; ++k) {
     const int l = L - 1 - k;
     const int st = w * L + l;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
     if (!__syncthreads_or(active ? 1 : 0)) break;
   }
   double F = 0.0;
-  const bool surf = p.cloud_on && active;
+  const bool surf = kstop_deck(kraw) && active;
 #pragma unroll
   for (int a = 0; a < kMaxAngles; a++) {
     if (a >= A) break;

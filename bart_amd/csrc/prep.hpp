@@ -199,7 +199,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     int ks = L - 1;
     if (has_cloud) {
       for (int k = 0; k < L; k++)
-        if (sPress[L - 1 - k] >= cloudtop) { ks = k; break; }
+        if (sPress[L - 1 - k] >= cloudtop) { ks = k | kDeckBit; break; }
     }
     p.kstop[w] = ks;
     if (p.ok) p.ok[w] = bad ? 0 : 1;

@@ -38,7 +38,11 @@ namespace bartrt {
 // i.e. quad-layer while the columns leave SIMDs empty, single-wave while every column
 // finds a SIMD of its own (<= 1 024), the producer/consumer pair for the first columns
 // that have to share one, single-wave beyond.
-constexpr long kQuadMaxColumns = 640;
+// Under rule 1 (round 3, same tool with BARTRT_INTEG=1; quad-layer / split / rt_eclipse_simpson):
+//   1 walker 22 (8 rows) / 38 / 38   2: 30 (8 rows) / 49 / 40   3: 39 / 50 / 41   4: 50 / 51 / 43
+//   5: 60 / 54 / 47   6: 64 / 58 / 50   7: 78 / 74 / 64   8: 81 / 78 / 68   9: 91 / 79 / 69   10: 103 / 102 / 71
+// -- the single-wave kernel from four walkers on, the producer / consumer pair never.
+constexpr long kQuadMaxColumns = 640, kQuadMaxColumnsSimpson = 480;
 constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this
 constexpr long kSplitMinColumns = 1025, kSplitMaxColumns = 1300;
 constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
@@ -125,7 +129,8 @@ void rt_eclipse_fast(RtArgs p) {
   ColumnFlux<INTEG, A> ci(p);
   double Bprev = 0.0;
   bool active = true;
-  const int kend = p.kstop[w];
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const bool deck_on = kstop_deck(kraw);
   const double tcap = tau_cap(p, A);
 
   // One layer's arithmetic.  Straight-line: layer indices past the end are
@@ -187,7 +192,7 @@ void rt_eclipse_fast(RtArgs p) {
     layer(k0 + 3, b1, cfO, cfE);
     if (!__any(active)) break;
   }
-  const double F = ci.flux(p, A, p.cloud_on && active, Bprev, L);
+  const double F = ci.flux(p, A, deck_on && active, Bprev, L);
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
     p.walked_out[(size_t)w * p.ntiles + tile] = (k0 + 4 < kend + 1 ? k0 + 4 : kend + 1);
@@ -240,7 +245,8 @@ void rt_eclipse_split(RtArgs p) {
   const int i = tile * 64 + lane;
   const bool valid = i < W;
   const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
-  const int kend = p.kstop[w];
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const bool deck_on = kstop_deck(kraw);
   const int nblk = kend / 4 + 1;  // 4-layer blocks; both waves run the same count
 
   if (role == 0) {
@@ -302,7 +308,7 @@ void rt_eclipse_split(RtArgs p) {
       handoff();
       if (stop) break;
     }
-    sEnd[lane] = (p.cloud_on && active) ? Bprev : 0.0;
+    sEnd[lane] = (deck_on && active) ? Bprev : 0.0;
     handoff();
     if (p.walked_out && lane == 0)
       p.walked_out[(size_t)w * p.ntiles + tile] = (4 * blk + 4 < kend + 1 ? 4 * blk + 4 : kend + 1);
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   const double nu = p.wn[ii];
   const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
   const double nu4 = (nu * nu) * (nu * nu);
-  const int kend = p.kstop[w];
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const bool deck_on = kstop_deck(kraw);
   const double tcap = tau_cap(p, A);
 
   // per-lane table addressing: plane offset of the lane's layer + the lane's
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       const double Gprev = q == 0 ? c_G : G_below;
       c_G = G_below;
       I = fma(hb, Gprev - G, I);
-      if (p.cloud_on && j == kend && live && !(tau > p.toomuch)) Fs = fma(B, G, Fs);  // deck reached below toomuch
+      if (deck_on && j == kend && live && !(tau > p.toomuch)) Fs = fma(B, G, Fs);  // deck reached below toomuch
     } else {
       // rules 1 / 2 are linear in Y = B sum_a (w_a / mu_a) E_a with angle-independent
       // weights (integ.hpp): ONE integrand per layer crosses the lane rows
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
         const double cterm = fma(w0, y2, fma(w1, y1, w2 * (pad ? 0.0 : y)));
         I += counts ? cterm : 0.0;
       }
-      if (p.cloud_on && j == kend && live && !(tau > p.toomuch))   // deck reached below toomuch
+      if (deck_on && j == kend && live && !(tau > p.toomuch))   // deck reached below toomuch
         Fs = fma(B, angle_sum<A>(p, E), Fs);
     }
     active = active && (over & col_bits) == 0ull;
@@ -670,7 +677,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, octo ? 8 : 4));
   err = hipSuccess;
   constexpr bool SQOK = true;   // exp(-2 tau / mu) = exp(-tau / mu)^2 under every rule
-  if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadMaxColumns)) && fits32) {
+  constexpr long quad_max = INTEG == kIntegSimpson ? kQuadMaxColumnsSimpson : kQuadMaxColumns;
+  if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= quad_max)) && fits32) {
     // the smallest launches take eight layers per step (8 wavenumbers per wave)
     b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;
     const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
@@ -690,7 +698,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     BARTRT_MC_LIST(BARTRT_QUAD)
 #undef BARTRT_QUAD
   }
-  if (kmode == "split" || (kmode.empty() && columns >= kSplitMinColumns && columns <= kSplitMaxColumns)) {
+  if (kmode == "split" ||
+      (kmode.empty() && INTEG != kIntegSimpson && columns >= kSplitMinColumns && columns <= kSplitMaxColumns)) {
     b.ntiles = ntiles64;
     const size_t shs = sh + sizeof(double) * (1024 + 2 + 64);
     if (info) { info->kernel = "rt_eclipse_split"; info->wn_per_column = 64; info->ncolumns = b.ntiles; }

@@ -87,7 +87,8 @@ void rt_eclipse_simpson(RtArgs p) {
   const double *sW = sWw;
   stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI, threadIdx.x,
                 blockDim.x);
-  const int kend = p.kstop[w];
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const bool deck_on = kstop_deck(kraw);
   __syncthreads();
   simpson_radius_table(sWw, sC, NC, L, kend, threadIdx.x, blockDim.x);
   __syncthreads();
@@ -269,7 +270,7 @@ void rt_eclipse_simpson(RtArgs p) {
   // lanes that never passed the cut end on the column's last layer
   oddf = oddf || (active && (kend & 1));
   double F = (oddf ? P1 : P0) * (1.0 / 6.0);
-  if (p.cloud_on) {
+  if (deck_on) {
     // an opaque deck reached below toomuch emits as a surface: B(kend) sum_a w_a E_a(tau(kend));
     // x1 is tau(kend) here (see the table's overrun entry)
     const bool deck = active && !(x1 > p.toomuch);
@@ -318,7 +319,7 @@ void rt_eclipse_simpson(RtArgs p) {
       act = act && !(tau > p.toomuch);
       if (!__any(act)) break;
     }
-    F = cf.flux(p, A, p.cloud_on && act, 0.0, L);
+    F = cf.flux(p, A, deck_on && act, 0.0, L);
   }
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
   const double *rt = p.rtop + (size_t)w * L;
   const double *dsw = p.ds + (size_t)w * chord_table_size(L);
 
-  const int kend = p.kstop[w];
+  const int kend = kstop_layer(p.kstop[w]);
   double eprev = 0.0, tau = 0.0, integ = 0.0, gprev = rt[0];
   bool active = true;
   int last = 0;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   const unsigned ii = i0 + m < W ? (unsigned)(i0 + m) : (unsigned)(W - 1);
   const double nu = p.wn[ii];
   const double nu4 = (nu * nu) * (nu * nu);
-  const int kend = p.kstop[w];
+  const int kend = kstop_layer(p.kstop[w]);
   const int nkt = (L + 15) / 16, ns = 4 * nkt;
   const double *__restrict__ dsm = p.ds + (size_t)w * chord_table_size(L);
 

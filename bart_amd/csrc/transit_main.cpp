@@ -82,6 +82,12 @@ int main(int argc, char **argv) {
   if (bartrt_get_radius(rad.data(), L) < 0) die("get_radius");
   if (bartrt_get_tau(tau.data(), last.data(), nwave, L) < 0) die("get_tau");
   const bool eclipse = !c.count("solution") || c["solution"] == "eclipse";
+  if (eclipse) {   // runs under different rules are not to be confused (the files keep the reference's layouts)
+    int rule = -1;
+    static const char *names[] = {"transmittance trapezoid", "Simpson hybrid, SURVEY App. A-4", "trapezoid in tau"};
+    if (bartrt_get_integ(&rule) == 0 && rule >= 0 && rule < 3)
+      std::printf("Integration rule of the eclipse geometry: integ %d (%s)\n", rule, names[rule]);
+  }
   const double toomuch = c.count("toomuch") ? std::atof(c["toomuch"].c_str()) : 20.0;
 
   if (c.count("outspec")) {

@@ -120,17 +120,42 @@ def run_batch_dev(d_prof, d_spec=None, stream=None):
     return d_spec
 
 
-def run_batch_sharded(d_prof, group=None):
+def run_batch_sharded(d_prof, group=None, force=False):
     """Every rank holds one wavenumber block of the tables and the full (tiny)
     profile batch; each computes spec[nwalkers, W/G] and one RCCL all-gather
-    reassembles spec[nwalkers, W] on every rank."""
-    import torch
+    reassembles spec[nwalkers, W] on every rank.  A group of one
+    skips the collective unless ``force`` (the single-GPU test of the RCCL path)."""
     import torch.distributed as dist
     local = run_batch_dev(d_prof)
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local
     return allgather_blocks(local, group, total=trm.get_no_samples())
+
+
+def block_sizes(total, world):
+    """Samples per rank under the engine's integer split (Engine::setup): W*(r+1)//n - W*r//n."""
+    return [total * (r + 1) // world - total * r // world for r in range(world)]
+
+
+def pad_block(local, wmax):
+    """A rank's block [n, W_r] as the all-gather sends it: [n, wmax], zero-padded on the right."""
+    import torch
+    if local.shape[1] == wmax:
+        return local.contiguous()
+    send = torch.zeros((local.shape[0], wmax), dtype=local.dtype, device=local.device)
+    send[:, :local.shape[1]] = local
+    return send
+
+
+def reassemble_blocks(out, n, sizes):
+    """The all-gather's receive buffer [world * n, wmax] (rank-major) -> spectra [n, sum(sizes)]."""
+    import torch
+    world, wmax = len(sizes), out.shape[1]
+    o = out.view(world, n, wmax)
+    if min(sizes) == wmax:
+        return o.permute(1, 0, 2).reshape(n, world * wmax)
+    return torch.cat([o[r, :, :sizes[r]] for r in range(world)], dim=1)
 
 
 def allgather_blocks(local, group=None, total=None, async_op=False, out=None):
@@ -150,7 +175,7 @@ def allgather_blocks(local, group=None, total=None, async_op=False, out=None):
     world = dist.get_world_size(group)
     n = local.shape[0]
     if total is not None:
-        sizes = [total * (r + 1) // world - total * r // world for r in range(world)]
+        sizes = block_sizes(total, world)
         assert sizes[dist.get_rank(group)] == local.shape[1]
     else:
         sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
@@ -158,21 +183,15 @@ def allgather_blocks(local, group=None, total=None, async_op=False, out=None):
                                             device=local.device), group=group)
         sizes = [int(s.item()) for s in sizes]
     wmax = max(sizes)
-    send = local
-    if local.shape[1] != wmax:
-        send = torch.zeros((n, wmax), dtype=local.dtype, device=local.device)
-        send[:, :local.shape[1]] = local
+    send = pad_block(local, wmax)
     if out is None:
         out = torch.empty((world * n, wmax), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(out, send.contiguous(), group=group, async_op=async_op)
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
 
     def finish():
         if work is not None:
             work.wait()                      # the current stream waits; the host does not
-        o = out.view(world, n, wmax)
-        if min(sizes) == wmax:
-            return o.permute(1, 0, 2).reshape(n, world * wmax)
-        return torch.cat([o[r, :, :sizes[r]] for r in range(world)], dim=1)
+        return reassemble_blocks(out, n, sizes)
 
     return (work, finish) if async_op else finish()
 
@@ -193,7 +212,7 @@ class GatherPipeline:
         import torch.distributed as dist
         self.n, self.wl, self.total, self.G, self.pg = nwalkers, wlocal, total, max(1, steps_per_bucket), pg
         world = dist.get_world_size(pg)
-        wmax = max(total * (r + 1) // world - total * r // world for r in range(world))
+        wmax = max(block_sizes(total, world))
         dtype = dtype or torch.float64
         self.local = [torch.empty((self.G, nwalkers, wlocal), dtype=dtype, device=device) for _ in range(2)]
         self.recv = [torch.empty((world * self.G * nwalkers, wmax), dtype=dtype, device=device) for _ in range(2)]
@@ -298,9 +317,10 @@ def step_batch_dev(d_params, nfilters, want_spec=False, stream=None):
     return (band, status, spec) if want_spec else (band, status)
 
 
-def step_batch_sharded(d_params, nfilters, group=None, stream=None):
+def step_batch_sharded(d_params, nfilters, group=None, stream=None, force=False):
     """Per-step callable on a wavenumber-sharded node: profiles on every rank,
-    RT on the local block, all-gather, band integration on the full grid."""
+    RT on the local block, all-gather, band integration on the full grid.
+    ``force``: issue the collective on a group of one too (run_batch_sharded)."""
     import torch
     n, npars = d_params.shape
     dev = d_params.device
@@ -309,7 +329,7 @@ def step_batch_sharded(d_params, nfilters, group=None, stream=None):
     _check(trm.lib().bartrt_step_profiles_dev(
         C.c_void_p(d_params.data_ptr()), n, npars, C.c_void_p(prof.data_ptr()),
         C.c_void_p(status.data_ptr()), _stream_ptr(stream)))
-    spec = run_batch_sharded(prof, group)
+    spec = run_batch_sharded(prof, group, force=force)
     band = torch.empty((n, nfilters), dtype=torch.float64, device=dev)
     _check(trm.lib().bartrt_step_bandflux_dev(
         C.c_void_p(spec.data_ptr()), n, C.c_void_p(status.data_ptr()),

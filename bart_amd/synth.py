@@ -158,15 +158,19 @@ class Case:
         return p
 
 
-def kappa_layer(seed, l, L, temps, M, wn, press_bar_l):
+def kappa_layer(seed, l, L, temps, M, wn, press_bar_l, model="forest"):
     """Seeded synthetic opacity slab [Nt][M][W] for layer l, cm2/g: log-normal
     line forest per molecule, smooth (exponential) in T, weak pressure trend.
-    Median ~1 cm2/g puts the photosphere near 0.01-1 bar for 1e-4 abundances."""
+    model "forest" (default): median ~1 cm2/g puts the photosphere near 0.01-1 bar for
+    1e-4 abundances; "survey8d": SURVEY.md 8d's literal exp(N(-25, 3)) cm2/g, smoothly
+    modulated in T -- a transparent column (every layer is walked)."""
     W = len(wn)
     out = np.empty((len(temps), M, W))
     for m in range(M):
         rng = np.random.default_rng([seed, m])      # same per-wn pattern in every layer
         g = rng.normal(0.0, 2.5, W) + np.log(2.0) - 0.6 * m
+        if model == "survey8d":
+            g = rng.normal(-25.0, 3.0, W)
         a = rng.normal(0.0, 0.6, W)
         b = 0.15 * rng.random(W)
         tt = (np.asarray(temps)[:, None] - 1500.0) / 1000.0
@@ -200,7 +204,8 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
               tlow=400.0, thigh=3000.0, tempdelt=100.0, seed=20260101,
               cia=True, raygrid=(0, 20, 40, 60, 80), toomuch=10.0,
               refpress=0.1, tep_rp_rjup=1.35, tep_mp_mjup=0.66,
-              ptop=1e-5, pbottom=100.0, extra_keys=None, write=True, reuse=False) -> Case:
+              ptop=1e-5, pbottom=100.0, extra_keys=None, write=True, reuse=False,
+              kappa_model="forest") -> Case:
     """Write a full seeded input set: SURVEY.md section 8(d) headline shape by
     default (L=100, W=1e4, M=4, Nt=27, H2-H2 CIA, 5 angles)."""
     if write and reuse:
@@ -240,7 +245,7 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
     ids = [MOLECULES[m][0] for m in opmol]
     if len(opmol) and write:
         write_opacity(p("opacity.dat"), ids, tgrid, press * 1e6, wn,
-                      plane_fn=lambda l: kappa_layer(seed, l, L, tgrid, len(opmol), wn, press[l]))
+                      plane_fn=lambda l: kappa_layer(seed, l, L, tgrid, len(opmol), wn, press[l], kappa_model))
     # cia: False / True (H2-H2) / number of pairs (H2-H2, H2-He, H2-CH4), each file
     # with its own temperature and wavenumber sampling
     cia_files = []
@@ -251,6 +256,8 @@ def make_case(outdir: str, nlayers=100, nwave=10000, wnlow=1000.0, wndelt=1.0,
         cw = np.arange(wn[0] - 20.0, wn[-1] + 20.1 + 3.0 * n, 10.0 + 3.0 * n)
         base = 1e-7 / (1 + 2 * n) * np.exp(-((cw - (0.4 + 0.15 * n) * (wn[0] + wn[-1]))
                                              / (0.6 * (wn[-1] - wn[0]))) ** 2)
+        if kappa_model == "survey8d":      # 8d: CIA table = 1e-45 exp(N(0, 1))
+            base = np.full(len(cw), 1e-45)
         al = base[None, :] * (1.0 + 0.3 * (ct[:, None] - 400.0) / 2600.0) \
             * np.exp(0.2 * rng.normal(size=(1, len(cw))))
         if write:

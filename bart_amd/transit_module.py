@@ -85,6 +85,7 @@ def lib():
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
         L.bartrt_timing_begin_sampled.argtypes = [i]
         L.bartrt_set_integ.argtypes = [i]
+        L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
         L.bartrt_algorithmic_bytes.argtypes = [i]
         L.bartrt_algorithmic_bytes.restype = d
@@ -149,11 +150,13 @@ INTEG_RULES = ("transmittance", "simpson", "trapz_tau")
 
 def set_integ(rule):
     """Integration rule of the eclipse geometry (include/bartrt.h, bartrt_set_integ):
-    0 / 'transmittance' (default), 1 / 'simpson' (SURVEY.md App. A-4), 2 / 'trapz_tau'."""
+    0 / 'transmittance', 1 / 'simpson' (the default), 2 / 'trapz_tau'."""
     if isinstance(rule, str):
         rule = INTEG_RULES.index(rule)
     check(lib().bartrt_set_integ(int(rule)))
 
 
 def get_integ() -> int:
-    return check(lib().bartrt_get_integ())
+    rule = C.c_int(-1)
+    check(lib().bartrt_get_integ(C.byref(rule)))
+    return int(rule.value)

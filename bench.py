@@ -7,13 +7,24 @@ A "step" is one pass of the hot path (profile prep + RT kernel; for N > 1 also
 the RCCL all-gather that reassembles each spectrum) over one batch of B*N
 synthetic walkers on the headline grid: 100 layers x 1e4 wavenumbers, 4 opacity
 molecules (H2O, CO, CO2, CH4), 27 table temperatures, H2-H2 CIA, ray angles
-0/20/40/60/80 deg, toomuch = 10.  Profiles and spectra stay
-resident in HBM inside the timed region.  N > 1 shards the wavenumber axis by
-block across the ranks, one process per GPU: under torch.distributed.run (RANK /
-WORLD_SIZE in the environment) this process is one rank; run plainly with
+0/20/40/60/80 deg, toomuch = 10, under the engine's default
+integration rule (integ 1; --integ overrides).  Profiles and
+spectra stay resident in HBM inside the timed region.  N > 1 shards the wavenumber
+axis by block across the ranks, one process per GPU: under torch.distributed.run
+(RANK / WORLD_SIZE in the environment) this process is one rank; run plainly with
 --gpus N > 1 it starts `python -m torch.distributed.run --nproc-per-node N` on
 itself as a CHILD process (before torch or HIP are touched here), relays the
 child's output and exits with its code.
+
+The contract's figure (`value`, `ms_per_step`) is the FIRST timed window: exactly K
+steps between barriers.  Around it the default run adds, outside that window:
+  * `windows`: --repeats further windows of K steps (median / min / max);
+  * `roofline.cold`: launches after a 1 GiB scratch sweep (nothing in L2 / Infinity Cache);
+  * `integ_sweep`: the three integration rules at 10 and 256 walkers;
+  * `batch_sweep`; `survey8d_workload` (SURVEY 8d's literal transparent opacities);
+  * `configs`: BASELINE.json configs 2, 4 (per-GPU work), transit geometry, 5;
+  * `cpu_baseline`; for N > 1 `scaling_diag` and a `replicas` comparison.
+--no-extras keeps only the contract's window (what the profiling scripts run).
 
 --dry-gloo replaces the GPU engine by a stub (spectra = a known function of the
 profile and the sample index) on CPU tensors with the gloo backend: it exercises
@@ -38,11 +49,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # kernel arguments in device memory (the ROCm default on this image; measured here: 78 against
-# 83 us per ten-walker step with it switched off) -- kept on if the environment says nothing
+# 83 us per ten-walker step with it switched off) -- kept on if the environment says nothing;
+# the value in force is recorded in the line's `config`
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PEAK_FP64_TFLOPS = 78.6  # MI355X vector fp64 peak (MI355X_MICROARCH.md): 256 CUs x 64 lanes x 2 x 2.4 GHz
+INTEG_NAMES = ("transmittance trapezoid", "Simpson hybrid of SURVEY App. A-4", "trapezoid in tau")
 
 
 # HD 209458b system values of the demo TEP file (examples/demo/HD209458b.tep) and the
@@ -96,30 +109,37 @@ def make_profiles(case, n, seed):
     return out
 
 
-def cpu_baseline(case, profs, seconds_target=12.0):
-    """The CPU oracle (a restatement, NOT reference transit: its source is an
-    empty submodule) timed on this host's cores, one walker per thread."""
+def cpu_baseline(case, integ, seconds_target=8.0):
+    """The CPU oracle (a restatement, NOT reference transit: its source is an empty
+    submodule) timed on this host's cores, one walker per thread, same integration
+    rule as the GPU line: a warm-up pass (thread pool, page faults), then passes of
+    growing size until one runs for at least 5 s."""
     from oracle import rt_oracle as orc
     cores = os.cpu_count() or 1
-    if len(profs) < 4 * cores:
-        profs = make_profiles(case, 4 * cores, seed=20260104)
-    eng = orc.OracleEngine(case.tcfg)
+    eng = orc.OracleEngine(case.tcfg, integ=integ)
+    warm = make_profiles(case, cores, seed=20260104)
     t0 = time.perf_counter()
-    eng.run(profs[0])
-    one = time.perf_counter() - t0
-    n = int(min(len(profs), max(cores, seconds_target / max(one, 1e-3))))
-    n = max(cores, (n // cores) * cores)
-    n = min(n, len(profs))
-    t0 = time.perf_counter()
-    eng.run_batch(profs[:n], threads=cores)
-    dt = time.perf_counter() - t0
+    eng.run_batch(warm, threads=cores)
+    rate = cores / max(time.perf_counter() - t0, 1e-3)          # includes the pool's start: an underestimate
+    n = dt = 0
+    for _ in range(4):
+        n = int(min(16384, max(cores, rate * seconds_target)))
+        n = max(cores, (n // cores) * cores)
+        profs = make_profiles(case, n, seed=20260105)
+        t0 = time.perf_counter()
+        eng.run_batch(profs, threads=cores)
+        dt = time.perf_counter() - t0
+        rate = n / dt
+        if dt >= 5.0 or n >= 16384:
+            break
     return {"value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
-            "sample": f"{n} spectra of the same workload (100x1e4, 4 molecules), "
-                      f"one walker per thread, {dt:.1f} s wall"}
+            "sample": f"{n} spectra of the same workload (100x1e4, 4 molecules, integ {integ}), one walker per "
+                      f"thread on {cores} threads, {dt:.1f} s wall after a warm-up pass of {cores} spectra"}
 
 
-RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "prep.hpp", "engine.hpp", "rt_eclipse_i0.hip",
-              "rt_eclipse_i0_ilp.hip", "kernels.hip", "engine.hip")
+RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "prep.hpp", "engine.hpp",
+              "rt_eclipse_i0.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1.hip", "rt_eclipse_i1_ilp.hip",
+              "kernels.hip", "engine.hip")
 
 
 def source_id():
@@ -218,6 +238,7 @@ class StubEngine:
         self.W, self.lo, self.hi = nwave, 0, nwave
 
     def init(self, tcfg, shard=None, device=None):
+        self.lo, self.hi = 0, self.W
         if shard is not None:
             r, n = shard
             self.lo, self.hi = self.W * r // n, self.W * (r + 1) // n   # Engine::setup's split
@@ -255,6 +276,11 @@ class StubEngine:
         return engine.GatherPipeline(*args, **kw)
 
 
+def _stats(ms):
+    ms = sorted(ms)
+    return {"n": len(ms), "median": float(np.median(ms)), "min": ms[0], "max": ms[-1]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,15 +292,27 @@ def main():
     ap.add_argument("--nlayers", type=int, default=100)
     ap.add_argument("--nsets", type=int, default=16,
                     help="distinct walker batches cycled through the steps")
+    ap.add_argument("--integ", type=int, default=None, choices=[0, 1, 2],
+                    help="integration rule of the headline run (default: the engine's, integ 1 = App. A-4)")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="further timed windows of --steps steps after the contract's (spread of the figure)")
     ap.add_argument("--sweep", default="64,256,1024",
                     help="extra batch sizes reported under batch_sweep (N=1 only; '' = none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="HIP events bracket every n-th RT launch of the timed region (a pair of event records "
-                         "costs the stream about 5 us, 7 %% of a ten-walker step; 1 = every launch)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the contract's window and its roofline record: no repeats, cold pass, sweeps, "
+                         "survey8d leg, configs, replicas comparison (what the profiling scripts run)")
+    ap.add_argument("--event-stride", type=int, default=3,
+                    help="HIP events bracket every n-th RT launch of the timed windows (a pair of event records "
+                         "costs the stream about 5 us, 7 %% of a ten-walker step; 1 = every launch).  Coprime with "
+                         "--nsets, so the sampled launches visit every cycled batch")
     ap.add_argument("--gather-steps", type=int, default=4,
                     help="N > 1: steps per all-gather bucket (fewer, larger collectives; the last bucket's "
                          "collective is the one nothing overlaps, so a bucket should stay a small part of the run)")
+    ap.add_argument("--mode", default="shard", choices=["shard", "replicas"],
+                    help="N > 1: shard = wavenumber blocks across the ranks + all-gather (north_star); replicas = "
+                         "every rank holds the whole grid and runs its own walkers, no collective (SURVEY 8e's "
+                         "baseline).  The default sharded run also times a replicas pass for comparison")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
     ap.add_argument("--workdir", default=None)
@@ -282,6 +320,9 @@ def main():
                     help="table: the headline opacity-table workload (BASELINE config 3, the contract's line); "
                          "lbl: BASELINE config 5, on-the-fly Voigt line-by-line (tools/lbl_bench.py's line)")
     ap.add_argument("--wnosamp", type=int, default=1, help="--config lbl: oversampling of the line sums")
+    ap.add_argument("--kappa", default="forest", choices=["forest", "survey8d"],
+                    help="opacity model of the headline run (survey8d: SURVEY 8d's literal exp(N(-25,3)); the "
+                         "default run reports it as the extra `survey8d_workload`)")
     ap.add_argument("--same-walkers", action="store_true",
                     help="diagnostic: every walker of a batch carries the batch's first profile (all table "
                          "planes shared: what the launch costs without its own HBM traffic); not a benchmark")
@@ -324,8 +365,8 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
-    use_dist = world > 1 or (a.force_collective and "RANK" in os.environ)
-    if use_dist:
+    in_group = world > 1 or (a.force_collective and "RANK" in os.environ)
+    if in_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL (and gloo) print a banner through C stdio on stdout when the first
         # communicator comes up; the contract is ONE JSON line there.  File
@@ -349,37 +390,51 @@ def main():
 
     from bart_amd import synth
     if dry:
-        engine = StubEngine(a.nwave)
+        engine, trm = StubEngine(a.nwave), None
     else:
-        from bart_amd import engine
+        from bart_amd import engine, transit_module as trm
 
     # ---- synthetic inputs (rank 0 of the node writes, everyone reads)
     wd = a.workdir or os.path.join(tempfile.gettempdir(),
                                    "bartrt_bench_%s" % os.environ.get("MASTER_PORT", "single"))
-    case = synth.make_case(wd, nlayers=a.nlayers, nwave=a.nwave,
+    if a.kappa != "forest":
+        wd += "_" + a.kappa
+    case = synth.make_case(wd, nlayers=a.nlayers, nwave=a.nwave, kappa_model=a.kappa,
                            write=(local_rank == 0 and not dry), reuse=True)
-    if use_dist:
+    if in_group:
         dist.barrier()
-    engine.init(case.tcfg, shard=(rank, world) if world > 1 else None, device=local_rank)
+    sharded = world > 1 and a.mode == "shard"
+    use_gather = sharded or (in_group and a.force_collective and a.mode == "shard")
+    engine.init(case.tcfg, shard=(rank, world) if sharded else None, device=local_rank)
+    if trm is not None and a.integ is not None:
+        trm.set_integ(a.integ)
+    integ = trm.get_integ() if trm is not None else -1
     lo, hi = engine.local_range()
 
-    def timed(nwalk, steps, warmup, record):
-        """`steps` passes of the hot path over batches of nwalk walkers; the
-        batches cycle through a.nsets distinct seeded sets so that consecutive
-        steps do not re-read exactly the same table planes."""
+    def timed(nwalk, steps, warmup, record, repeats=0, gather=None):
+        """The contract's window -- `steps` passes of the hot path over batches of nwalk
+        walkers between barriers -- and `repeats` more windows of the same length.  The
+        batches cycle through a.nsets distinct seeded sets so that consecutive steps do
+        not re-read exactly the same table planes.  Returns a dict: dt (first window, max
+        over ranks), windows_ms (per-step time of every window), kern_ms / nlaunch (RT
+        kernel time of the sampled launches of all windows), ok, profs, diag (N > 1)."""
+        gather = use_gather if gather is None else gather
+        l0, h0 = engine.local_range()
         nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
-        profs_h = make_profiles(case, nwalk * nsets, seed=20260103).reshape(nsets, nwalk, -1)
+        profs_h = make_profiles(case, nwalk * nsets, seed=20260103 + (0 if gather or world == 1 else rank))
+        profs_h = profs_h.reshape(nsets, nwalk, -1)
         if a.same_walkers:
             profs_h[:] = profs_h[:, :1]
         d_prof = torch.from_numpy(profs_h).to(dev)
         # N > 1: the steps' local blocks go into bucket slots; one all-gather per
         # bucket runs on RCCL's stream while the next bucket's kernels run on the
         # compute stream (engine.GatherPipeline)
-        d_local = [torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev) for _ in range(2)]
-        pipe = engine.GatherPipeline(nwalk, hi - lo, a.nwave, a.gather_steps, dev) if use_dist else None
+        d_local = [torch.empty((nwalk, h0 - l0), dtype=torch.float64, device=dev) for _ in range(2)]
+        pipe = engine.GatherPipeline(nwalk, h0 - l0, a.nwave, a.gather_steps, dev) if gather else None
+        wfull = a.nwave if gather else h0 - l0
 
         def step(i):
-            if not use_dist:
+            if not gather:
                 engine.run_batch_dev(d_prof[i % nsets], d_local[i & 1])
                 return d_local[i & 1]
             engine.run_batch_dev(d_prof[i % nsets], pipe.slot(i))
@@ -390,48 +445,105 @@ def main():
             outs = pipe.drain(last)
             return [outs[-1][-1]] if outs else []
 
+        def window(nsteps, first_step=0):
+            """-> (seconds between the barriers on this rank, seconds of the final drain, last output)"""
+            out_ = None
+            sync()
+            if in_group:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            for i in range(nsteps):
+                o = step(i)
+                out_ = o if o is not None else out_
+            t1 = time.perf_counter()
+            if gather:   # (t1: the kernels are enqueued, the collectives of the filled buckets too)
+                out_ = (drain(nsteps - 1) or [out_])[-1]
+            sync()
+            t2 = time.perf_counter()
+            if in_group:
+                dist.barrier()
+            sync()
+            return time.perf_counter() - t0, t2 - t1, out_
+
         out = None
         for i in range(warmup):
             out = step(i)
-        if use_dist and warmup:
+        if gather and warmup:
             out = (drain(warmup - 1) or [out])[-1]
-        sync()
-        if use_dist:
-            dist.barrier()
-        sync()
         if record:
             engine.timing_begin(a.event_stride)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            o = step(i)
-            out = o if o is not None else out
-        if use_dist:
-            out = (drain(steps - 1) or [out])[-1]
-        sync()
-        if use_dist:
-            dist.barrier()
-        sync()
-        dt = time.perf_counter() - t0
+        dt_local, drain_s, out = window(steps)
+        wins = [dt_local]
+        for _ in range(repeats):
+            wins.append(window(steps)[0])
         kern_ms, nlaunch = engine.timing_end() if record else (0.0, 0)
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        ok = out.shape == (nwalk, a.nwave) and bool(torch.isfinite(out).all())
+        dt = dt_local
+        diag = None
+        if in_group:
+            t = torch.tensor([dt_local, drain_s, kern_ms / max(nlaunch, 1)] + wins, dtype=torch.float64, device=dev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            allt = torch.stack(allt).cpu().numpy()              # [rank][...]
+            dt = float(allt[:, 0].max())
+            wins = list(allt[:, 3:].max(axis=0))
+            wmax = max(a.nwave * (r + 1) // world - a.nwave * r // world for r in range(world))
+            diag = {
+                "mode": "shard" if gather else "replicas",
+                "per_rank_window_s": [float(x) for x in allt[:, 0]],
+                "rank_skew_ms": float((allt[:, 0].max() - allt[:, 0].min()) * 1e3),
+                "per_rank_rt_kernel_ms": [float(x) for x in allt[:, 2]],
+                "per_rank_final_drain_ms": [float(x * 1e3) for x in allt[:, 1]],
+                "exposed_gather_note": "final_drain = host time from the last step's enqueue to the end of the last "
+                                       "bucket's collective and reassembly (the part of the run no kernel overlaps)",
+            }
+            if gather:
+                diag.update({
+                    "steps_per_bucket": a.gather_steps,
+                    "allgather_send_bytes_per_rank_per_bucket": a.gather_steps * nwalk * wmax * 8,
+                    "allgather_recv_bytes_per_rank_per_bucket": world * a.gather_steps * nwalk * wmax * 8,
+                    "ms_per_step_minus_rt_kernel": float(dt / steps * 1e3 - allt[:, 2].max()),
+                })
+        ok = out is not None and out.shape == (nwalk, wfull) and bool(torch.isfinite(out).all())
         if dry:   # the reassembled spectra of the last step, sample for sample
-            ok = ok and bool(torch.equal(out, StubEngine.expected(d_prof[(steps - 1) % nsets], 0, a.nwave)))
-        return dt, kern_ms, nlaunch, ok, profs_h
+            ok = ok and bool(torch.equal(out, StubEngine.expected(d_prof[(steps - 1) % nsets], 0 if gather else l0,
+                                                                  a.nwave if gather else h0)))
+        return {"dt": dt, "windows_ms": [w / steps * 1e3 for w in wins], "kern_ms": kern_ms, "nlaunch": nlaunch,
+                "ok": ok, "profs": profs_h, "d_prof": d_prof, "diag": diag}
 
-    nwalk = a.walkers * world            # weak scaling: per-GPU work is fixed
-    dt, kern_ms, nlaunch, ok, profs_all = timed(nwalk, a.steps, a.warmup, True)
+    # weak scaling: per-GPU work is fixed.  Sharded: every rank evaluates all B*N walkers on its
+    # wavenumber block; replicas: every rank evaluates its own B walkers on the whole grid.
+    nwalk = a.walkers * world if (sharded or world == 1) else a.walkers
+    nspectra_per_step = a.walkers * world
+    extras = not a.no_extras and not dry
+    main_run = timed(nwalk, a.steps, a.warmup, True, repeats=a.repeats if extras else 0)
+    dt, kern_ms, nlaunch, ok, profs_all = (main_run[k] for k in ("dt", "kern_ms", "nlaunch", "ok", "profs"))
     profs0 = profs_all[0]
 
+    # ---- N > 1, sharded: the same per-GPU work as independent replicas (SURVEY 8e's baseline)
+    replicas = None
+    if extras and world > 1 and sharded:
+        trm.free_memory()
+        engine.init(case.tcfg, shard=None, device=local_rank)
+        if a.integ is not None:
+            trm.set_integ(a.integ)
+        rr = timed(a.walkers, a.steps, a.warmup, True, gather=False)
+        replicas = {"value": nspectra_per_step * a.steps / rr["dt"], "unit": "spectra/s",
+                    "ms_per_step": rr["dt"] / a.steps * 1e3, "walkers_per_rank": a.walkers,
+                    "note": "every rank holds the whole grid and runs its own walkers: no collective; same "
+                            "spectra per step as the sharded line", "diag": rr["diag"]}
+        trm.free_memory()
+        engine.init(case.tcfg, shard=(rank, world), device=local_rank)
+        if a.integ is not None:
+            trm.set_integ(a.integ)
+
     sweep = {}
-    if world == 1 and a.sweep:
+    if world == 1 and a.sweep and extras:
         for b in [int(x) for x in a.sweep.split(",") if x]:
             k = max(16, min(50, 4000 // b))
-            sdt, skm, snl, sok, _ = timed(b, k, 8, True)
-            sweep[str(b)] = {"spectra_per_s": b * k / sdt, "ms_per_step": sdt / k * 1e3,
+            r = timed(b, k, 8, True)
+            skm, snl = r["kern_ms"], r["nlaunch"]
+            sweep[str(b)] = {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
                              "rt_kernel_ms": skm / max(snl, 1),
                              "survey8d_algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
 
@@ -444,12 +556,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "DRY RUN (stub engine, gloo, CPU): launch path and step loop only, "
                                    "%d walkers per rank per step, %d samples" % (a.walkers, a.nwave),
-                       "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave,
-                       "parallelism": "wavenumber-block shard x%d + all-gather" % world},
+                       "walkers_per_step": nspectra_per_step, "nlayers": a.nlayers, "nwave": a.nwave,
+                       "parallelism": ("wavenumber-block shard x%d + all-gather" if a.mode == "shard"
+                                       else "replicas x%d, no collective") % world},
+            "scaling_diag": main_run["diag"],
             "roofline": None, "cpu_baseline": None}), flush=True)
     elif rank == 0:
         assert ok
-        value = nwalk * a.steps / dt
+        value = nspectra_per_step * a.steps / dt
         alg = engine.algorithmic_bytes(nwalk)          # SURVEY 8d bytes per RT launch on this GPU
         per_launch_s = kern_ms / 1e3 / max(nlaunch, 1)
         # ---- what one launch has to move: untimed passes over the same batches with
@@ -459,16 +573,39 @@ def main():
         d_out = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
         for sset in range(nsets):
             engine.walked_begin()
-            engine.run_batch_dev(torch.from_numpy(profs_all[sset]).to(dev), d_out)
+            engine.run_batch_dev(main_run["d_prof"][sset], d_out)
             torch.cuda.synchronize()
             walked, wpc, kname = engine.walked_end()
             models.append(launch_byte_model(case, profs_all[sset], walked, wpc, hi - lo))
         mean = lambda key: float(np.mean([m[key] for m in models]))
         uniq, eff, wfrac = mean("unique_bytes"), mean("effective_bytes"), mean("layers_walked_frac")
+        # ---- cold launches: a 1 GiB scratch sweep in front of each (L2 and the 256 MiB Infinity
+        # Cache hold nothing of the tables: every compulsory byte comes from HBM)
+        cold = None
+        if extras and world == 1:
+            scratch = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+            cms = []
+            for j in range(12):
+                scratch.add_(1.0)
+                torch.cuda.synchronize()
+                engine.timing_begin(1)
+                engine.run_batch_dev(main_run["d_prof"][j % nsets], d_out)
+                torch.cuda.synchronize()
+                ms, n = engine.timing_end()
+                cms.append(ms / max(n, 1))
+            del scratch
+            cmed = float(np.median(cms))
+            cold = {"launch_ms": _stats(cms), "achieved_GBps": uniq / (cmed / 1e3) / 1e9,
+                    "frac": uniq / (cmed / 1e3) / 1e9 / PEAK_HBM_GBS,
+                    "note": "RT kernel after a 1 GiB read-modify-write of a scratch buffer (4x the Infinity Cache): "
+                            "the launch's compulsory bytes all come from HBM; the warm figure above is taken in "
+                            "the timed loop, where consecutive batches share most table planes through the "
+                            "256 MiB Infinity Cache, and is an upper bound on DRAM utilisation"}
         # ---- committed profiler figures of THIS build (tools/profile_round.sh), if any
         sid = source_id()
         same = lambda j: (j.get("source_id") == sid and j.get("walkers") == nwalk and j.get("nwave") == a.nwave
-                          and j.get("nlayers") == a.nlayers and world == 1)
+                          and j.get("nlayers") == a.nlayers and j.get("integ", 0) == integ and world == 1
+                          and a.kappa == "forest")
         traffic = traffic_src = None
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
@@ -488,6 +625,20 @@ def main():
                         "source": "profiles/%s" % j.get("file", "isa_latest.json")}
         except Exception:
             pass
+        bound_measured = None
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
+            if j.get("source_id") == sid:
+                bound_measured = {"source": "profiles/%s" % j.get("file", "sq_latest.json")}
+                for k_, v in j.get("batches", {}).items():
+                    busy = v["fp64_pipe_busy_fraction"]
+                    bound_measured[k_] = {
+                        "bound": "fp64_valu" if busy >= 0.75 else "issue/latency",
+                        "fp64_pipe_busy_fraction": busy, "resident_waves_per_simd": v["resident_waves_per_simd"],
+                        "wave_time": v["wave_time"]}
+        except Exception:
+            pass
+        wms = main_run["windows_ms"]
         res = {
             "metric": "forward spectra/sec (100 layers x 1e4 wavenumbers)",
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": a.steps,
@@ -497,25 +648,36 @@ def main():
             "config": {
                 "workload": "H2O+CO+CO2+CH4 eclipse, %d layers x %d wavenumbers, %d walkers "
                             "batched per GPU per step, opacity-table path, 27 T planes, "
-                            "H2-H2 CIA, 5 ray angles, toomuch 10, integration rule 0 (integ=0: trapezoid "
-                            "in the transmittance); walkers: PT_line T(p) with parameters uniform in the demo "
-                            "retrieval's prior box, %d distinct batches cycled.  Departure from SURVEY 8d: "
-                            "the synthetic opacities are a log-normal line forest of median ~1 cm2/g "
-                            "(bart_amd/synth.py kappa_layer) instead of exp(N(-25,3)) cm2/g, which would be a "
-                            "transparent atmosphere; with it the photosphere lies inside the column and the "
-                            "`toomuch` cut skips the fraction of layers reported as 1 - roofline.layers_walked_frac"
-                            % (a.nlayers, a.nwave, a.walkers, nsets),
-                "walkers_per_step": nwalk, "nlayers": a.nlayers, "nwave": a.nwave, "integ": 0,
+                            "H2-H2 CIA, 5 ray angles, toomuch 10, integration rule %d (%s); "
+                            "walkers: PT_line T(p) with parameters uniform in the demo "
+                            "retrieval's prior box, %d distinct batches cycled.  %s"
+                            % (a.nlayers, a.nwave, a.walkers, integ, INTEG_NAMES[integ], nsets,
+                               "Departure from SURVEY 8d: the synthetic opacities are a log-normal line forest of "
+                               "median ~1 cm2/g (bart_amd/synth.py kappa_layer) instead of exp(N(-25,3)) cm2/g, which "
+                               "is a transparent atmosphere (timed as the extra `survey8d_workload`); with the forest "
+                               "the photosphere lies inside the column and the `toomuch` cut skips the fraction of "
+                               "layers reported as 1 - roofline.layers_walked_frac" if a.kappa == "forest" else
+                               "Opacities: SURVEY 8d's literal exp(N(-25,3)) cm2/g (transparent column)"),
+                "walkers_per_step": nspectra_per_step, "nlayers": a.nlayers, "nwave": a.nwave, "integ": integ,
+                "kappa_model": a.kappa,
+                "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
                 **({"DIAGNOSTIC": "--same-walkers: identical profiles in a batch, not the benchmark"}
                    if a.same_walkers else {}),
-                "parallelism": "wavenumber-block shard x%d + all-gather" % world if world > 1
-                               else "single GPU",
+                "parallelism": ("wavenumber-block shard x%d + all-gather" % world if sharded else
+                                "replicas x%d, no collective" % world) if world > 1 else "single GPU",
             },
+            "windows": {
+                "value_is": "the FIRST window: exactly --steps steps between barriers, as the contract times them; "
+                            "the other %d windows ran right after it, same length" % (len(wms) - 1),
+                "ms_per_step": _stats(wms), "spectra_per_s_median": nspectra_per_step / (np.median(wms) / 1e3),
+            } if len(wms) > 1 else None,
             "roofline": {
                 "bound": "hbm", "achieved": uniq / per_launch_s / 1e9, "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": uniq / per_launch_s / 1e9 / PEAK_HBM_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_GBps": traffic / per_launch_s / 1e9 if traffic else None,
+                "bound_measured": bound_measured,
+                "cold": cold,
                 "bytes_model": "achieved = unique_bytes_per_launch / avg launch time: every (layer, T plane, "
                                "molecule, 64-wavenumber column) row the launch's walkers read down to the layer "
                                "where their wave stopped, counted once per launch (walkers share planes; a row "
@@ -525,7 +687,9 @@ def main():
                 "unique_bytes_per_launch": uniq,
                 "effective_bytes_per_launch": eff,
                 "layers_walked_frac": wfrac,
-                "kernel": kname, "launches": nlaunch, "event_stride": a.event_stride, "avg_launch_ms": per_launch_s * 1e3,
+                "kernel": kname, "launches": nlaunch, "event_stride": a.event_stride,
+                "sets_sampled": int(min(nsets, nlaunch)) if np.gcd(a.event_stride, nsets) == 1 else None,
+                "avg_launch_ms": per_launch_s * 1e3,
                 # SURVEY 8d's per-spectrum figure x walkers: no credit for rows shared between the
                 # walkers of a launch or for layers below the cut, so it is NOT bounded by the HBM
                 # peak (the shared rows are served by L2) -- kept as a labelled throughput figure
@@ -535,19 +699,47 @@ def main():
             },
             "source_id": sid,
         }
+        if main_run["diag"]:
+            res["scaling_diag"] = main_run["diag"]
+        if replicas:
+            res["replicas"] = replicas
         if sweep:
             res["batch_sweep"] = sweep
+        if extras and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            # the three rules at 10 and 256 walkers
+            isw = {}
+            for rule in (0, 1, 2):
+                trm.set_integ(rule)
+                isw[str(rule)] = {"rule": INTEG_NAMES[rule]}
+                for b in (10, 256):
+                    k = 150 if b == 10 else 25
+                    r = timed(b, k, 10, True)
+                    isw[str(rule)][str(b)] = {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
+                                              "rt_kernel_us": r["kern_ms"] / max(r["nlaunch"], 1) * 1e3}
+            trm.set_integ(integ)
+            for b in ("10", "256"):
+                isw["rule1_over_rule0_rt_kernel_" + b] = isw["1"][b]["rt_kernel_us"] / isw["0"][b]["rt_kernel_us"]
+            res["integ_sweep"] = isw
+            trm.free_memory()
+            if a.kappa == "forest":
+                res["survey8d_workload"] = bench_configs.survey8d_leg(a, wd, integ, make_profiles, launch_byte_model,
+                                                                      PEAK_HBM_GBS)
+            res["configs"] = bench_configs.run_all(integ)
         if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(case, profs0)
+            res["cpu_baseline"] = cpu_baseline(case, integ)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if use_dist:
+    if in_group:
         dist.barrier()
         dist.destroy_process_group()
     if not dry:
-        from bart_amd import transit_module as trm
-        trm.free_memory()
+        try:
+            trm.free_memory()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

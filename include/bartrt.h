@@ -66,14 +66,20 @@ int bartrt_free_memory(void);
 
 /* Integration rule of the eclipse geometry (no counterpart in the reference's
  * module: its engine, whose source would settle the rule, is an empty submodule --
- * DESIGN.md conventions C6 / C8).  0 = trapezoid in the transmittance (default);
- * 1 = the Simpson / trapezoid hybrid of SURVEY.md App. A-4 for the optical depth
- * (over radius) and for B exp(-tau/mu) (over tau, zero-padded past `last`);
- * 2 = plain trapezoid in tau of B exp(-tau/mu).  Also the cfg key `integ` (number
- * or transmittance / simpson / trapz_tau) and the environment variable
- * BARTRT_INTEG, read by bartrt_init; every eclipse kernel is built for each rule. */
+ * DESIGN.md conventions C6 / C8).
+ *   1 (DEFAULT) = the Simpson / trapezoid hybrid SURVEY.md App. A-4 recalls for the
+ *       reference's engine: the optical depth over radius and B exp(-tau/mu) over tau
+ *       (zero-padded past `last`) -- the only statement about the engine's integrator
+ *       the project holds;
+ *   0 = trapezoid in the transmittance (exact for isothermal columns);
+ *   2 = plain trapezoid in tau of B exp(-tau/mu).
+ * Also the cfg key `integ` (number or transmittance / simpson / trapz_tau) and the
+ * environment variable BARTRT_INTEG, read by bartrt_init; every eclipse kernel is built
+ * for each rule.  bartrt_get_integ writes the rule in force to *rule and returns a status
+ * like every other entry point (rule 0 and BARTRT_OK would otherwise share a value); the
+ * `transit` executable and the worker log the rule they ran under. */
 int bartrt_set_integ(int rule);
-int bartrt_get_integ(void);
+int bartrt_get_integ(int *rule);
 
 /* ---- batched / device-resident variants (same arithmetic) ------------- */
 

@@ -203,7 +203,7 @@ class OracleEngine:
         c.ntemp, c.nwave, c.nangles = len(self.tgrid), W, len(self.angles)
         c.ncia = len(s1)
         if integ is None:      # the cfg key the product reads too (number or name)
-            v = k.get("integ", "0")
+            v = k.get("integ", "1")    # the product's default (App. A-4's rule)
             integ = {"transmittance": 0, "simpson": 1, "trapz_tau": 2, "trapz": 2}.get(v)
             integ = int(v) if integ is None else integ
         c.integ = int(integ)

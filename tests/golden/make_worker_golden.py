@@ -224,7 +224,7 @@ CASES = {
     # more than they receive
     "eclipse_ebalance": dict(kw=dict(nwave=420, wnlow=1500.0, wndelt=4.0, nlayers=26, opmol=("CH4",), molfit=("CH4",),
                                      nfilters=3, ebalance=True, params=(-3.5, 0.0, 1.0, 0.0, 0.98, -0.5)),
-                             extra={"tint": "800.0"}, sma_scan=(0.3, 0.35, 0.38, 0.4, 0.42, 0.45, 0.5, 0.6)),
+                             extra={"tint": "800.0"}, sma_scan=(0.3, 0.33, 0.35, 0.37, 0.38, 0.39, 0.4, 0.41, 0.42, 0.43, 0.44, 0.45, 0.46, 0.47, 0.48, 0.5, 0.52, 0.55, 0.6)),
     # PT_NoInversion raises ValueError for some draws; the loop logs it and goes on with the
     # temperature array as the previous step left it (BARTfunc.py:318-330)
     "eclipse_madhu_valueerror": dict(

@@ -30,6 +30,27 @@ def test_gpus2_self_launch_one_json_line():
     assert j["n_gpus"] == 2 and j["steps"] == 11 and j["warmup"] == 3
     assert j["scaling"] == "weak" and j["config"]["walkers_per_step"] == 6   # walkers scale with N
     assert j["ms_per_step"] > 0
+    # the N > 1 line explains itself: per-rank window and kernel times, the
+    # bucket's bytes, the final drain, the skew between the ranks
+    d = j["scaling_diag"]
+    assert d["mode"] == "shard" and len(d["per_rank_window_s"]) == 2 and len(d["per_rank_rt_kernel_ms"]) == 2
+    assert d["steps_per_bucket"] == 4 and d["rank_skew_ms"] >= 0 and len(d["per_rank_final_drain_ms"]) == 2
+    wmax = 2501 - 2501 // 2
+    assert d["allgather_send_bytes_per_rank_per_bucket"] == 4 * 6 * wmax * 8
+    assert d["allgather_recv_bytes_per_rank_per_bucket"] == 2 * 4 * 6 * wmax * 8
+
+
+def test_gpus2_replicas_mode_has_no_collective():
+    """--mode replicas: SURVEY 8e's baseline -- every rank the whole grid and its own walkers."""
+    r = _bench("--gpus", "2", "--dry-gloo", "--mode", "replicas", "--steps", "5", "--warmup", "1", "--walkers", "3",
+               "--nwave", "700", "--sweep", "")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["walkers_per_step"] == 6
+    assert "replicas x2" in j["config"]["parallelism"]
+    assert j["scaling_diag"]["mode"] == "replicas" and "steps_per_bucket" not in j["scaling_diag"]
 
 
 def test_child_failure_becomes_the_exit_code():

@@ -20,30 +20,43 @@ def _profiles(case, n, seed):
     return bench.make_profiles(case, n, seed)
 
 
-def test_full_grid_properties(full_case):
+@pytest.mark.parametrize("rule", [1, 0])
+def test_full_grid_properties(full_case, rule):
+    """Size-independent properties at BASELINE's full size (100 x 1e4, 864 MB grid) under the default
+    integration rule (1, App. A-4) and under rule 0; the oracle follows on slices.  The closed
+    forms and bounds of (1) and (3) belong to rule 0 (trapezoid in the transmittance: exact for
+    isothermal columns, never above the hottest Planck function); rule 1 is held to them loosely
+    -- it converges on them with the layer spacing -- and to the oracle tightly."""
     from bart_amd import engine, transit_module as trm
     from oracle import rt_oracle as orc
     c = full_case
     engine.init(c.tcfg)
     try:
+        assert trm.get_integ() == 1
+        trm.set_integ(rule)
         n = trm.get_no_samples()
         assert n == 10000 and engine.nlayers() == 100
         profs = _profiles(c, 12, seed=77)
         spec = engine.run_batch(profs)
-        assert spec.shape == (12, 10000) and np.all(np.isfinite(spec)) and spec.min() > 0
+        assert spec.shape == (12, 10000) and np.all(np.isfinite(spec))
         # (1) every spectrum is below the Planck flux of its hottest layer
         wn = trm.get_waveno_arr(n)
         for w in range(12):
             tmax = profs[w, :100].max()
             bmax = 2 * orc.H * wn ** 3 * orc.LS ** 2 / np.expm1(orc.H * orc.LS * wn / (orc.KB * tmax))
-            assert np.all(spec[w] <= np.pi * bmax * (1 + 1e-12))
+            if rule == 0:
+                assert spec[w].min() > 0 and np.all(spec[w] <= np.pi * bmax * (1 + 1e-12))
+            else:
+                assert np.mean((spec[w] > 0) & (spec[w] <= np.pi * bmax * 1.02)) > 0.99
         # (2) walkers are independent: any order, any batch size, same bits
         perm = np.random.default_rng(1).permutation(12)
         assert np.array_equal(engine.run_batch(profs[perm]), spec[perm])
-        # one walker takes the quad-layer kernel: same arithmetic, other schedule
-        np.testing.assert_allclose(engine.run_batch(profs[3:4])[0], spec[3], rtol=1e-13)
+        # one walker takes the quad-layer kernel: same arithmetic, other schedule (rule 1: the
+        # single-wave kernel adds its panels in another form, see rt_eclipse_s1.hpp)
+        tol = dict(rtol=1e-13) if rule == 0 else dict(rtol=1e-10, atol=1e-12 * np.abs(spec).max())
+        np.testing.assert_allclose(engine.run_batch(profs[3:4])[0], spec[3], **tol)
         big = engine.run_batch(np.tile(profs[:4], (40, 1)))          # 160 walkers: other kernel path
-        np.testing.assert_allclose(big[:4], spec[:4], rtol=1e-13)
+        np.testing.assert_allclose(big[:4], spec[:4], **tol)
         assert np.array_equal(big[4:8], big[:4])
         # (3) isothermal closed form with the engine's own optical depths
         iso = c.profiles(temp=np.full(100, 1400.0)).ravel()
@@ -55,10 +68,13 @@ def test_full_grid_properties(full_case):
         edges = np.radians([0, 10, 30, 50, 70, 90])
         wgt = np.pi * np.diff(np.sin(edges) ** 2)
         closed = sum(wg * B * (1 - np.exp(-tl / np.cos(a))) for a, wg in zip(ang, wgt))
-        np.testing.assert_allclose(s_iso, closed, rtol=1e-11)
+        if rule == 0:
+            np.testing.assert_allclose(s_iso, closed, rtol=1e-11)
+        else:   # the padded zero and the Simpson panels of the last steps: a few per cent
+            assert np.median(np.abs(s_iso / closed - 1)) < 0.05
         # (4) the oracle on three 150-sample slices of the full grid
         for lo in (0, 4321, 9850):
-            o = orc.OracleEngine(c.tcfg, wn_lo=lo, wn_hi=lo + 150)
+            o = orc.OracleEngine(c.tcfg, wn_lo=lo, wn_hi=lo + 150, integ=rule)
             for w in (0, 7):
                 np.testing.assert_allclose(spec[w, lo:lo + 150], o.run(profs[w]), rtol=1e-10)
     finally:

@@ -202,7 +202,7 @@ def test_integration_rules_outputs_and_setter(small_case, integ):
     for cfg in (c.tcfg, cfg2):
         engine.init(cfg)
         try:
-            assert trm.get_integ() == 0
+            assert trm.get_integ() == 1          # the default: App. A-4's rule
             trm.set_integ(integ)
             o = orc.OracleEngine(cfg, integ=integ)
             profs = walkers(c, 7, seed=31)

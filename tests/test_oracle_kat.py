@@ -10,9 +10,10 @@ from bart_amd import synth
 from oracle import rt_oracle as orc
 
 
-def _engine(tmp_path, **kw):
+def _engine(tmp_path, integ=None, **kw):
+    """integ: the integration rule the known answer belongs to (None: the default, rule 1)."""
     case = synth.make_case(str(tmp_path), **kw)
-    return case, orc.OracleEngine(case.tcfg)
+    return case, orc.OracleEngine(case.tcfg, integ=integ)
 
 
 def _wgt(angles):
@@ -58,9 +59,11 @@ def test_table_interpolation_at_nodes_and_midpoints(tmp_path):
 
 
 def test_isothermal_closed_form(tmp_path):
-    """Isothermal column, any opacity: I(mu) = B (1 - exp(-tau_last/mu))
-    exactly, so the flux tends to pi*B from below once tau >> 1."""
-    case, e = _engine(tmp_path, nwave=40)
+    """Isothermal column, any opacity: under rule 0 (trapezoid in the
+    transmittance) I(mu) = B (1 - exp(-tau_last/mu)) exactly, so the flux tends to pi*B from
+    below once tau >> 1.  (Rules 1 and 2 reach it in the limit of fine layers:
+    test_all_rules_converge_on_a_finely_layered_isothermal_column.)"""
+    case, e = _engine(tmp_path, integ=0, nwave=40)
     T = 1500.0
     spec, tau, last = e.run(case.profiles(temp=np.full(100, T)), want_tau=True)
     wg = _wgt(e.angles)
@@ -74,14 +77,14 @@ def test_isothermal_closed_form(tmp_path):
 
 
 def test_intensity_never_exceeds_hottest_planck(tmp_path):
-    """A jump of tau by >> 1 across one layer (a line core) must not push the
-    intensity above the hottest layer's Planck function."""
+    """Rule 0: a jump of tau by >> 1 across one layer (a line core) does not push the
+    intensity above the hottest layer's Planck function (rule 2 does)."""
     case = synth.make_case(str(tmp_path), nwave=8, nlayers=30, opmol=("H2O",), cia=False)
     op = orc.read_opacity(case.opacity)
     kap = np.full(op["kappa"].shape, 1e-2)
     kap[:12] = 1e7                      # layers are bottom -> top: an opaque floor at mid-column
     synth.write_opacity(case.opacity, op["ids"], op["temps"], op["press"], op["wn"], kappa=kap)
-    e = orc.OracleEngine(case.tcfg)
+    e = orc.OracleEngine(case.tcfg, integ=0)
     prof = case.profiles()
     spec, tau, last = e.run(prof, want_tau=True)
     assert np.max(np.diff(tau[0][:last[0] + 1])) > 5.0
@@ -103,7 +106,7 @@ def test_grey_atmosphere_tau_is_column_mass(tmp_path):
     op = orc.read_opacity(case.opacity)
     synth.write_opacity(case.opacity, op["ids"], op["temps"], op["press"], op["wn"],
                         kappa=np.full(op["kappa"].shape, kap))
-    e = orc.OracleEngine(case.tcfg)
+    e = orc.OracleEngine(case.tcfg, integ=0)      # tau by trapezoid over radius (rules 0 / 2)
     T = 1200.0
     prof = case.profiles(temp=np.full(100, T))
     spec, tau, last = e.run(prof, want_tau=True)

@@ -30,7 +30,7 @@ def main():
         for name, env in VARIANTS:
             steps = max(10, min(300, 3000 // n))
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--walkers", str(n), "--steps", str(steps),
-                   "--warmup", "10", "--sweep", "", "--no-cpu", "--workdir", wd]
+                   "--warmup", "10", "--no-extras", "--no-cpu", "--workdir", wd]
             out = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             if not line:

@@ -1,0 +1,269 @@
+"""The other BASELINE.json configurations as entries of bench.py's line (`configs`), and
+SURVEY 8d's literal opacity model as an extra leg (`survey8d_workload`).  Each entry is
+measured on one GPU with its inputs resident in HBM and carries a `roofline` that names
+the bound that applies to it:
+
+  demo_1walker        BASELINE config 2: demo eclipse shape (CH4, 2501 samples), one walker
+  wasp12b_step        BASELINE config 4's per-GPU work: WASP-12b shape (2424 samples, 4 molecules,
+                      4 filters), 10 walkers through the per-step callable (parameters -> band fluxes)
+  transit_10 / _256   transit geometry on the bench grid (rt_transit_mfma)
+  lbl_wnosamp1 / 2160 BASELINE config 5: on-the-fly Voigt line-by-line, 1e6 lines x 1e5 points
+
+Imported by bench.py (N = 1, default run); `python tools/bench_configs.py` prints the
+object on its own."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0          # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate
+PEAK_FP64_TFLOPS = 78.6        # vector fp64; the fp64 matrix pipe has the same peak on this part
+PEAK_FP64_TOPS = PEAK_FP64_TFLOPS / 2.0   # fp64 VALU lane-operations per second (an FMA is ONE operation)
+# fp64 VALU operations of one Voigt sample by branch of voigt_k (csrc/lbl.hip, counted in the source:
+# reciprocal + Newton steps, synthetic-division steps at two FMAs per coefficient, the accumulate):
+# far wing |z| >= 100 (three-term series, real arithmetic), 8 <= |z| < 100 (eleven-term series),
+# |z| < 8 (Weideman N = 40)
+VOIGT_OPS = {"far": 25, "mid": 42, "core": 110}
+
+
+def _time_launches(engine, torch, d_prof, out, steps, warm=5):
+    nsets = d_prof.shape[0]
+    for i in range(warm):
+        engine.run_batch_dev(d_prof[i % nsets], out)
+    torch.cuda.synchronize()
+    engine.timing_begin(1)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        engine.run_batch_dev(d_prof[i % nsets], out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, nl = engine.timing_end()
+    return dt / steps, kms / max(nl, 1) / 1e3
+
+
+def survey8d_leg(a, wd, integ, make_profiles, launch_byte_model, peak_hbm):
+    """SURVEY 8d's workload to the letter: kappa = exp(N(-25, 3)) cm2/g, CIA 1e-45 exp(N(0,1)):
+    a transparent column, every layer walked by every wave (no credit from the toomuch cut)."""
+    import torch
+    from bart_amd import engine, synth, transit_module as trm
+    case = synth.make_case(wd + "_survey8d", nlayers=a.nlayers, nwave=a.nwave, kappa_model="survey8d", reuse=True)
+    engine.init(case.tcfg)
+    try:
+        trm.set_integ(integ)
+        n, nsets = a.walkers, 16
+        profs = make_profiles(case, n * nsets, seed=20260103).reshape(nsets, n, -1)
+        d_prof = torch.from_numpy(profs).cuda()
+        out = torch.empty((n, a.nwave), dtype=torch.float64, device="cuda")
+        step_s, kern_s = _time_launches(engine, torch, d_prof, out, 60)
+        engine.walked_begin()
+        engine.run_batch_dev(d_prof[0], out)
+        torch.cuda.synchronize()
+        walked, wpc, kname = engine.walked_end()
+        m = launch_byte_model(case, profs[0], walked, wpc, a.nwave)
+        alg = engine.algorithmic_bytes(n)
+        return {
+            "workload": "SURVEY 8d's opacity model to the letter (exp(N(-25,3)) cm2/g, CIA 1e-45 exp(N(0,1))): "
+                        "transparent column, %d walkers per step, integ %d" % (n, integ),
+            "value": n / step_s, "unit": "spectra/s", "ms_per_step": step_s * 1e3, "rt_kernel_ms": kern_s * 1e3,
+            "kernel": kname, "layers_walked_frac": m["layers_walked_frac"],
+            "spectrum_max": float(out.max()),
+            "roofline": {"bound": "hbm", "achieved": m["unique_bytes"] / kern_s / 1e9, "peak": peak_hbm, "unit": "GB/s",
+                         "frac": m["unique_bytes"] / kern_s / 1e9 / peak_hbm,
+                         "unique_bytes_per_launch": m["unique_bytes"],
+                         "survey8d_algorithmic_bytes_per_launch": alg,
+                         "survey8d_algorithmic_GBps": alg / kern_s / 1e9,
+                         "note": "all layers walked: unique bytes = every plane pair the batch's temperatures bracket, "
+                                 "down to the bottom; the 8d figure (no credit for planes shared between walkers) "
+                                 "stays a labelled L2 + HBM throughput, not a fraction of the HBM peak"}}
+    finally:
+        trm.free_memory()
+
+
+def demo_1walker(integ):
+    import torch
+    import bench
+    from bart_amd import engine, synth, transit_module as trm
+    d = os.path.join(tempfile.gettempdir(), "bartrt_cfg_demo")
+    case = synth.make_case(d, nlayers=100, nwave=2501, wnlow=2500.0, opmol=("CH4",), seed=7, reuse=True)
+    engine.init(case.tcfg)
+    try:
+        trm.set_integ(integ)
+        nsets = 16
+        profs = bench.make_profiles(case, nsets, seed=5).reshape(nsets, 1, -1)
+        d_prof = torch.from_numpy(profs).cuda()
+        out = torch.empty((1, 2501), dtype=torch.float64, device="cuda")
+        step_s, kern_s = _time_launches(engine, torch, d_prof, out, 300, warm=20)
+        engine.walked_begin()
+        engine.run_batch_dev(d_prof[0], out)
+        torch.cuda.synchronize()
+        walked, wpc, kname = engine.walked_end()
+        m = bench.launch_byte_model(case, profs[0], walked, wpc, 2501)
+        # the reference's call shape: host array in, new host array out (trm.run_transit)
+        lat = []
+        p0 = profs[0, 0].copy()
+        for i in range(220):
+            t0 = time.perf_counter()
+            trm.run_transit(p0, 2501)
+            lat.append(time.perf_counter() - t0)
+        lat = np.array(lat[20:])
+        return {
+            "workload": "BASELINE config 2: demo eclipse shape (CH4, 100 layers x 2501 samples, 2-4 um), ONE walker, "
+                        "precomputed opacity table, integ %d" % integ,
+            "value": 1.0 / step_s, "unit": "spectra/s", "ms_per_step": step_s * 1e3, "rt_kernel_ms": kern_s * 1e3,
+            "kernel": kname,
+            "host_call_run_transit_us": {"median": float(np.median(lat) * 1e6), "p90": float(np.percentile(lat, 90) * 1e6)},
+            "roofline": {"bound": "latency (one walker: 40 columns of 100 dependent layers on a 1 024-SIMD chip; the "
+                                  "quad-layer kernel walks them 8 layers per step) -- quoted against HBM for scale",
+                         "achieved": m["unique_bytes"] / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": m["unique_bytes"] / kern_s / 1e9 / PEAK_HBM_GBS,
+                         "unique_bytes_per_launch": m["unique_bytes"], "layers_walked_frac": m["layers_walked_frac"]}}
+    finally:
+        trm.free_memory()
+
+
+def wasp12b_step(integ):
+    import torch
+    from bart_amd import BARTfunc, engine, synthcfg, transit_module as trm
+    mols = ("H2O", "CO", "CO2", "CH4")
+    p0 = (-2.0, 0.0, 1.0, 0.0, 0.98, -0.5, -0.5, -0.5, -0.5)
+    d = os.path.join(tempfile.gettempdir(), "bartrt_cfg_wasp")
+    case, cfg = synthcfg.make_worker_case(d, nwave=2424, wnlow=910.0, opmol=mols, molfit=mols, params=p0,
+                                          nfilters=4, reuse=True)
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        trm.set_integ(integ)
+        rng = np.random.default_rng(5)
+        nsets, n, steps = 16, 10, 300
+        pars = np.array(p0) + rng.normal(0, [0.3, 0.2, 0.2, 0.05, 0.02, 0.5, 0.5, 0.5, 0.5], (nsets, n, 9))
+        pars[..., 3] = np.clip(pars[..., 3], 0, 1)
+        d_par = torch.from_numpy(pars).cuda()
+        for i in range(20):
+            band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
+        torch.cuda.synchronize()
+        engine.timing_begin(1)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kms, nl = engine.timing_end()
+        kern_s = kms / max(nl, 1) / 1e3
+        alg = engine.algorithmic_bytes(n)
+        return {
+            "workload": "BASELINE config 4's per-GPU work: WASP-12b shape (100 layers x 2424 samples, 4 molecules, "
+                        "4 filters), 10 walkers per step through the per-step callable (parameters -> T(p), "
+                        "abundances -> RT -> band fluxes, all on the device), integ %d" % integ,
+            "value": n / dt, "unit": "walker-steps/s", "ms_per_step": dt * 1e3, "rt_kernel_ms": kern_s * 1e3,
+            "accepted_in_last_batch": int((status.cpu().numpy() == 0).sum()),
+            "roofline": {"bound": "latency / issue (four short dependent launches per step; the RT launch is 380 "
+                                  "columns on 1 024 SIMDs) -- quoted as SURVEY 8d bytes over the RT kernel for scale",
+                         "achieved": alg / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": alg / kern_s / 1e9 / PEAK_HBM_GBS,
+                         "survey8d_algorithmic_bytes_per_launch": alg,
+                         "rt_kernel_share_of_step": kern_s / dt,
+                         "note": "8d bytes give no credit for the planes the ten walkers share (served by L2): an "
+                                 "upper bound on the launch's DRAM traffic"}}
+    finally:
+        w.close()
+
+
+def transit_geometry(integ, batches=(10, 256)):
+    import torch
+    import bench
+    from bart_amd import engine, synth, transit_module as trm
+    d = os.path.join(tempfile.gettempdir(), "bartrt_cfg_transit")
+    case = synth.make_case(d, nlayers=100, nwave=10000, reuse=True,
+                           extra_keys={"solution": "transit", "starrad": 1.145})
+    engine.init(case.tcfg)
+    out = {}
+    try:
+        L, W = 100, 10000
+        nkt = (L + 15) // 16
+        for n in batches:
+            nsets = 8
+            profs = bench.make_profiles(case, n * nsets, seed=11).reshape(nsets, n, -1)
+            d_prof = torch.from_numpy(profs).cuda()
+            spec = torch.empty((n, W), dtype=torch.float64, device="cuda")
+            steps = max(10, min(100, 2000 // n))
+            step_s, kern_s = _time_launches(engine, torch, d_prof, spec, steps)
+            alg = engine.algorithmic_bytes(n)
+            # a wave (16 wavenumbers of one walker) reads its 16-wavenumber slice of the table rows
+            # (SURVEY 8d bytes) and the walker's chord-operand tiles: the chord matrix is lower
+            # triangular, row tile kt takes the steps of the layers 0 .. 16 kt + 15: sum_kt 4 (kt + 1)
+            # tile-steps of 512 B and one v_mfma_f64_16x16x4 (2 x 16 x 16 x 4 flop) each
+            tile_steps = 2 * nkt * (nkt + 1)
+            chord = n * (W / 16.0) * tile_steps * 512.0
+            mfma_flops = n * (W / 16.0) * tile_steps * 2.0 * 16 * 16 * 4
+            out["transit_%d" % n] = {
+                "workload": "transit geometry (modulation spectra), 100 layers x 1e4 wavenumbers, %d walkers per "
+                            "step, chord optical depths on v_mfma_f64_16x16x4" % n,
+                "value": n / step_s, "unit": "spectra/s", "ms_per_step": step_s * 1e3, "rt_kernel_ms": kern_s * 1e3,
+                "roofline": {"bound": "l2 (table rows + chord-operand tiles out of L2; MFMA pipe lightly loaded)",
+                             "achieved": (alg + chord) / kern_s / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
+                             "frac": (alg + chord) / kern_s / 1e9 / PEAK_L2_GBS,
+                             "l2_bytes_model": {"table_rows_survey8d": alg, "chord_operand_tiles": chord},
+                             "mfma": {"flop_per_launch": mfma_flops, "achieved_TFLOPs": mfma_flops / kern_s / 1e12,
+                                      "peak_TFLOPs": PEAK_FP64_TFLOPS,
+                                      "frac": mfma_flops / kern_s / 1e12 / PEAK_FP64_TFLOPS},
+                             "note": "upper bounds: row tiles below the toomuch cut are skipped (neither loaded nor "
+                                     "multiplied); the kernel records no walked depth"}}
+    finally:
+        trm.free_memory()
+    return out
+
+
+def lbl(integ, wnosamps=(1, 2160)):
+    """Config 5 through tools/lbl_bench.py's harness, with the fp64 operation count of the Voigt
+    samples as the roofline (the path is arithmetic: under one byte of line list and extinction
+    array per sample)."""
+    import contextlib
+    import io
+    import lbl_bench
+    out = {}
+    for o in wnosamps:
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = lbl_bench.run(["--wnosamp", str(o), "--reps", "3"])
+        ops = sum(VOIGT_OPS[k] * r["voigt_samples_by_branch"][k] for k in VOIGT_OPS)
+        out["lbl_wnosamp%d" % o] = {
+            "workload": "BASELINE config 5: " + r["workload"],
+            "value": r["value"], "unit": "spectra/s", "ms_per_step": r["seconds_per_spectrum"] * 1e3,
+            "voigt_samples": r["voigt_samples"], "voigt_samples_per_s": r["voigt_samples_per_s"],
+            "roofline": {"bound": "fp64_valu (Voigt arithmetic: 25-110 fp64 operations per profile sample, under "
+                                  "one byte per sample)",
+                         "achieved": ops / r["seconds_per_spectrum"] / 1e12, "peak": PEAK_FP64_TOPS,
+                         "unit": "Tops/s (fp64 VALU lane-operations; an FMA counts once; peak = 78.6 TFLOP/s / 2)",
+                         "frac": ops / r["seconds_per_spectrum"] / 1e12 / PEAK_FP64_TOPS,
+                         "op_model": {"per_sample": VOIGT_OPS, "samples_by_branch": r["voigt_samples_by_branch"],
+                                        "note": "samples inside the lines' cuts by branch of the Faddeeva evaluation "
+                                                "(tools/lbl_bench.py work_units) x the branch's fp64 operations; "
+                                                "staging, strengths and the reduction of oversampled layers are not "
+                                                "counted, so this is a lower bound on the arithmetic done"},
+                         "algorithmic_GBps": r["algorithmic_GBps"]}}
+    return out
+
+
+def run_all(integ):
+    res = {}
+    for name, fn in (("demo_1walker", demo_1walker), ("wasp12b_step", wasp12b_step)):
+        try:
+            res[name] = fn(integ)
+        except Exception as e:      # an extra leg must not take the contract's line down
+            res[name] = {"error": repr(e)}
+    for fn in (transit_geometry, lbl):
+        try:
+            res.update(fn(integ))
+        except Exception as e:
+            res[fn.__name__] = {"error": repr(e)}
+    return res
+
+
+if __name__ == "__main__":
+    from bart_amd import transit_module as trm   # noqa: F401
+    print(json.dumps(run_all(int(sys.argv[1]) if len(sys.argv) > 1 else 1)))

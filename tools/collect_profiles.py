@@ -66,6 +66,7 @@ if __name__ == "__main__":
             "tag": tag, "source_id": bench.source_id(),
             # the workload of tools/profile_round.sh's PMC passes (bench.py defaults)
             "walkers": int(os.environ.get("PMC_WALKERS", 10)), "nwave": 10000, "nlayers": 100,
+            "integ": int(os.environ.get("PMC_INTEG", 1)),      # the engine's default rule (bench.py without --integ)
             "kernel": names[0] if len(names) == 1 else names,
             "calibration_kernel": cal_names[0] if len(cal_names) == 1 else cal_names,
             "launches_averaged": n,

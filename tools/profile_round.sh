@@ -8,13 +8,13 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="--steps 200 --warmup 20 --no-cpu --sweep="
+B="--steps 200 --warmup 20 --no-cpu --no-extras"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$out/stats_w10" --output-format csv -- python3 "$root/bench.py" $B > "$out/stats_w10.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/stats_w1" --output-format csv -- python3 "$root/bench.py" $B --walkers 1 > "$out/stats_w1.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/stats_w256" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --sweep= --walkers 256 > "$out/stats_w256.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --sweep= > "$out/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w256" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras --walkers 256 > "$out/stats_w256.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --no-extras > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --no-extras > "$out/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_calib" --output-format csv -- python3 "$root/tools/pmc_calib.py" > "$out/pmc_calib.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/stats_transit" --output-format csv -- python3 "$root/tools/transit_bench.py" 10 256 > "$out/stats_transit.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/stats_6mol2cia" --output-format csv -- python3 "$root/tools/shape_bench.py" 1 10 256 > "$out/stats_6mol2cia.log" 2>&1
@@ -27,7 +27,9 @@ python3 tools/collect_profiles.py "${tag}_w1" "$out/stats_w1"
 python3 tools/collect_profiles.py "${tag}_w256" "$out/stats_w256"
 # instruction mix of the build (the bench line's fp64 figure is computed from it)
 python3 tools/isa_stats.py > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq.txt"
-python3 tools/isa_stats.py --ilp --json profiles/isa_latest.json > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq_ilp.txt"
+python3 tools/isa_stats.py --ilp > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq_ilp.txt"
+# (the default rule's kernel: its figures feed the bench line's fp64 record)
+python3 tools/isa_stats.py --ilp --json profiles/isa_latest.json rt_eclipse_simpsonILi5ELi4ELi1ELb1ELi1ELb0E > "profiles/${tag}_isa_rt_eclipse_simpson_5_4_1_sq_ilp.txt"
 # the bench line last, so that its `traffic` is this round's PMC figure
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cp "$out/bench.json" "profiles/${tag}_bench.json"

@@ -9,10 +9,10 @@ root=$(pwd)
 out=$root/gpurun_out/$tag/sq
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp
-B="--steps 60 --warmup 10 --no-cpu --sweep="
+B="--steps 60 --warmup 10 --no-cpu --no-extras"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d "$out/w10" --output-format csv -- python3 "$root/bench.py" $B > "$out/w10.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU -d "$out/w10b" --output-format csv -- python3 "$root/bench.py" $B > "$out/w10b.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d "$out/w256" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --sweep= --walkers 256 > "$out/w256.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d "$out/w256" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras --walkers 256 > "$out/w256.log" 2>&1
 cd "$root"
 python3 - "$tag" <<'PY'
 import collections, csv, glob, json, os, sys
@@ -42,5 +42,12 @@ path = "gpurun_out/%s/profiles" % tag
 os.makedirs(path, exist_ok=True)
 for p in (path, "profiles"):
     json.dump(out, open(os.path.join(p, tag + "_sq_counters.json"), "w"), indent=1)
+# what bench.py's roofline.bound_measured quotes, tied to the sources it was taken on
+sys.path.insert(0, os.getcwd())
+import bench
+latest = {"source_id": bench.source_id(), "file": tag + "_sq_counters.json",
+          "batches": {"10": out["w10"]["derived"], "256": out["w256"]["derived"]}}
+for p in (path, "profiles"):
+    json.dump(latest, open(os.path.join(p, "sq_latest.json"), "w"), indent=1)
 print(json.dumps({k: v.get("derived") for k, v in out.items()}, indent=1))
 PY

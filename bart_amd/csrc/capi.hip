@@ -105,6 +105,14 @@ int bartrt_set_integ(int rule) {
   return BARTRT_OK;
 }
 
+int bartrt_prefetch_profiles_dev(const double *d_prof_next, int nwalkers) {
+  NEED_ENGINE();
+  if (nwalkers < 0 || (nwalkers > 0 && !d_prof_next)) return fail(BARTRT_EINVAL, "prefetch_profiles_dev: null buffer");
+  g_eng->pf_req_prof = nwalkers > 0 ? d_prof_next : nullptr;
+  g_eng->pf_req_n = nwalkers;
+  return BARTRT_OK;
+}
+
 int bartrt_get_integ(int *rule) {
   NEED_ENGINE();
   if (!rule) return fail(BARTRT_EINVAL, "get_integ: null output pointer");

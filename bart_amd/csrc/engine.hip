@@ -42,7 +42,7 @@ Engine::~Engine() {
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_mass);
   fr(d_prep_consts); fr(d_diam); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
-  fr(d_walked);
+  fr(d_walked); fr(d_coef2); fr(d_idx2); fr(d_kstop2); fr(d_ok2);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
@@ -413,6 +413,14 @@ void Engine::ensure_walkers(int n) {
     HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(*p)));
   };
   if (last_prof == d_prof) last_prof = nullptr;
+  pf_have_prof = nullptr;   // (prefetched records, if any, are dropped with their buffers' sizes)
+  if (cap2) {
+    re(d_coef2, (size_t)cap * L * coef_stride(M, C));
+    re(d_idx2, (size_t)cap * L * idx_stride(C));
+    re(d_kstop2, (size_t)cap);
+    re(d_ok2, (size_t)cap);
+    cap2 = cap;
+  }
   re(d_prof, (size_t)cap * (S + 1) * L);
   re(d_coef, (size_t)cap * L * coef_stride(M, C));
   re(d_idx, (size_t)cap * L * idx_stride(C));
@@ -478,6 +486,34 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   // coefficient workspaces are sized by cap_walkers; the caller's profile and
   // spectrum buffers are used in place
   if (n > cap_walkers) ensure_walkers(n);
+  // prefetched preparation: only the plain table path of the eclipse geometry takes part
+  const bool pf_ok = !prep_hook && !prep_over_once && !lbl_fused && !d_ext && solution == 0 && !want_tau &&
+                     !want_intens && !lbl;
+  const bool want_next = pf_ok && pf_req_prof && pf_req_n > 0;
+  if (want_next && pf_req_n > cap_walkers) ensure_walkers(pf_req_n);   // (drops prefetched records)
+  const bool have = pf_ok && pf_have_prof && pf_have_prof == d_prof_in && pf_have_n == n;
+  const int bset = have ? pf_have_buf : 0;        // record buffers this call's RT kernel reads
+  pf_have_prof = nullptr;
+  if (want_next) {
+    if (cap2 < cap_walkers) {   // first request: the second set of record buffers (nothing prefetched yet)
+      HIPCHK(hipDeviceSynchronize());
+      auto re2 = [&](auto *&p, size_t count) {
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(*p)));
+      };
+      re2(d_coef2, (size_t)cap_walkers * L * coef_stride(M, C));
+      re2(d_idx2, (size_t)cap_walkers * L * idx_stride(C));
+      re2(d_kstop2, (size_t)cap_walkers);
+      re2(d_ok2, (size_t)cap_walkers);
+      cap2 = cap_walkers;
+    }
+  }
+  const bool use_have = have;
+  double *coef_b[2] = {d_coef, d_coef2};
+  idx_t *idx_b[2] = {d_idx, d_idx2};
+  int *kstop_b[2] = {d_kstop, d_kstop2};
+  unsigned char *ok_b[2] = {d_ok, d_ok2};
   PrepArgs pa = prep;
   pa.nwalkers = n;
   pa.prof = d_prof_in;
@@ -485,7 +521,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.scat_flag = scat_flag; pa.scat_value = scat_value;
   pa.has_cloud = has_cloud; pa.cloudtop = cloudtop;
   pa.cloud_rup = cloud_rup; pa.cloud_rdown = cloud_rdown; pa.cloud_ext = cloud_ext;
-  pa.coef = d_coef; pa.idx = d_idx; pa.kstop = d_kstop;
+  pa.coef = coef_b[bset]; pa.idx = idx_b[bset]; pa.kstop = kstop_b[bset];
   pa.ok = d_okp ? d_okp : d_ok;
   pa.rad_out = d_rad;
   pa.over = prep_over_once;
@@ -493,14 +529,28 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   prep_over_once = nullptr;
   pa.rtop = solution == 1 ? d_rtop : nullptr;
   pa.ds = solution == 1 ? d_ds : nullptr;
-  if (prep_hook) HIPCHK(prep_hook(pa, st, prep_hook_ctx));
+  if (use_have) {
+    // prepared by the previous call's RT launch; its flags go where this call wants them
+    if (d_okp) HIPCHK(hipMemcpyAsync(d_okp, ok_b[bset], (size_t)n, hipMemcpyDeviceToDevice, st));
+  } else if (prep_hook) HIPCHK(prep_hook(pa, st, prep_hook_ctx));
   else HIPCHK(launch_prep(pa, st));
   if (solution == 1) HIPCHK(launch_chord_table(pa, st));
 
   RtArgs r = rt;
   r.nwalkers = n;
-  r.coef = d_coef; r.idx = d_idx; r.kstop = d_kstop;
+  r.coef = coef_b[bset]; r.idx = idx_b[bset]; r.kstop = kstop_b[bset];
   r.ext = d_ext;
+  r.nprep = 0;
+  if (want_next) {
+    PrepArgs pn = pa;      // same engine settings; the next batch's profiles into the other buffer set
+    pn.nwalkers = pf_req_n;
+    pn.prof = pf_req_prof;
+    pn.coef = coef_b[1 - bset]; pn.idx = idx_b[1 - bset]; pn.kstop = kstop_b[1 - bset];
+    pn.ok = ok_b[1 - bset];
+    pn.over = nullptr;
+    r.nprep = pf_req_n;
+    r.prep_next = pn;
+  }
   r.cloud_on = has_cloud || over_cloud;
   r.integ = integ;
   r.toomuch = toomuch;
@@ -526,7 +576,9 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   // Timing: the RT kernel's own dispatch stamps the two events (BARTRT_RT_LAUNCH) -- no marker
   // packets in the stream; only the fused line-by-line path (several kernels) is bracketed
   // by event records.
-  const bool timed = timing && (timing_seen++ % timing_stride == 0);
+  // (a call that launches nothing -- no walkers -- takes no event pair: bartrt_timing_end
+  // would read events no dispatch has stamped)
+  const bool timed = timing && n > 0 && r.W > 0 && (timing_seen++ % timing_stride == 0);
   r.ev_start = r.ev_stop = nullptr;
   if (timed) {
     while ((int)ev.size() < ev_used + 2) {
@@ -553,7 +605,16 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   }
   if (lbl_fused) lbl_rt_eclipse(*this, d_prof_in, n, r, st);
   else if (solution == 1) HIPCHK(launch_transit(r, st));
-  else HIPCHK(launch_rt(r, block, st, want_walked ? &walked_info : nullptr));
+  else {
+    RtLaunchInfo li;
+    HIPCHK(launch_rt(r, block, st, &li));
+    if (want_walked) walked_info = li;
+    if (want_next && li.prep_fused) {
+      pf_have_prof = pf_req_prof; pf_have_n = pf_req_n; pf_have_buf = 1 - bset;
+    }
+  }
+  pf_req_prof = nullptr;
+  pf_req_n = 0;
   if (timed) {
     if (lbl_fused) HIPCHK(hipEventRecord(ev[ev_used + 1], st));
     ev_used += 2;

@@ -84,6 +84,19 @@ struct Engine {
   long timing_seen = 0;      // records costs the stream ~5 us: bench.py samples)
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
+  // Prefetched preparation (bartrt_prefetch_profiles_dev): the caller names the NEXT batch's
+  // profile buffer; the RT launch of the current call prepares that batch's layer records in
+  // extra workgroups (RtArgs::nprep) into the second set of record buffers, and the next
+  // call -- if it is for that buffer -- starts on its RT kernel directly.
+  const double *pf_req_prof = nullptr;   // requested for the call after the next run
+  int pf_req_n = 0;
+  const double *pf_have_prof = nullptr;  // records of this batch are in buffer set pf_have_buf
+  int pf_have_n = 0, pf_have_buf = 0;
+  double *d_coef2 = nullptr;
+  idx_t *d_idx2 = nullptr;
+  int *d_kstop2 = nullptr;
+  unsigned char *d_ok2 = nullptr;
+  int cap2 = 0;                          // walkers the second set holds
   // per-step converters
   StepArgs *step = nullptr;
   Lbl *lbl = nullptr;

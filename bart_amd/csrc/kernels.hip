@@ -38,15 +38,7 @@ extern template bool launch_rt_spec<2>(const RtArgs &, int, hipStream_t, const s
 
 __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   extern __shared__ double sm[];
-  const int L = p.L, S = p.S, w = blockIdx.x;
-  // Everything this kernel reads from HBM (the walker's profile and the block of
-  // per-engine constants) is pulled into LDS in ONE batch of independent loads;
-  // the phases of prep_body then run out of LDS.  The kernel is pure latency:
-  // each dependent trip to memory it avoids is worth most of a microsecond.
-  stage2_to_lds(prep_lds_profile(sm, L), p.prof + (size_t)w * (S + 1) * L, (S + 1) * L,
-                prep_lds_consts(sm, L, S), p.consts, 2 * L + S + 2 * p.Nt + 2 * p.ncia_temps,
-                threadIdx.x, blockDim.x);
-  prep_body(p, w, sm, p.over ? p.over + (size_t)3 * w : nullptr);
+  prep_block(p, blockIdx.x, sm);
 }
 
 // XCD-aware block -> (tile, walker) map (see rt_eclipse.hpp)
@@ -224,7 +216,10 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *i
     }
     if (done) return err;
   }
-  if (info) { info->kernel = "rt_eclipse (generic)"; info->wn_per_column = 64; info->ncolumns = a.ntiles * (block / 64); }
+  if (info) {   // (the generic kernel does not carry a prefetched preparation)
+    info->kernel = "rt_eclipse (generic)"; info->wn_per_column = 64; info->ncolumns = a.ntiles * (block / 64);
+    info->prep_fused = false;
+  }
   switch (a.integ * 2 + (a.A == 5 ? 1 : 0)) {
     case 0: return launch_rt_t<0, 0>(a, block, nblocks, st);
     case 1: return launch_rt_t<5, 0>(a, block, nblocks, st);

@@ -198,13 +198,21 @@ struct RtArgs {
   // host side only (BARTRT_RT_LAUNCH): events the dispatch of the RT kernel itself stamps with its
   // start and end, or null -- timing without marker packets in the stream (bartrt_timing_*)
   hipEvent_t ev_start, ev_stop;
+  // Prefetched preparation (bartrt_prefetch_profiles_dev): the single-wave kernels run
+  // prep_profiles' body for the NEXT batch in nprep extra workgroups at the head of this launch
+  // (the grid is prep_slots(nprep) + RT workgroups: a multiple of eight keeps the XCD map), into
+  // the other set of record buffers -- the next call then starts on its RT kernel directly.
+  int nprep;
+  PrepArgs prep_next;
 };
+__host__ __device__ inline int prep_slots(int nprep) { return (nprep + 7) / 8 * 8; }
 
 // What launch_rt launched (diagnostics; the byte model of bench.py)
 struct RtLaunchInfo {
   const char *kernel = "";
   int wn_per_column = 64;   // granularity of RtArgs::walked_out
   int ncolumns = 0;         // entries of walked_out per walker
+  bool prep_fused = false;  // the launch carried RtArgs::nprep workgroups of the next batch's preparation
 };
 
 // ---------------------------------------------------------------------------

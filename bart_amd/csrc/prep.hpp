@@ -83,7 +83,9 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
   }
   __syncthreads();
   const bool bad = sBad != 0;
-  if (!bad && (threadIdx.x == 0 || threadIdx.x == 64)) {
+  // (a 64-lane workgroup -- the preparation fused into an RT launch -- walks both chains in one wave)
+  const unsigned up_lane = blockDim.x >= 128 ? 64 : blockDim.x / 2;
+  if (!bad && (threadIdx.x == 0 || threadIdx.x == up_lane)) {
     const int ix = p.ref_idx;
     double r = refradius;
     if (!p.ref_exact) {
@@ -204,6 +206,18 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     p.kstop[w] = ks;
     if (p.ok) p.ok[w] = bad ? 0 : 1;
   }
+}
+
+// One workgroup's whole job for walker w: everything the body reads from HBM (the walker's
+// profile and the block of per-engine constants) is pulled into LDS in ONE batch of
+// independent loads; the phases of prep_body then run out of LDS.  The kernel is pure latency:
+// each dependent trip to memory it avoids is worth most of a microsecond.
+__device__ inline void prep_block(const PrepArgs &p, int w, double *sm) {
+  const int L = p.L, S = p.S;
+  stage2_to_lds(prep_lds_profile(sm, L), p.prof + (size_t)w * (S + 1) * L, (S + 1) * L,
+                prep_lds_consts(sm, L, S), p.consts, 2 * L + S + 2 * p.Nt + 2 * p.ncia_temps,
+                threadIdx.x, blockDim.x);
+  prep_body(p, w, sm, p.over ? p.over + (size_t)3 * w : nullptr);
 }
 
 }  // namespace bartrt

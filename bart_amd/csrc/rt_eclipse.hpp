@@ -13,6 +13,7 @@
 #pragma once
 #include "integ.hpp"
 #include "kernels.hpp"
+#include "prep.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -94,8 +95,14 @@ void rt_eclipse_fast(RtArgs p) {
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
   constexpr int NR = NLD + (EXT ? 1 : 0) > 0 ? NLD + (EXT ? 1 : 0) : 1;
   const int L = p.L, W = p.W;
+  int bid = blockIdx.x;
+  if (p.nprep > 0) {   // the head of the grid prepares the NEXT batch's layer records (RtArgs::nprep)
+    if (bid < p.nprep) { prep_block(p.prep_next, bid, smem); return; }
+    bid -= prep_slots(p.nprep);
+    if (bid < 0) return;
+  }
   int tile, w;
-  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  block_to_work(bid, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
@@ -218,8 +225,14 @@ void rt_eclipse_split(RtArgs p) {
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
   constexpr int NR = NLD > 0 ? NLD : 1;
   const int L = p.L, W = p.W;
+  int bid = blockIdx.x;
+  if (p.nprep > 0) {   // the head of the grid prepares the NEXT batch's layer records (RtArgs::nprep)
+    if (bid < p.nprep) { prep_block(p.prep_next, bid, smem); return; }
+    bid -= prep_slots(p.nprep);
+    if (bid < 0) return;
+  }
   int tile, w;
-  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  block_to_work(bid, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
@@ -391,8 +404,14 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   constexpr int WN = 64 / R;           // wavenumbers per wave
   constexpr bool SIMPSON = INTEG == kIntegSimpson;
   const int L = p.L, W = p.W;
+  int bid = blockIdx.x;
+  if (p.nprep > 0) {   // the head of the grid prepares the NEXT batch's layer records (RtArgs::nprep)
+    if (bid < p.nprep) { prep_block(p.prep_next, bid, smem); return; }
+    bid -= prep_slots(p.nprep);
+    if (bid < 0) return;
+  }
   int tile, w;
-  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  block_to_work(bid, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;
@@ -664,6 +683,15 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   // (the producer/consumer kernel adds 9 kB of its own)
   RtArgs b = a;
   const bool sq = allow_sq && order_angles_for_square(b);
+  // every specialised kernel carries the next batch's preparation (RtArgs::nprep) at the head of
+  // its grid: prep_slots(nprep) more workgroups, LDS for the larger of the two jobs
+  const int pslots = a.nprep > 0 ? prep_slots(a.nprep) : 0;
+  size_t shp = 0;   // LDS the preparation needs beyond the RT workgroups'
+  if (a.nprep > 0) {
+    const size_t need = sizeof(double) * prep_lds_doubles(a.prep_next.L, a.prep_next.S, a.prep_next.Nt, a.prep_next.ncia_temps);
+    shp = need > sh ? need - sh : 0;
+    if (info) info->prep_fused = true;
+  }
   // too few single-wave columns to load the 1 024 SIMDs evenly -> several
   // waves per 64 wavenumbers: four 16-wavenumber waves that take four layers at
   // a time (quad-layer), or a producer / consumer pair
@@ -681,16 +709,17 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= quad_max)) && fits32) {
     // the smallest launches take eight layers per step (8 wavenumbers per wave)
     b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;
-    const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+    const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
+    const size_t shq = sh + shp;
     if (info) { info->kernel = octo ? "rt_eclipse_quad<R=8>" : "rt_eclipse_quad<R=4>"; info->wn_per_column = octo ? 8 : 16; info->ncolumns = 4 * b.ntiles; }
 #define BARTRT_QUAD(MM, CC)                                                                                          \
   if (a.M == MM && a.C == CC) {                                                                                      \
     if (octo) {                                                                                                      \
-      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, SQOK, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
-      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 8, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, SQOK, 8, INTEG>), dim3(nbq), dim3(256), shq, st, b);     \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 8, INTEG>), dim3(nbq), dim3(256), shq, st, b);       \
     } else {                                                                                                         \
-      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, SQOK, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);     \
-      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG>), dim3(nbq), dim3(256), sh, st, b);       \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, SQOK, 4, INTEG>), dim3(nbq), dim3(256), shq, st, b);     \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG>), dim3(nbq), dim3(256), shq, st, b);       \
     }                                                                                                                \
     err = hipGetLastError();                                                                                         \
     return true;                                                                                                     \
@@ -701,12 +730,13 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   if (kmode == "split" ||
       (kmode.empty() && INTEG != kIntegSimpson && columns >= kSplitMinColumns && columns <= kSplitMaxColumns)) {
     b.ntiles = ntiles64;
-    const size_t shs = sh + sizeof(double) * (1024 + 2 + 64);
+    const size_t shs = sh + sizeof(double) * (1024 + 2 + 64) + shp;
+    const int nbs = nb64 + pslots;
     if (info) { info->kernel = "rt_eclipse_split"; info->wn_per_column = 64; info->ncolumns = b.ntiles; }
 #define BARTRT_SPLIT(MM, CC)                                                                                       \
   if (a.M == MM && a.C == CC) {                                                                                    \
-    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_split<5, MM, CC, SQOK, INTEG>), dim3(nb64), dim3(128), shs, st, b);     \
-    else BARTRT_RT_LAUNCH((rt_eclipse_split<5, MM, CC, false, INTEG>), dim3(nb64), dim3(128), shs, st, b);       \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_split<5, MM, CC, SQOK, INTEG>), dim3(nbs), dim3(128), shs, st, b);     \
+    else BARTRT_RT_LAUNCH((rt_eclipse_split<5, MM, CC, false, INTEG>), dim3(nbs), dim3(128), shs, st, b);       \
     err = hipGetLastError();                                                                                       \
     return true;                                                                                                   \
   }
@@ -715,6 +745,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
   b.ntiles = a.ntiles;
   if (info) { info->kernel = "rt_eclipse_fast"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
+  const size_t sh1 = sh + shp;
+  const int nblocks1 = nblocks + pslots;
   [[maybe_unused]] const bool ilp = kmode != "mono_occ" && (kmode == "mono_ilp" || columns < kIlpMaxColumns);
   if constexpr (INTEG == kIntegSimpson) {
     // rule 1 has its own single-wave kernel (rt_eclipse_s1.hpp), built under the ILP schedule
@@ -722,16 +754,16 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     // 64: 333 / 375, 256: 1 138 / 1 220 -- the default schedule needs 182 registers for two
     // resident waves, or drops the record read-ahead for three and waits on LDS instead)
     if (info) info->kernel = "rt_eclipse_simpson (ILP-scheduled build)";
-    if (launch_rt_simpson_ilp(b, sq, block, nblocks, sh, st, err)) return true;
+    if (launch_rt_simpson_ilp(b, sq, block, nblocks1, sh1, st, err)) return true;
   } else {
     if (INTEG == kIntegTransmittance && ilp) {
       if (info) info->kernel = "rt_eclipse_fast (ILP-scheduled build)";
-      if (launch_rt_fast_ilp(b, sq, block, nblocks, sh, st, err)) return true;
+      if (launch_rt_fast_ilp(b, sq, block, nblocks1, sh1, st, err)) return true;
     }
 #define BARTRT_FAST(MM, CC)                                                                                        \
   if (a.M == MM && a.C == CC) {                                                                                    \
-    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks), dim3(block), sh, st, b);  \
-    else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, INTEG>), dim3(nblocks), dim3(block), sh, st, b);    \
+    if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, SQOK, INTEG>), dim3(nblocks1), dim3(block), sh1, st, b); \
+    else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, INTEG>), dim3(nblocks1), dim3(block), sh1, st, b);   \
     err = hipGetLastError();                                                                                       \
     return true;                                                                                                   \
   }

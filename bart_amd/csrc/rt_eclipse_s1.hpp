@@ -77,8 +77,14 @@ void rt_eclipse_simpson(RtArgs p) {
   constexpr int NR = NLD + (EXT ? 1 : 0) > 0 ? NLD + (EXT ? 1 : 0) : 1;
   constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
   const int L = p.L, W = p.W;
+  int bid = blockIdx.x;
+  if (p.nprep > 0) {   // the head of the grid prepares the NEXT batch's layer records (RtArgs::nprep)
+    if (bid < p.nprep) { prep_block(p.prep_next, bid, smem); return; }
+    bid -= prep_slots(p.nprep);
+    if (bid < 0) return;
+  }
   int tile, w;
-  block_to_work(blockIdx.x, p.nwalkers, tile, w);
+  block_to_work(bid, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
   double *sC = smem;

@@ -100,17 +100,29 @@ def voigt(x: np.ndarray, y: np.ndarray) -> np.ndarray:
 
 # ---- device-resident (torch tensors own the memory) ----------------------
 def _stream_ptr(stream=None):
+    """The HIP stream the library is to enqueue on: torch's current stream.  torch's DEFAULT stream
+    is the null stream (handle 0), which the C ABI reads as "the engine's own stream"
+    (include/bartrt.h) -- a different, non-blocking stream that torch's next operation (a clone, a
+    collective) would not wait for.  The default stream therefore travels as hipStreamLegacy (1),
+    HIP's explicit handle for it."""
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
-    return C.c_void_p(s.cuda_stream)
+    return C.c_void_p(s.cuda_stream or 1)
 
 
-def run_batch_dev(d_prof, d_spec=None, stream=None):
+def run_batch_dev(d_prof, d_spec=None, stream=None, next_prof=None):
     """d_prof: float64 CUDA tensor [nwalkers, (S+1)*L]; returns [nwalkers, W_local]
-    on the same device.  Asynchronous on torch's current stream."""
+    on the same device.  Asynchronous on torch's current stream.
+
+    ``next_prof``: the batch of the NEXT call, if it is known and already complete in HBM
+    (include/bartrt.h, bartrt_prefetch_profiles_dev): this call's RT launch prepares its layer
+    records on the side and the next call skips its preparation launch.  Bit-identical results."""
     import torch
     assert d_prof.is_cuda and d_prof.dtype == torch.float64 and d_prof.is_contiguous()
     n = d_prof.shape[0]
+    if next_prof is not None:
+        assert next_prof.is_cuda and next_prof.dtype == torch.float64 and next_prof.is_contiguous()
+        _check(trm.lib().bartrt_prefetch_profiles_dev(C.c_void_p(next_prof.data_ptr()), next_prof.shape[0]))
     lo, hi = local_range()
     if d_spec is None:
         d_spec = torch.empty((n, hi - lo), dtype=torch.float64, device=d_prof.device)

@@ -85,6 +85,7 @@ def lib():
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
         L.bartrt_timing_begin_sampled.argtypes = [i]
         L.bartrt_set_integ.argtypes = [i]
+        L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
         L.bartrt_algorithmic_bytes.argtypes = [i]

@@ -254,7 +254,7 @@ class StubEngine:
         i = torch.arange(lo, hi, dtype=torch.float64)
         return prof.sum(1, keepdim=True) * 1e-3 + i[None, :]
 
-    def run_batch_dev(self, d_prof, d_spec):
+    def run_batch_dev(self, d_prof, d_spec, next_prof=None):
         d_spec.copy_(self.expected(d_prof, self.lo, self.hi))
         return d_spec
 
@@ -323,6 +323,10 @@ def main():
     ap.add_argument("--kappa", default="forest", choices=["forest", "survey8d"],
                     help="opacity model of the headline run (survey8d: SURVEY 8d's literal exp(N(-25,3)); the "
                          "default run reports it as the extra `survey8d_workload`)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not name the next batch to the engine (bartrt_prefetch_profiles_dev): every step then "
+                         "launches its own prep_profiles kernel, as an MCMC step whose proposal depends on the "
+                         "previous step's spectra has to")
     ap.add_argument("--same-walkers", action="store_true",
                     help="diagnostic: every walker of a batch carries the batch's first profile (all table "
                          "planes shared: what the launch costs without its own HBM traffic); not a benchmark")
@@ -411,7 +415,7 @@ def main():
     integ = trm.get_integ() if trm is not None else -1
     lo, hi = engine.local_range()
 
-    def timed(nwalk, steps, warmup, record, repeats=0, gather=None):
+    def timed(nwalk, steps, warmup, record, repeats=0, gather=None, prefetch=None):
         """The contract's window -- `steps` passes of the hot path over batches of nwalk
         walkers between barriers -- and `repeats` more windows of the same length.  The
         batches cycle through a.nsets distinct seeded sets so that consecutive steps do
@@ -419,6 +423,7 @@ def main():
         over ranks), windows_ms (per-step time of every window), kern_ms / nlaunch (RT
         kernel time of the sampled launches of all windows), ok, profs, diag (N > 1)."""
         gather = use_gather if gather is None else gather
+        prefetch = (not a.no_prefetch) if prefetch is None else prefetch
         l0, h0 = engine.local_range()
         nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
         profs_h = make_profiles(case, nwalk * nsets, seed=20260103 + (0 if gather or world == 1 else rank))
@@ -433,11 +438,15 @@ def main():
         pipe = engine.GatherPipeline(nwalk, h0 - l0, a.nwave, a.gather_steps, dev) if gather else None
         wfull = a.nwave if gather else h0 - l0
 
+        # the batches are resident and independent: each call names the next one, whose layer
+        # records the current RT launch prepares on the side (bartrt_prefetch_profiles_dev)
+        nxt = (lambda i: None) if prefetch is False else (lambda i: d_prof[(i + 1) % nsets])
+
         def step(i):
             if not gather:
-                engine.run_batch_dev(d_prof[i % nsets], d_local[i & 1])
+                engine.run_batch_dev(d_prof[i % nsets], d_local[i & 1], next_prof=nxt(i))
                 return d_local[i & 1]
-            engine.run_batch_dev(d_prof[i % nsets], pipe.slot(i))
+            engine.run_batch_dev(d_prof[i % nsets], pipe.slot(i), next_prof=nxt(i))
             done = pipe.submit(i)            # reassembled spectra of an earlier bucket, or None
             return done[-1] if done is not None else None
 
@@ -661,6 +670,11 @@ def main():
                 "walkers_per_step": nspectra_per_step, "nlayers": a.nlayers, "nwave": a.nwave, "integ": integ,
                 "kappa_model": a.kappa,
                 "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                "prefetch": "off (--no-prefetch): every step launches its own prep_profiles" if a.no_prefetch else
+                            "on: the batches are resident and independent, each call names the next batch "
+                            "(bartrt_prefetch_profiles_dev) and the RT launch prepares its layer records in extra "
+                            "workgroups -- no work is skipped, the next step's prep_profiles launch is; see "
+                            "`no_prefetch` for the plain sequence",
                 **({"DIAGNOSTIC": "--same-walkers: identical profiles in a batch, not the benchmark"}
                    if a.same_walkers else {}),
                 "parallelism": ("wavenumber-block shard x%d + all-gather" % world if sharded else
@@ -699,6 +713,14 @@ def main():
             },
             "source_id": sid,
         }
+        if extras and world == 1 and not a.no_prefetch:
+            r = timed(nwalk, a.steps, a.warmup, True, repeats=4, prefetch=False)
+            res["no_prefetch"] = {
+                "note": "the same windows with every step launching its own prep_profiles kernel (what an MCMC "
+                        "step whose proposal depends on the previous spectra has to do)",
+                "ms_per_step": _stats(r["windows_ms"]),
+                "spectra_per_s_median": nspectra_per_step / (np.median(r["windows_ms"]) / 1e3),
+                "rt_kernel_ms": r["kern_ms"] / max(r["nlaunch"], 1)}
         if main_run["diag"]:
             res["scaling_diag"] = main_run["diag"]
         if replicas:

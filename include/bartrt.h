@@ -81,6 +81,19 @@ int bartrt_free_memory(void);
 int bartrt_set_integ(int rule);
 int bartrt_get_integ(int *rule);
 
+/* Prefetched preparation.  Names the profile batch of the bartrt_run_transit_batch_dev call
+ * AFTER the next one: the next call's RT launch prepares that batch's layer records
+ * (hydrostatic radii, densities, interpolation weights) in extra workgroups of its own grid,
+ * and the call that follows -- if it is made with exactly this buffer and walker count --
+ * starts on its RT kernel directly (one launch and ~8 us of dependent latency less per
+ * batch).  THE CALLER'S PROMISE: the named buffer is complete, and stays unchanged, from the
+ * next call on.  True of batches resident in HBM (a grid or population of models evaluated
+ * chunk by chunk; bench.py); not of an MCMC step whose proposal depends on the previous
+ * step's spectra -- do not prefetch there.  Without a matching call the records are simply
+ * dropped.  Table path of the eclipse geometry; other engines ignore the request.  Results
+ * are bit-identical with and without.  nwalkers = 0 withdraws a request. */
+int bartrt_prefetch_profiles_dev(const double *d_prof_next, int nwalkers);
+
 /* ---- batched / device-resident variants (same arithmetic) ------------- */
 
 /* nwalkers profiles -> nwalkers spectra; ok[w] = 0 marks a profile the
@@ -91,7 +104,9 @@ int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
                              double *spec, int nwave, unsigned char *ok);
 
 /* Same with HBM-resident buffers, asynchronous on `stream` (a hipStream_t;
- * NULL = the engine's own stream).  d_spec is [nwalkers][local samples]. */
+ * NULL = the engine's own non-blocking stream, which nothing else is ordered with: a
+ * caller that works on the device's default stream passes hipStreamLegacy, (hipStream_t)1,
+ * as bart_amd/engine.py does for torch's default stream).  d_spec is [nwalkers][local samples]. */
 int bartrt_run_transit_batch_dev(const double *d_prof, int nwalkers,
                                  double *d_spec, unsigned char *d_ok,
                                  void *stream);

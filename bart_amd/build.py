@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
-SOURCES = ["rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
+SOURCES = ["rt_eclipse_angles.hip", "rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
            "transit_geom.hip",
            "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "io.cpp"]   # longest first
 HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
@@ -18,8 +18,11 @@ HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "
 
 
 # per-file compiler options (see the comment on rt_eclipse_fast in csrc/rt_eclipse.hpp)
-EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-               "rt_eclipse_i1_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ILP, "rt_eclipse_i1_ilp.hip": ILP}
+# rt_eclipse_angles.hip is compiled once per ray-grid size other than five: (object name, flags)
+ANGLE_SIZES = (1, 2, 3, 4, 6, 7, 8, 9)
+VARIANTS = {"rt_eclipse_angles.hip": [("rt_eclipse_a%d" % n, ["-DBARTRT_ANGLES=%d" % n, *ILP]) for n in ANGLE_SIZES]}
 
 
 def _hipcc() -> str:
@@ -41,17 +44,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", 
              "-Wall", "-Wno-unused-result", *os.environ.get("BARTRT_CXXFLAGS", "").split()]
-    def compile_one(src: str) -> str:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), *flags, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job) -> str:
+        src, name, extra = job
+        obj = os.path.join(CSRC, name + ".o")
+        cmd = [_hipcc(), *flags, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         return obj
 
+    jobs = []
+    for src in SOURCES:
+        if src in VARIANTS:
+            jobs += [(src, name, extra) for name, extra in VARIANTS[src]]
+        else:
+            jobs.append((src, os.path.splitext(src)[0], EXTRA_FLAGS.get(src, [])))
     # translation units are independent: a few compilers side by side
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, jobs))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
     subprocess.check_call(cmd)
     # the standalone `transit` executable (C ABI only), found next to the library

@@ -180,8 +180,10 @@ int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
                  reinterpret_cast<unsigned char *>(dp + (size_t)nwalkers * nprof + (size_t)nwalkers * Wl),
                  e->stream, false);
       e->last_prof = dp;   // stays valid until the next host-buffer call
+      e->last_n = nwalkers;
     } else {
       e->last_prof = e->d_prof;
+      e->last_n = nwalkers;
       HIPCHK(hipMemcpyAsync(e->d_prof, e->h_pin, pb, hipMemcpyHostToDevice, e->stream));
       e->run_dev(e->d_prof, nwalkers, e->d_spec, e->d_ok, e->stream, false);
       HIPCHK(hipMemcpyAsync(hs, e->d_spec, sb, hipMemcpyDeviceToHost, e->stream));
@@ -217,16 +219,24 @@ int bartrt_run_transit_batch_dev(const double *d_prof, int nwalkers, double *d_s
   });
 }
 
-int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
+// the profile the optical-depth / intensity getters re-run: walker w of the latest host-buffer call
+static const double *latest_profile(Engine *e, int walker, const char *who) {
+  if (!e->last_prof)
+    throw IoError{std::string(who) + ": no host-buffer spectrum has been computed since the engine's buffers were last "
+                  "(re)built (device-buffer calls keep no profile: call bartrt_run_transit with the one in question)"};
+  if (walker < 0 || walker >= e->last_n)
+    throw IoError{std::string(who) + ": walker index outside the latest call's batch"};
+  return e->last_prof + (size_t)walker * (e->S + 1) * e->L;
+}
+
+int bartrt_get_tau_of(int walker, double *tau, int *last, int nwave, int nlayers) {
   NEED_ENGINE();
   Engine *e = g_eng;
   if (!tau || nwave != e->W() || nlayers != e->L)
     return fail(BARTRT_EINVAL, "get_tau: shape must be [local samples][nlayers]");
   return guarded([&] {
-    // re-run the most recent profile of a host-buffer call with the
-    // optical-depth output enabled
-    if (!e->last_prof) throw IoError{"get_tau: no spectrum has been computed yet"};
-    e->run_dev(e->last_prof, 1, e->d_spec, e->d_ok, e->stream, true);
+    // re-run that profile of the latest host-buffer call with the optical-depth output enabled
+    e->run_dev(latest_profile(e, walker, "get_tau"), 1, e->d_spec, e->d_ok, e->stream, true);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(tau, e->d_tau, sizeof(double) * (size_t)nwave * nlayers, hipMemcpyDeviceToHost));
     if (last) HIPCHK(hipMemcpy(last, e->d_last, sizeof(int) * (size_t)nwave, hipMemcpyDeviceToHost));
@@ -257,6 +267,13 @@ int bartrt_get_radius(double *rad, int nlayers) {
 
 int bartrt_get_nangles(void) { NEED_ENGINE(); return g_eng->A; }
 
+int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
+  NEED_ENGINE();
+  if (g_eng->last_prof && g_eng->last_n > 1)
+    return fail(BARTRT_EINVAL, "get_tau: the latest call was a batch; name the walker with bartrt_get_tau_of()");
+  return bartrt_get_tau_of(0, tau, last, nwave, nlayers);
+}
+
 int bartrt_get_angles(double *deg, int n) {
   NEED_ENGINE();
   if (!deg || n != g_eng->A) return fail(BARTRT_EINVAL, "get_angles: bad length");
@@ -266,14 +283,21 @@ int bartrt_get_angles(double *deg, int n) {
 
 int bartrt_get_intensity(double *intens, int nangles, int nwave) {
   NEED_ENGINE();
+  if (g_eng->last_prof && g_eng->last_n > 1)
+    return fail(BARTRT_EINVAL, "get_intensity: the latest call was a batch; name the walker with bartrt_get_intensity_of()");
+  return bartrt_get_intensity_of(0, intens, nangles, nwave);
+}
+
+int bartrt_get_intensity_of(int walker, double *intens, int nangles, int nwave) {
+  NEED_ENGINE();
   Engine *e = g_eng;
   if (e->solution != 0) return fail(BARTRT_EINVAL, "get_intensity: eclipse geometry only");
   if (!intens || nangles != e->A || nwave != e->W()) return fail(BARTRT_EINVAL, "get_intensity: bad shape");
   return guarded([&] {
-    if (!e->last_prof) throw IoError{"get_intensity: no spectrum has been computed yet"};
+    const double *prof = latest_profile(e, walker, "get_intensity");
     e->want_intens = true;
     try {
-      e->run_dev(e->last_prof, 1, e->d_spec, e->d_ok, e->stream, false);
+      e->run_dev(prof, 1, e->d_spec, e->d_ok, e->stream, false);
     } catch (...) { e->want_intens = false; throw; }
     e->want_intens = false;
     HIPCHK(hipStreamSynchronize(e->stream));

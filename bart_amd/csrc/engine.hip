@@ -20,21 +20,6 @@ static T *dev_upload(const std::vector<T> &v) {
   return d;
 }
 
-static std::vector<std::string> split_commas(const std::string &s) {
-  std::vector<std::string> out;
-  std::string cur;
-  for (char ch : s) {
-    if (ch == ',' || ch == ' ' || ch == '\t') {
-      if (!cur.empty()) out.push_back(cur);
-      cur.clear();
-    } else {
-      cur.push_back(ch);
-    }
-  }
-  if (!cur.empty()) out.push_back(cur);
-  return out;
-}
-
 Engine::~Engine() {
   delete step;
   delete lbl;
@@ -244,22 +229,36 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   d_wn = dev_upload(wn_loc);
   d_wn_full = dev_upload(wn_full);
   if (M > 0) {
-    size_t n = (size_t)L * Nt * M * Wl;
-    double *h = nullptr;
-    HIPCHK(hipHostMalloc(&h, n * sizeof(double), hipHostMallocDefault));
+    // The file's order o[L][Nt][M][W] goes up slab by slab -- a bounded number of (layer,
+    // temperature) planes through one pinned host buffer and one device staging buffer
+    // (256 MB, BARTRT_INIT_SLAB_BYTES) -- and is re-laid out on the device with each
+    // wavenumber's molecules contiguous (kernels.hpp, "Table layout"): peak memory during
+    // init is the table + one slab, on the device and on the host.
+    const size_t n = (size_t)L * Nt * M * Wl;
+    const long planes = (long)L * Nt;
+    const size_t plane_doubles = (size_t)M * Wl;
+    size_t slab_bytes = (size_t)256 << 20;
+    if (const char *e = std::getenv("BARTRT_INIT_SLAB_BYTES")) slab_bytes = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+    const long per = std::max<long>(1, std::min<long>(planes, (long)(slab_bytes / (plane_doubles * sizeof(double)))));
+    double *h = nullptr, *d_stage = nullptr;
+    HIPCHK(hipMalloc(&d_kappa, n * sizeof(double)));
+    hipError_t er = hipHostMalloc(&h, (size_t)per * plane_doubles * sizeof(double), hipHostMallocDefault);
+    if (er == hipSuccess) er = hipMalloc(&d_stage, (size_t)per * plane_doubles * sizeof(double));
     try {
-      read_opacity_block(cfg["opacityfile"], oh, lo, hi, h);
-    } catch (...) { (void)hipHostFree(h); throw; }
-    // the file's order o[L][Nt][M][W] goes up as it lies and is re-laid out on the
-    // device with each wavenumber's molecules contiguous (kernels.hpp, "Table layout")
-    double *d_file = nullptr;
-    hipError_t er = hipMalloc(&d_file, n * sizeof(double));
-    if (er == hipSuccess) er = hipMemcpy(d_file, h, n * sizeof(double), hipMemcpyHostToDevice);
-    (void)hipHostFree(h);
-    if (er == hipSuccess) er = hipMalloc(&d_kappa, n * sizeof(double));
-    if (er == hipSuccess) er = launch_grid_transpose(d_file, d_kappa, (long)L * Nt, M, Wl, stream);
-    if (er == hipSuccess) er = hipStreamSynchronize(stream);
-    if (d_file) (void)hipFree(d_file);
+      for (long p0 = 0; p0 < planes && er == hipSuccess; p0 += per) {
+        const long np = std::min(per, planes - p0);
+        read_opacity_rows(cfg["opacityfile"], oh, lo, hi, p0 * M, np * M, h);
+        er = hipMemcpyAsync(d_stage, h, (size_t)np * plane_doubles * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (er == hipSuccess) er = launch_grid_transpose(d_stage, d_kappa + (size_t)p0 * plane_doubles, np, M, Wl, stream);
+        if (er == hipSuccess) er = hipStreamSynchronize(stream);   // the slab buffers are reused
+      }
+    } catch (...) {
+      if (h) (void)hipHostFree(h);
+      if (d_stage) (void)hipFree(d_stage);
+      throw;
+    }
+    if (h) (void)hipHostFree(h);
+    if (d_stage) (void)hipFree(d_stage);
     HIPCHK(er);
   }
   // CIA: resample on the local grid (linear in wn, zero outside the file) and lay
@@ -268,7 +267,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   std::vector<double> cia_planes, cia_temp;
   PrepArgs &pa = prep;
   if (cfg_has(cfg, "csfile")) {
-    auto files = split_commas(cfg["csfile"]);
+    auto files = split_file_list(cfg["csfile"]);
     if ((int)files.size() > kMaxCia) throw IoError{"csfile: too many cross-section files"};
     for (auto &fn : files) {
       Cia c = read_cia(fn);

@@ -49,7 +49,8 @@ struct Engine {
   // workspaces (grown on demand, never inside a timed launch sequence twice)
   int cap_walkers = 0;
   double *d_prof = nullptr, *d_coef = nullptr, *d_spec = nullptr;
-  const double *last_prof = nullptr;  // first profile of the latest host-buffer call (get_tau, get_intensity)
+  const double *last_prof = nullptr;  // profiles of the latest host-buffer call (get_tau, get_intensity)
+  int last_n = 0;                     // ... and how many they are
   idx_t *d_idx = nullptr;
   int *d_kstop = nullptr;
   double *d_rtop = nullptr, *d_ds = nullptr;  // transit geometry workspaces

@@ -55,6 +55,22 @@ TCfg read_tcfg(const std::string &path) {
   return c;
 }
 
+std::vector<std::string> split_file_list(const std::string &s) {
+  std::vector<std::string> out;
+  std::string cur;
+  auto flush = [&] {
+    const std::string t = trim(cur);
+    if (!t.empty()) out.push_back(t);
+    cur.clear();
+  };
+  for (char ch : s) {
+    if (ch == ',' || ch == '\n') flush();
+    else cur.push_back(ch);
+  }
+  flush();
+  return out;
+}
+
 bool cfg_has(const TCfg &c, const std::string &k) {
   auto it = c.find(k);
   return it != c.end() && !it->second.empty();
@@ -195,6 +211,25 @@ void read_opacity_block(const std::string &path, const OpacityHeader &h, long lo
   } else {
     for (long r = 0; r < nrows && ok; r++) {
       std::fseek(fp, h.data_offset + 8L * (r * h.nwave + lo), SEEK_SET);
+      ok = std::fread(dst + r * w, sizeof(double), w, fp) == (size_t)w;
+    }
+  }
+  std::fclose(fp);
+  if (!ok) throw IoError{"short read from opacity file '" + path + "'"};
+}
+
+void read_opacity_rows(const std::string &path, const OpacityHeader &h, long lo, long hi, long row0,
+                       long nrows, double *dst) {
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) throw IoError{"cannot open opacity file '" + path + "'"};
+  const long total = h.nlayer * h.ntemp * h.nmol, w = hi - lo;
+  bool ok = row0 >= 0 && nrows >= 0 && row0 + nrows <= total;
+  if (ok && lo == 0 && hi == h.nwave) {
+    std::fseek(fp, h.data_offset + 8L * row0 * h.nwave, SEEK_SET);
+    ok = std::fread(dst, sizeof(double), (size_t)nrows * w, fp) == (size_t)nrows * w;
+  } else {
+    for (long r = 0; r < nrows && ok; r++) {
+      std::fseek(fp, h.data_offset + 8L * ((row0 + r) * h.nwave + lo), SEEK_SET);
       ok = std::fread(dst + r * w, sizeof(double), w, fp) == (size_t)w;
     }
   }

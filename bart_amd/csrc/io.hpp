@@ -48,6 +48,13 @@ struct OpacityHeader {
 };
 OpacityHeader read_opacity_header(const std::string &path);
 // Copies o[:, :, :, lo:hi] into dst ([L][Nt][M][hi-lo], host memory).
+// rows [row0, row0 + nrows) of the grid (a row = one (layer, temperature, molecule)), samples [lo, hi)
+void read_opacity_rows(const std::string &path, const OpacityHeader &h, long lo, long hi, long row0,
+                       long nrows, double *dst);
+// File lists of the transit cfg (`linedb`, `csfile`): comma separated -- one `key value` line
+// per file is joined with commas by read_tcfg, code/makecfg.py:87-104 -- or one per line;
+// blanks around a name are dropped, blanks INSIDE a path are kept.
+std::vector<std::string> split_file_list(const std::string &s);
 void read_opacity_block(const std::string &path, const OpacityHeader &h, long lo,
                         long hi, double *dst);
 

@@ -770,26 +770,19 @@ void lbl_init(Engine &e, const std::string &paths) {
   Lbl *b = new Lbl();
   delete e.lbl;
   e.lbl = b;
-  // `linedb` may name several TLI files (comma / blank separated; one line each
-  // in the cfg, code/makecfg.py:93-104): their databases are merged in file order
+  // `linedb` may name several TLI files (comma separated; one line each in the cfg,
+  // code/makecfg.py:93-104): their databases are merged in file order.  A molecule may come
+  // in several databases (the usual per-band split of a line list): each stays a group of
+  // its own here (own partition functions, own ethresh reference); lbl_write_opacity sums
+  // the groups of one molecule into that molecule's plane.
   Tli &t = b->tli;
-  {
-    std::string cur;
-    auto flush = [&] {
-      if (cur.empty()) return;
-      Tli one = read_tli(cur);
-      if (one.db.empty()) throw IoError{"TLI file '" + cur + "' holds no database"};
-      if (t.db.empty()) { t.wn_lo = one.wn_lo; t.wn_hi = one.wn_hi; }
-      t.wn_lo = std::min(t.wn_lo, one.wn_lo);
-      t.wn_hi = std::max(t.wn_hi, one.wn_hi);
-      for (auto &db : one.db) t.db.push_back(std::move(db));
-      cur.clear();
-    };
-    for (char ch : paths) {
-      if (ch == ',' || ch == ' ' || ch == '\t') flush();
-      else cur.push_back(ch);
-    }
-    flush();
+  for (const std::string &one_path : split_file_list(paths)) {
+    Tli one = read_tli(one_path);
+    if (one.db.empty()) throw IoError{"TLI file '" + one_path + "' holds no database"};
+    if (t.db.empty()) { t.wn_lo = one.wn_lo; t.wn_hi = one.wn_hi; }
+    t.wn_lo = std::min(t.wn_lo, one.wn_lo);
+    t.wn_hi = std::max(t.wn_hi, one.wn_hi);
+    for (auto &db : one.db) t.db.push_back(std::move(db));
   }
   const std::string &path = paths;
   if (t.db.empty()) throw IoError{"linedb '" + path + "' names no TLI file"};
@@ -971,8 +964,18 @@ void lbl_rt_eclipse(Engine &e, const double *d_prof, int nwalkers, const RtArgs 
 
 void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<double> &tgrid) {
   Lbl *b = e.lbl;
-  const int Nt = (int)tgrid.size(), L = e.L, M = b->dev.ngroup, W = e.W();
+  const int Nt = (int)tgrid.size(), L = e.L, G = b->dev.ngroup, W = e.W();
   if (e.lo != 0 || e.hi != e.Wfull) throw IoError{"the opacity grid is generated on an unsharded engine"};
+  // one plane per MOLECULE (the file's layout): the databases of one molecule
+  // -- several TLI files, or several databases in one -- are summed into its plane
+  std::vector<int> ids, slot(G);
+  for (int g = 0; g < G; g++) {
+    const int id = e.mol.id[e.mol.find_name(b->tli.db[g].molecule)];
+    auto it = std::find(ids.begin(), ids.end(), id);
+    slot[g] = (int)(it - ids.begin());
+    if (it == ids.end()) ids.push_back(id);
+  }
+  const int M = (int)ids.size();
   double *d_tg = nullptr, *d_ab = nullptr, *d_out = nullptr;
   HIPCHK(hipMalloc(&d_tg, sizeof(double) * Nt));
   HIPCHK(hipMemcpy(d_tg, tgrid.data(), sizeof(double) * Nt, hipMemcpyHostToDevice));
@@ -982,15 +985,13 @@ void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<dou
   if (!fp) { (void)hipFree(d_tg); (void)hipFree(d_ab); throw IoError{"cannot create opacity file '" + path + "'"}; }
   long dims[4] = {M, Nt, L, W};
   std::fwrite(dims, sizeof(long), 4, fp);
-  std::vector<int> ids(M);
-  for (int g = 0; g < M; g++) ids[g] = e.mol.id[e.mol.find_name(b->tli.db[g].molecule)];
   std::fwrite(ids.data(), sizeof(int), M, fp);
   std::fwrite(tgrid.data(), sizeof(double), Nt, fp);
   std::fwrite(e.atm.press.data(), sizeof(double), L, fp);
   std::fwrite(e.wn_full.data(), sizeof(double), W, fp);
   // layers in slabs so the device buffer stays bounded: [nl][Nt][M][W]
-  const int slab = std::max(1, std::min(L, (int)((size_t)256 * 1024 * 1024 / ((size_t)Nt * M * W * 8) + 1)));
-  std::vector<double> host((size_t)slab * Nt * M * W);
+  const int slab = std::max(1, std::min(L, (int)((size_t)256 * 1024 * 1024 / ((size_t)Nt * G * W * 8) + 1)));
+  std::vector<double> host((size_t)slab * Nt * G * W), merged(M == G ? 0 : (size_t)slab * Nt * M * W);
   HIPCHK(hipMalloc(&d_out, host.size() * sizeof(double)));
   ensure_states(e, (long)slab * Nt, false);
   try {
@@ -1003,8 +1004,19 @@ void lbl_write_opacity(Engine &e, const std::string &path, const std::vector<dou
       aa.per_group = 1; aa.out = d_out;
       run_states(e, sa, aa, e.stream);
       HIPCHK(hipStreamSynchronize(e.stream));
-      HIPCHK(hipMemcpy(host.data(), d_out, sizeof(double) * (size_t)nl * Nt * M * W, hipMemcpyDeviceToHost));
-      std::fwrite(host.data(), sizeof(double), (size_t)nl * Nt * M * W, fp);
+      HIPCHK(hipMemcpy(host.data(), d_out, sizeof(double) * (size_t)nl * Nt * G * W, hipMemcpyDeviceToHost));
+      if (M == G) {
+        std::fwrite(host.data(), sizeof(double), (size_t)nl * Nt * M * W, fp);
+      } else {
+        std::fill(merged.begin(), merged.begin() + (size_t)nl * Nt * M * W, 0.0);
+        for (size_t pl = 0; pl < (size_t)nl * Nt; pl++)
+          for (int g = 0; g < G; g++) {
+            const double *src = host.data() + (pl * G + g) * W;
+            double *dst = merged.data() + (pl * M + slot[g]) * W;
+            for (int i = 0; i < W; i++) dst[i] += src[i];
+          }
+        std::fwrite(merged.data(), sizeof(double), (size_t)nl * Nt * M * W, fp);
+      }
     }
   } catch (...) {
     std::fclose(fp); std::remove(path.c_str());

@@ -653,6 +653,13 @@ bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t
 // ... and with the line-by-line extinction array as input (no table, 0-2 CIA pairs)
 bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
+// ... and for ray grids of 1 .. 9 angles other than five (rt_eclipse_angles.hip, one object per size)
+#define BARTRT_ANGLE_SIZES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(9)
+#define BARTRT_DECL_ANGLES(N) \
+  bool launch_rt_angles_##N(const RtArgs &b, int integ, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+BARTRT_ANGLE_SIZES(BARTRT_DECL_ANGLES)
+#undef BARTRT_DECL_ANGLES
+
 template <int INTEG>
 bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::string &kmode, bool force_window,
                     bool allow_sq, hipError_t &err, RtLaunchInfo *info) {
@@ -679,7 +686,31 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       return true;
     return false;
   }
-  if (!(a.A == 5 && !a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
+  if (!(!a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
+  if (a.A != 5) {
+    // other ray-grid sizes: the single-wave kernel of rule 0 / rule 1 at every batch size
+    if (INTEG == kIntegTrapzTau || a.A < 1 || a.A > 9 || kmode == "quad" || kmode == "octo" || kmode == "split") return false;
+    size_t sha = sh;
+    int nba = nblocks;
+    if (a.nprep > 0) {
+      sha = std::max(sh, sizeof(double) * prep_lds_doubles(a.prep_next.L, a.prep_next.S, a.prep_next.Nt, a.prep_next.ncia_temps));
+      nba += prep_slots(a.nprep);
+    }
+    if (info) {
+      info->kernel = INTEG == kIntegSimpson ? "rt_eclipse_simpson (ray grid of another size)" : "rt_eclipse_fast (ray grid of another size)";
+      info->wn_per_column = block; info->ncolumns = a.ntiles; info->prep_fused = a.nprep > 0;
+    }
+    err = hipSuccess;
+    bool done = false;
+    switch (a.A) {
+#define BARTRT_CASE_ANGLES(N) case N: done = launch_rt_angles_##N(a, INTEG, block, nba, sha, st, err); break;
+      BARTRT_ANGLE_SIZES(BARTRT_CASE_ANGLES)
+#undef BARTRT_CASE_ANGLES
+      default: break;
+    }
+    if (!done && info) info->prep_fused = false;
+    return done;
+  }
   // (the producer/consumer kernel adds 9 kB of its own)
   RtArgs b = a;
   const bool sq = allow_sq && order_angles_for_square(b);

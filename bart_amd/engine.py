@@ -69,13 +69,17 @@ def run_batch(profiles: np.ndarray, want_ok: bool = False):
     return (spec, ok) if want_ok else spec
 
 
-def get_tau():
-    """Optical depth of the last single-profile run: (tau[W_local, L], last[W_local]),
-    layer index 0 = top (the tau.dat convention, code/cf.py:68-94)."""
+def get_tau(walker=None):
+    """Optical depth of the latest host-buffer call's profile: (tau[W_local, L], last[W_local]),
+    layer index 0 = top (the tau.dat convention, code/cf.py:68-94).  After a batch call the
+    walker has to be named (include/bartrt.h, bartrt_get_tau_of)."""
     lo, hi = local_range()
     tau = np.zeros((hi - lo, nlayers()))
     last = np.zeros(hi - lo, np.int32)
-    _check(trm.lib().bartrt_get_tau(_ptr(tau), _ptr(last), hi - lo, nlayers()))
+    if walker is None:
+        _check(trm.lib().bartrt_get_tau(_ptr(tau), _ptr(last), hi - lo, nlayers()))
+    else:
+        _check(trm.lib().bartrt_get_tau_of(int(walker), _ptr(tau), _ptr(last), hi - lo, nlayers()))
     return tau, last
 
 

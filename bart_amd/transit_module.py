@@ -80,6 +80,8 @@ def lib():
         L.bartrt_get_species.argtypes = [C.c_char_p, i]
         L.bartrt_get_pressure.argtypes = [p, i]
         L.bartrt_get_tau.argtypes = [p, p, i, i]
+        L.bartrt_get_tau_of.argtypes = [i, p, p, i, i]
+        L.bartrt_get_intensity_of.argtypes = [i, p, i, i]
         L.bartrt_get_lbl_extinction.argtypes = [p, i, p, i, i]
         L.bartrt_voigt.argtypes = [p, p, p, C.c_long]
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]

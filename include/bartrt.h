@@ -10,11 +10,20 @@
  * library computes ONLY on the GPU: with no HIP device every compute entry
  * point fails with BARTRT_ENODEV -- there is no CPU fallback.
  *
- * Engine state is a process-global singleton, like the reference module's
- * (created by transit_init, destroyed by free_memory; BARTfunc.py:230,406).
- * Calls are not re-entrant: drive the engine from one host thread at a time
- * (the reference runs one engine per MPI process); the `_dev` entry points
- * are asynchronous on the stream they are given.
+ * Engine state is a process-global SINGLETON, like the reference module's
+ * (created by transit_init, destroyed by free_memory; BARTfunc.py:230,406):
+ *   - one engine, on one device, per process.  bartrt_init on a live engine REPLACES it
+ *     (the old one is destroyed first); a host that drives several GPUs runs one process per GPU (that is
+ *     how bench.py, bart_amd.retrieve and the MC3-driven worker shard a node), each with
+ *     "--device <n>" or LOCAL_RANK;
+ *   - calls are NOT re-entrant and not thread-safe: drive the engine from one host thread
+ *     at a time (the reference runs one engine per MPI process).  The launch state of the
+ *     kernels (variant switches read from the environment, the timing and walked-layer
+ *     records, the prefetch request) belongs to that one engine;
+ *   - the `_dev` entry points are asynchronous on the stream they are given; the others
+ *     return when their result is in the caller's buffer;
+ *   - the environment variables (BARTRT_INTEG, BARTRT_KERNEL, BARTRT_LBL, ...) are read
+ *     once per process or per bartrt_init, not per call.
  */
 #ifndef BARTRT_H
 #define BARTRT_H
@@ -194,9 +203,14 @@ int bartrt_get_nprof(void);                 /* (S+1)*L */
 int bartrt_get_local_range(int *lo, int *hi); /* shard's [lo,hi) of the grid */
 int bartrt_get_species(char *buf, int buflen); /* space-separated names */
 int bartrt_get_pressure(double *out, int n);   /* barye, atm order */
-/* optical depth of the last single-walker run: tau[nwave_local][L], layer
- * index 0 = top (the tau.dat convention read by code/cf.py:68-94). */
+/* optical depth of the latest HOST-buffer call's profile: tau[nwave_local][L], layer
+ * index 0 = top (the tau.dat convention read by code/cf.py:68-94); last[i] = the layer
+ * where the column of sample i ended.  bartrt_get_tau serves a single-profile call
+ * (bartrt_run_transit, the reference's shape); after a batch call it is an ERROR, not the
+ * first walker's or an older call's values: name the walker with bartrt_get_tau_of (the
+ * profile is re-run with the output enabled).  Device-buffer calls keep no profile. */
 int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers);
+int bartrt_get_tau_of(int walker, double *tau, int *last, int nwave, int nlayers);
 
 /* Outputs of the standalone run (reference: `transit -c cfg`, code/bestFit.py:421-427,
  * code/cf.py:46-64).  get_atm_profile: the (S+1)*L profile array of the atmosphere
@@ -208,6 +222,7 @@ int bartrt_get_radius(double *rad, int nlayers);
 int bartrt_get_nangles(void);
 int bartrt_get_angles(double *deg, int n);
 int bartrt_get_intensity(double *intens, int nangles, int nwave);
+int bartrt_get_intensity_of(int walker, double *intens, int nangles, int nwave);  /* as bartrt_get_tau_of */
 
 /* Line-by-line engines only (cfg has `linedb`, no `opacityfile`): the Voigt
  * extinction of one profile, ext[nlayers][nwave_local] in cm-1, atm layer order. */

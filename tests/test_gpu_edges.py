@@ -128,3 +128,31 @@ def test_walked_layer_record(tmp_path, mode):
         deepest = last[col * wpc:(col + 1) * wpc].max()
         assert deepest + 1 <= w[1, col] <= min(60, deepest + 1 + 8), (col, deepest, w[1, col])
     assert (w < 60).any()
+
+
+def test_table_goes_up_slab_by_slab(small_case, monkeypatch):
+    """bartrt_init uploads and re-lays the opacity grid out a bounded slab of (layer, temperature)
+    planes at a time (the whole grid used to sit on the device twice).  Slabs of one
+    plane, of seven (an uneven last slab) and the default give the same bits, unsharded and as a
+    wavenumber block."""
+    from bart_amd import engine, transit_module as trm
+    from test_gpu_parity import walkers
+    c = small_case
+    profs = walkers(c, 5, seed=12)
+    plane = 4 * 777 * 8          # four molecules x 777 samples
+    ref = {}
+    for slab in (None, plane, 7 * plane + 100):
+        if slab is None:
+            monkeypatch.delenv("BARTRT_INIT_SLAB_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("BARTRT_INIT_SLAB_BYTES", str(slab))
+        for shard in (None, (1, 3)):
+            engine.init(c.tcfg, shard=shard)
+            try:
+                got = engine.run_batch(profs)
+            finally:
+                trm.free_memory()
+            if slab is None:
+                ref[shard] = got
+            else:
+                assert np.array_equal(got, ref[shard]), (slab, shard)

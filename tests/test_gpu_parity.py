@@ -63,6 +63,39 @@ def test_tau_and_last_match_oracle(small_case):
         trm.free_memory()
 
 
+def test_tau_after_a_batch_needs_the_walker_named(small_case):
+    """bartrt_get_tau / _get_intensity serve the latest single-profile host call; after a batch they
+    refuse (no stale or silently-first-walker data) and bartrt_get_tau_of /
+    _get_intensity_of return the named walker's arrays."""
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = small_case
+    engine.init(c.tcfg)
+    try:
+        o = orc.OracleEngine(c.tcfg)
+        profs = walkers(c, 4, seed=21)
+        n = trm.get_no_samples()
+        engine.run_batch(profs)
+        with pytest.raises(trm.TransitError, match="batch"):
+            engine.get_tau()
+        inten = np.zeros((5, n))
+        assert trm.lib().bartrt_get_intensity(trm._ptr(inten), 5, n) < 0
+        for w in (0, 3):
+            tau, last = engine.get_tau(walker=w)
+            _, rtau, rlast = o.run(profs[w], want_tau=True)
+            assert np.array_equal(last, rlast)
+            np.testing.assert_allclose(tau, rtau, rtol=RTOL, atol=1e-300)
+            trm.check(trm.lib().bartrt_get_intensity_of(w, trm._ptr(inten), 5, n))
+            np.testing.assert_allclose(inten, o.intensity(profs[w]), rtol=RTOL)
+        with pytest.raises(trm.TransitError, match="walker index"):
+            engine.get_tau(walker=4)
+        trm.run_transit(profs[2], n)           # a single-profile call: the plain getter again
+        tau, last = engine.get_tau()
+        np.testing.assert_allclose(tau, o.run(profs[2], want_tau=True)[1], rtol=RTOL, atol=1e-300)
+    finally:
+        trm.free_memory()
+
+
 @pytest.mark.parametrize("nw", [1, 3, 17])
 def test_batch_matches_oracle(small_case, nw):
     from bart_amd import engine, transit_module as trm
@@ -403,5 +436,41 @@ def test_transparent_planet(tmp_path):
     engine.init(e.tcfg)
     try:
         np.testing.assert_allclose(engine.run_batch(profs), orc.OracleEngine(e.tcfg).run_batch(profs), rtol=RTOL)
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.parametrize("nang", [1, 2, 3, 4, 6, 7, 8, 9, 10])
+def test_ray_grids_of_other_sizes(tmp_path, nang):
+    """`raygrid` is free-form (examples/demo/BART_eclipse.cfg:135).  One to nine angles run the
+    single-wave kernels of rules 0 and 1 instantiated for that size (csrc/rt_eclipse_angles.hip),
+    ten the generic kernel; rule 2 always the generic one.  Against the oracle, with a cloud deck,
+    with one walker and with a batch, and with the next batch prefetched."""
+    import torch
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    grid = tuple(np.round(np.linspace(0.0, 84.0, nang), 3)) if nang > 1 else (35.0,)
+    c = synth.make_case(str(tmp_path), nlayers=37, nwave=300, raygrid=grid, tlow=400.0, thigh=3000.0, tempdelt=650.0)
+    engine.init(c.tcfg)
+    try:
+        profs = walkers(c, 12, seed=nang)
+        for rule in (1, 0, 2):
+            trm.set_integ(rule)
+            o = orc.OracleEngine(c.tcfg, integ=rule)
+            ref = o.run_batch(profs)
+            tol = dict(rtol=RTOL, atol=1e-12 * np.abs(ref).max() if rule == 1 else 0.0)
+            np.testing.assert_allclose(engine.run_batch(profs), ref, **tol)
+            np.testing.assert_allclose(engine.run_batch(profs[:1]), ref[:1], **tol)
+            d = torch.from_numpy(profs).cuda()
+            a, b = d[:6].contiguous(), d[6:].contiguous()
+            engine.run_batch_dev(a, next_prof=b)
+            got = engine.run_batch_dev(b).cpu().numpy()
+            np.testing.assert_allclose(got, ref[6:], **tol)
+            trm.set_cloudtop(-1.5); o.set_cloudtop(-1.5)
+            refc = o.run_batch(profs)
+            np.testing.assert_allclose(engine.run_batch(profs), refc,
+                                       rtol=RTOL, atol=1e-12 * np.abs(refc).max() if rule == 1 else 0.0)
+            assert not np.allclose(ref, refc)
+            trm.set_cloudtop(3.0); o.set_cloudtop(3.0)      # below the bottom layer: no deck
     finally:
         trm.free_memory()

@@ -49,7 +49,8 @@ def main():
     labels.append(lab)
     # the layer loop: the largest block that loops on itself (a peeled first block or a masked last
     # block may be larger: they run once per column); else the largest block
-    big = max((blocks[i] for i in loops), key=len) if loops else max(blocks, key=len)
+    cand = [blocks[i] for i in loops if len(blocks[i]) > 300]     # (a fused prep_body brings small loops of its own)
+    big = max(cand, key=len) if cand else max(blocks, key=len)
     cls = collections.Counter()
     for m in big:
         if m.startswith(FP64):

@@ -132,6 +132,10 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     if (const char *ev = std::getenv("BARTRT_INTEG")) if (*ev) v = ev;
     integ = parse_integ(v);
   }
+  // `voigt exact | grid` (line-by-line evaluation, lbl.hpp / DESIGN.md C18) is checked whether or
+  // not this engine ends up reading the lines
+  if (cfg_has(cfg, "voigt") && cfg["voigt"] != "exact" && cfg["voigt"] != "grid")
+    throw IoError{"voigt: '" + cfg["voigt"] + "' is neither exact nor grid"};
   atm = read_atm(cfg["atm"]);
   mol = read_molfile(cfg["molfile"]);
   L = (int)atm.press.size();
@@ -395,7 +399,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     // as a whole, so the lazy fused kernel (55 ms) loses to the eager two-pass form
     // (43 ms) that exposes all layers as parallel work; BARTRT_LBL=lazy selects it
     // (the fused kernel evaluates the line sums on the output points: no oversampling)
-    lbl_eager = !(m && std::string(m) == "lazy") || lbl->dev.osamp > 1;
+    lbl_eager = !(m && std::string(m) == "lazy") || lbl->dev.osamp > 1 || lbl->dev.voigt_grid;
   }
   HIPCHK(hipMalloc(&d_tau, sizeof(double) * (size_t)Wl * L));
   HIPCHK(hipMalloc(&d_last, sizeof(int) * (size_t)Wl));

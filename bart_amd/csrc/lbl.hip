@@ -14,6 +14,7 @@
 #include "lbl.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -248,6 +249,10 @@ struct AccArgs {
   const double *wn;
   const double *state, *smax;
   double *out;
+  // width-grid mode (LblDev::voigt_grid; Lbl's d_g* arrays)
+  const int *ginfo, *gK;
+  const long *goff, *gbase;   // gbase[state]: first double of the state's profiles in ptab
+  const double *ptab;
 };
 
 // ---------------------------------------------------------------------------
@@ -639,6 +644,196 @@ __global__ __launch_bounds__(64) void lbl_accumulate_fine(LblDev d, AccArgs a, i
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Width-grid Voigt evaluation (LblDev::voigt_grid).
+//
+// Nearest index of a half-width on a log-spaced grid (ln0, dln, n).
+__device__ __forceinline__ int grid_index(double a, double ln0, double dln, int n) {
+  if (n <= 1 || !(dln > 0.0)) return 0;
+  const double t = floor((log(a) - ln0) / dln + 0.5);
+  return t < 0.0 ? 0 : (t > (double)(n - 1) ? n - 1 : (int)t);
+}
+
+// Sampling point nearest to a line centre on a grid of spacing 1 / inv_step from wn_first:
+// product and sum rounded one after the other (the scalar restatement does the same).
+__device__ __forceinline__ long centre_index(double nu0, double wn_first, double inv_step) {
+  return (long)floor(add_rounded(mul_rounded(nu0 - wn_first, inv_step), 0.5));
+}
+
+// One wave per state, lane = isotope: which profiles the state needs -- the isotope's Lorentz
+// index, the run of Doppler indices its lines' centres span, the reach of each profile on the
+// state's sampling grid -- and where they go in the state's block of the profile buffer.
+__global__ __launch_bounds__(64) void lbl_grid_layout(LblDev d, const double *state, int *ginfo, int *gK, long *goff,
+                                                      long *gsize) {
+  const int st = blockIdx.x, k = threadIdx.x;
+  const double *sv = state + (size_t)st * (2 + 3 * d.niso);
+  const double step = d.wndelt / sv[1];
+  long mine = 0;
+  int iL = 0, iDa = 0, nD = 0;
+  if (k < d.niso) {
+    iL = grid_index(sv[3 + 3 * k], d.lor_ln0, d.lor_dln, d.nlor);
+    iDa = grid_index(d.nu_lo * sv[2 + 3 * k], d.dop_ln0, d.dop_dln, d.ndop);
+    const int iDb = grid_index(d.nu_hi * sv[2 + 3 * k], d.dop_ln0, d.dop_dln, d.ndop);
+    nD = min(iDb - iDa + 1, d.dspan);
+    for (int j = 0; j < nD; j++) {
+      const int K = (int)floor(d.nwidth * fmax(d.dgrid[iDa + j], d.lgrid[iL]) / step);
+      gK[((size_t)st * d.niso + k) * d.dspan + j] = K;
+      goff[((size_t)st * d.niso + k) * d.dspan + j] = mine;   // within the isotope's run; shifted below
+      mine += K + 1;
+    }
+    ginfo[((size_t)st * d.niso + k) * 3] = iL;
+    ginfo[((size_t)st * d.niso + k) * 3 + 1] = iDa;
+    ginfo[((size_t)st * d.niso + k) * 3 + 2] = nD;
+  }
+  long incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const long v = __shfl_up(incl, o);
+    if (k >= o) incl += v;
+  }
+  if (k < d.niso)
+    for (int j = 0; j < nD; j++) goff[((size_t)st * d.niso + k) * d.dspan + j] += incl - mine;
+  if (k == 63) gsize[st] = incl;
+}
+
+// exclusive scan of the states' sizes (in place: gsize[st] -> first double of state st; gsize[nstate] = total)
+__global__ void lbl_grid_scan(long *gsize, int nstate) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long run = 0;
+  for (int s = 0; s < nstate; s++) { const long n = gsize[s]; gsize[s] = run; run += n; }
+  gsize[nstate] = run;
+}
+
+// The profiles: block (Doppler index of the run, isotope, state), lanes over the offsets 0 .. K.
+// P_j = sqrt(ln 2 / pi) / aD * Re w(sqrt(ln 2) (j step + i aL) / aD) at the GRID widths.
+__global__ __launch_bounds__(256) void lbl_grid_profiles(LblDev d, const double *state, const int *ginfo, const int *gK,
+                                                         const long *goff, const long *gbase, double *ptab) {
+  const int j = blockIdx.x, k = blockIdx.y, st = blockIdx.z;
+  const int *gi = ginfo + ((size_t)st * d.niso + k) * 3;
+  if (j >= gi[2]) return;
+  const double *sv = state + (size_t)st * (2 + 3 * d.niso);
+  const double step = d.wndelt / sv[1];
+  const double aD = d.dgrid[gi[1] + j], aL = d.lgrid[gi[0]];
+  const double xs = kSqrtLn2 / aD, amp = kSqrtLn2 * kInvSqrtPi / aD, y = aL * xs;
+  const int K = gK[((size_t)st * d.niso + k) * d.dspan + j];
+  double *out = ptab + gbase[st] + goff[((size_t)st * d.niso + k) * d.dspan + j];
+  for (int o = threadIdx.x; o <= K; o += blockDim.x)
+    out[o] = mul_rounded(amp, voigt_k(mul_rounded(mul_rounded((double)o, step), xs), y));
+}
+
+// Accumulation by table lookup, every state (oversampled or not).  Line-major like
+// lbl_accumulate_fine: one wave per sub-tile of sampling points whose sums live in LDS; 64 lines
+// are staged at a time (lane = line: strength, threshold, the profile its widths select, the
+// sampling point nearest to its centre), then each kept line adds strength x profile[|k - kc|]
+// with lane = sampling point -- one load and one multiply-add per (line, point) instead of a
+// Faddeeva evaluation.  Every point adds its lines in list order, whatever the tiling.
+__global__ __launch_bounds__(64) void lbl_accumulate_grid(LblDev d, AccArgs a, int nfmax) {
+  extern __shared__ double s_dyn[];
+  double *s_fine = s_dyn;                                     // [nfmax]
+  double *s_amp = s_dyn + nfmax;                              // [64] line strengths
+  long *s_tab = reinterpret_cast<long *>(s_amp + 64);         // [64] profile offsets in ptab
+  int *s_rng = reinterpret_cast<int *>(s_tab + 64);           // [64][3]: first point, centre, last point (sub-tile index)
+  const int st = blockIdx.y;
+  const int tile0 = blockIdx.x * 64;
+  const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
+  const int dv = (int)sv[1], h = dv / 2;
+  const double invT = 1.0 / sv[0], step = d.wndelt / dv, inv_step = dv / d.wndelt;
+  const int lane = threadIdx.x;
+  const long kmax = (long)(d.wfull - 1) * dv;            // last sampling point of the full grid
+  const int tile_end = min(tile0 + 64, a.W);
+  const int TO = min(64, max(1, kFineTarget / dv));      // output points per sub-tile
+  const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
+  const int *gi_st = a.ginfo + (size_t)st * d.niso * 3;
+  const long base_st = a.gbase[st];
+  for (int o0 = tile0; o0 < tile_end; o0 += TO) {
+    const int o1 = min(o0 + TO, tile_end);               // output points [o0, o1)
+    const long c0 = (long)(d.i_off + o0) * dv, c1 = (long)(d.i_off + o1 - 1) * dv;
+    const long fa = max(c0 - h, 0L), fb = min(c1 + h, kmax);
+    const int nf = (int)(fb - fa + 1);
+    for (int p = lane; p < nf; p += 64) s_fine[p] = 0.0;
+    const double nu_a = d.wn_first + (double)fa * step, nu_b = d.wn_first + (double)fb * step;
+    wave_sync();
+    for (int g = g_lo; g < g_hi; g++) {
+      // window of the sorted list: the widest profile of the group's isotopes, plus the snap
+      double cmax = 0.0;
+      for (int k = 0; k < d.niso; k++)
+        if (d.iso_group[k] == g) {
+          const int *gi = gi_st + 3 * k;
+          cmax = fmax(cmax, d.nwidth * fmax(d.dgrid[gi[1] + gi[2] - 1], d.lgrid[gi[0]]));
+        }
+      cmax += 2.0 * step;
+      int b0 = (int)floor((nu_a - cmax - d.bmin) / d.bstep), b1 = (int)floor((nu_b + cmax - d.bmin) / d.bstep) + 1;
+      b0 = b0 < 0 ? 0 : (b0 > d.nbucket ? d.nbucket : b0);
+      b1 = b1 < 0 ? 0 : (b1 > d.nbucket ? d.nbucket : b1);
+      const long j0 = d.bucket[d.boff[g] + b0], j1 = d.bucket[d.boff[g] + b1];
+      const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
+      for (long base = j0; base < j1; base += 64) {
+        const long j = base + lane;
+        bool keep1 = false;
+        double Sj = 0.0;
+        long toff = 0;
+        int r0 = 0, rc = 0, r1 = -1;
+        if (j < j1) {
+          const int k = d.liso[j];
+          const double n0 = d.nu0[j];
+          Sj = line_strength(d.gf[j], d.elow[j], n0, sv[4 + 3 * k], invT);
+          if (Sj >= thresh && Sj > 0.0) {
+            const int *gi = gi_st + 3 * k;
+            int jd = grid_index(n0 * sv[2 + 3 * k], d.dop_ln0, d.dop_dln, d.ndop) - gi[1];
+            jd = jd < 0 ? 0 : (jd >= gi[2] ? gi[2] - 1 : jd);
+            const size_t slot = ((size_t)st * d.niso + k) * d.dspan + jd;
+            const int K = a.gK[slot];
+            const long kc = centre_index(n0, d.wn_first, inv_step);
+            const long lo = max(kc - K, fa), hi = min(kc + K, fb);
+            if (lo <= hi) {
+              keep1 = true;
+              toff = base_st + a.goff[slot];
+              r0 = (int)(lo - fa); r1 = (int)(hi - fa);
+              rc = (int)max(min(kc - fa, (long)INT_MAX / 2), (long)INT_MIN / 2);
+            }
+          }
+        }
+        const unsigned long long keep = __ballot(keep1);
+        const int cnt = __popcll(keep);
+        if (cnt == 0) continue;
+        if (keep1) {
+          const int pos = __popcll(keep & ((1ull << lane) - 1ull));   // list order
+          s_amp[pos] = Sj; s_tab[pos] = toff;
+          s_rng[3 * pos] = r0; s_rng[3 * pos + 1] = rc; s_rng[3 * pos + 2] = r1;
+        }
+        wave_sync();
+        for (int t = 0; t < cnt; t++) {
+          const double l_amp = s_amp[t];
+          const double *tab = a.ptab + s_tab[t];
+          const int klo = __builtin_amdgcn_readfirstlane(s_rng[3 * t]);
+          const int kc = __builtin_amdgcn_readfirstlane(s_rng[3 * t + 1]);
+          const int khi = __builtin_amdgcn_readfirstlane(s_rng[3 * t + 2]);
+          for (int k = klo + lane; k <= khi; k += 64)
+            s_fine[k] = add_rounded(s_fine[k], mul_rounded(l_amp, tab[abs(k - kc)]));
+        }
+        wave_sync();
+      }
+    }
+    wave_sync();
+    if (lane < o1 - o0) {
+      const int o = o0 + lane;
+      const long c = (long)(d.i_off + o) * dv;
+      const long lo = max(c - h, 0L), hi = min(c + h, kmax);
+      const bool even = (dv & 1) == 0;
+      double sum = 0.0, wsum = 0.0;
+      for (long f = lo; f <= hi; f++) {
+        const double wgt = (even && (f == c - h || f == c + h)) ? 0.5 : 1.0;
+        sum = fma(wgt, s_fine[f - fa], sum);
+        wsum += wgt;
+      }
+      const double v = sum / wsum;
+      if (a.per_group) a.out[((size_t)st * d.ngroup + blockIdx.z) * a.W + o] = v;
+      else a.out[(size_t)st * a.W + o] = v;
+    }
+    wave_sync();
+  }
+}
+
 // Fused lazy line-by-line + eclipse RT (see lbl.hpp).  One workgroup of 256
 // lanes per (wavenumber tile, walker); same per-layer arithmetic as
 // rt_eclipse, with the layer's line sum computed in place.
@@ -756,6 +951,7 @@ Lbl::~Lbl() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_nu0); fr(d_elow); fr(d_gf); fr(d_ztab); fr(d_ztemp); fr(d_liso);
   fr(d_state); fr(d_smax); fr(d_ext); fr(d_bucket); fr(d_dvmax);
+  fr(d_dgrid); fr(d_lgrid); fr(d_ginfo); fr(d_gK); fr(d_goff); fr(d_gsize); fr(d_ptab);
 }
 
 template <class T>
@@ -868,6 +1064,65 @@ void lbl_init(Engine &e, const std::string &paths) {
     d.i_off = e.lo;
     d.wfull = e.Wfull;
   }
+  // Voigt evaluation (LblDev, "Voigt evaluation"): `voigt exact` (default) or
+  // `voigt grid`, BARTRT_VOIGT overrides; grid sizes `ndop` / `nlor` (40 each), ranges `dmin` /
+  // `dmax` / `lmin` / `lmax` in cm-1.  Default ranges: Doppler half-widths of the TLI's isotopes
+  // over the line centres kept and the temperatures tlow .. thigh (defaults 500 / 3000 K, the
+  // opacity grid's keys); Lorentz half-widths over the atmosphere file's layers and
+  // abundances at those two temperatures.
+  {
+    std::string v = cfg_has(e.cfg, "voigt") ? e.cfg["voigt"] : "exact";
+    if (const char *ev = std::getenv("BARTRT_VOIGT")) if (*ev) v = ev;
+    if (v != "exact" && v != "grid") throw IoError{"voigt: '" + v + "' is neither exact nor grid"};
+    d.voigt_grid = v == "grid";
+    d.nu_lo = nu0.empty() ? e.wn_full.front() : *std::min_element(nu0.begin(), nu0.end());
+    d.nu_hi = nu0.empty() ? e.wn_full.back() : *std::max_element(nu0.begin(), nu0.end());
+    d.ndop = d.nlor = 1;
+    d.dspan = 1;
+    if (d.voigt_grid) {
+      const int nd = (int)cfg_num(e.cfg, "ndop", 40.0), nl = (int)cfg_num(e.cfg, "nlor", 40.0);
+      if (nd < 1 || nd > 4096 || nl < 1 || nl > 4096) throw IoError{"transit cfg: ndop / nlor must lie in 1 .. 4096"};
+      const double tlo = cfg_num(e.cfg, "tlow", 500.0), thi = cfg_num(e.cfg, "thigh", 3000.0);
+      if (!(tlo > 0) || !(thi >= tlo)) throw IoError{"transit cfg: bad tlow / thigh"};
+      double dmin = 1e300, dmax = 0.0, lmin = 1e300, lmax = 0.0;
+      for (int k = 0; k < d.niso; k++) {
+        const double mi = d.iso_mass[k] * kAMU;
+        auto dop = [&](double T) { return std::sqrt(2.0 * 0.6931471805599453 * kKB * T / mi) / kLS; };
+        dmin = std::min(dmin, d.nu_lo * dop(tlo));
+        dmax = std::max(dmax, d.nu_hi * dop(thi));
+        const int g = d.iso_group[k];
+        for (int l = 0; l < e.L; l++) {
+          double sum = 0.0;
+          for (int c : {e.iH2, e.iHe}) {
+            if (c < 0) continue;
+            const double dd = 0.5 * (d.gdiam[g] + e.mol.diam[e.mol.find_name(e.atm.species[c])] * 1e-8);
+            sum += e.atm.abund[(size_t)l * e.S + c] * dd * dd * std::sqrt(1.0 / mi + 1.0 / (e.mass[c] * kAMU));
+          }
+          auto lor = [&](double T) { return std::sqrt(2.0) / (kLS * std::sqrt(kPI * kKB * T)) * e.atm.press[l] * sum; };
+          if (sum > 0.0) { lmin = std::min(lmin, lor(thi)); lmax = std::max(lmax, lor(tlo)); }
+        }
+      }
+      if (!(lmax > 0.0)) { lmin = lmax = 1e-30; }   // no collider in the atmosphere file: pure Doppler profiles
+      dmin = cfg_num(e.cfg, "dmin", dmin); dmax = cfg_num(e.cfg, "dmax", dmax);
+      lmin = cfg_num(e.cfg, "lmin", lmin); lmax = cfg_num(e.cfg, "lmax", lmax);
+      if (!(dmin > 0) || !(dmax >= dmin) || !(lmin > 0) || !(lmax >= lmin))
+        throw IoError{"transit cfg: bad Voigt width-grid range (dmin / dmax / lmin / lmax)"};
+      auto logspace = [](double a, double b, int n, double &ln0, double &dln) {
+        std::vector<double> g(n);
+        ln0 = n > 1 ? std::log(a) : 0.5 * (std::log(a) + std::log(b));
+        dln = n > 1 ? (std::log(b) - std::log(a)) / (n - 1) : 0.0;
+        for (int i = 0; i < n; i++) g[i] = std::exp(ln0 + dln * i);
+        return g;
+      };
+      const std::vector<double> dg = logspace(dmin, dmax, nd, d.dop_ln0, d.dop_dln);
+      const std::vector<double> lg = logspace(lmin, lmax, nl, d.lor_ln0, d.lor_dln);
+      b->d_dgrid = upv(dg); b->d_lgrid = upv(lg);
+      d.dgrid = b->d_dgrid; d.lgrid = b->d_lgrid;
+      d.ndop = nd; d.nlor = nl;
+      // at one state an isotope's Doppler widths follow its lines' centres: a factor nu_hi / nu_lo
+      d.dspan = d.dop_dln > 0.0 ? std::min(nd, (int)std::ceil(std::log(d.nu_hi / d.nu_lo) / d.dop_dln) + 2) : 1;
+    }
+  }
   // free the host copy of the big arrays
   for (auto &db : t.db) { db.wn.clear(); db.wn.shrink_to_fit(); db.elow.clear(); db.elow.shrink_to_fit();
                           db.gf.clear(); db.gf.shrink_to_fit(); db.isoid.clear(); db.isoid.shrink_to_fit(); }
@@ -907,6 +1162,48 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
   HIPCHK(hipGetLastError());
   aa.W = e.W(); aa.nstate = sa.nstate; aa.wn = e.d_wn; aa.state = b->d_state; aa.smax = b->d_smax;
   aa.pair_reach = kPairReach;
+  if (d.voigt_grid) {
+    // width-grid mode: lay the states' profile tables out, size the buffer, tabulate, accumulate
+    const long ns = sa.nstate;
+    if (ns > b->cap_gstate) {
+      HIPCHK(hipDeviceSynchronize());
+      auto re = [&](auto *&p, size_t n) {
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(*p)));
+      };
+      re(b->d_ginfo, (size_t)ns * d.niso * 3);
+      re(b->d_gK, (size_t)ns * d.niso * d.dspan);
+      re(b->d_goff, (size_t)ns * d.niso * d.dspan);
+      re(b->d_gsize, (size_t)ns + 1);
+      b->cap_gstate = ns;
+    }
+    hipLaunchKernelGGL(lbl_grid_layout, dim3(sa.nstate), dim3(64), 0, st, d, b->d_state, b->d_ginfo, b->d_gK,
+                       b->d_goff, b->d_gsize);
+    hipLaunchKernelGGL(lbl_grid_scan, dim3(1), dim3(1), 0, st, b->d_gsize, sa.nstate);
+    HIPCHK(hipGetLastError());
+    long total = 0;
+    int dvmax = 0;
+    HIPCHK(hipMemcpyAsync(&total, b->d_gsize + ns, sizeof(long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&dvmax, b->d_dvmax, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (total > b->cap_ptab) {
+      if (b->d_ptab) HIPCHK(hipFree(b->d_ptab));
+      b->d_ptab = nullptr;
+      HIPCHK(hipMalloc(&b->d_ptab, std::max<size_t>((size_t)total, 1) * sizeof(double)));
+      b->cap_ptab = total;
+    }
+    hipLaunchKernelGGL(lbl_grid_profiles, dim3(d.dspan, d.niso, sa.nstate), dim3(256), 0, st, d, b->d_state,
+                       b->d_ginfo, b->d_gK, b->d_goff, b->d_gsize, b->d_ptab);
+    HIPCHK(hipGetLastError());
+    aa.ginfo = b->d_ginfo; aa.gK = b->d_gK; aa.goff = b->d_goff; aa.gbase = b->d_gsize; aa.ptab = b->d_ptab;
+    const int nfmax = std::max(kFineTarget, std::max(dvmax, 1)) + 1;
+    const size_t sh = sizeof(double) * ((size_t)nfmax + 64) + sizeof(long) * 64 + sizeof(int) * 3 * 64;
+    hipLaunchKernelGGL(lbl_accumulate_grid, dim3((aa.W + 63) / 64, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(64),
+                       sh, st, d, aa, nfmax);
+    HIPCHK(hipGetLastError());
+    return;
+  }
   const int ntile = (aa.W + 255) / 256;
   hipLaunchKernelGGL(lbl_accumulate, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
                      0, st, d, aa);

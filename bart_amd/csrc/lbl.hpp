@@ -39,6 +39,16 @@ struct LblDev {
   int osamp, osamp_rule, ndiv, i_off, wfull;
   int odiv[64];                  // divisors of osamp, ascending
   double wn_first, wndelt;
+  // Voigt evaluation (cfg `voigt`; SURVEY.md App. A-5 as recalled): 0 = the
+  // Faddeeva function per (line, point) at the line's own widths; 1 = WIDTH GRID: profiles are
+  // tabulated once per state on a grid of ndop Doppler x nlor Lorentz half-widths (log spaced,
+  // dgrid / lgrid), a line takes the profile of the nearest grid widths, centred on the sampling
+  // point nearest to its centre and reaching floor(nwidth max(aD, aL) / step) points either side.
+  int voigt_grid, ndop, nlor;
+  int dspan;                     // most Doppler-grid indices the lines of one isotope can span at one state
+  const double *dgrid, *lgrid;   // [ndop], [nlor] half-widths, cm-1
+  double dop_ln0, dop_dln, lor_ln0, lor_dln;   // ln of the first grid width and ln spacing (0: one width)
+  double nu_lo, nu_hi;           // range of the line centres kept (Doppler widths scale with the centre)
   // coarse index of the sorted lists: bucket[boff[g] + b] = first line of group g
   // with nu0 >= bmin + b * bstep (b = 0..nbucket; entry nbucket = gend[g])
   const long *bucket;
@@ -60,6 +70,14 @@ struct Lbl {
   double *d_ext = nullptr;       // [nstate][W] (extinction mode)
   int *d_dvmax = nullptr;        // largest oversampling factor among the states of a call
   long cap_state = 0;
+  // width-grid mode (LblDev::voigt_grid): the grids, and per call the profile tables
+  double *d_dgrid = nullptr, *d_lgrid = nullptr;
+  int *d_ginfo = nullptr;        // [nstate][niso][3]: Lorentz index, first Doppler index, Doppler indices used
+  int *d_gK = nullptr;           // [nstate][niso][dspan]: reach of profile (isotope, Doppler index), points either side
+  long *d_goff = nullptr;        // [nstate][niso][dspan]: its offset in d_ptab
+  long *d_gsize = nullptr;       // [nstate + 1]: profile doubles per state, then their total
+  double *d_ptab = nullptr;      // the profiles of the call, state after state
+  long cap_gstate = 0, cap_ptab = 0;
   ~Lbl();
 };
 

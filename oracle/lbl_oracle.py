@@ -20,6 +20,15 @@ fine points centred on the output point; an even factor takes dv + 1 points with
 the two end points at half weight, over dv; the first / last output point use
 the half of that window that lies on the grid, normalised by its own weights.
 wnosamp = 1: the line sums are evaluated on the output points themselves.
+
+Voigt evaluation (cfg key `voigt` of the product; SURVEY.md App. A-5 as recalled,
+unverified): "exact" evaluates the Faddeeva function per (line, point) at the line's own widths.
+"grid" is the width-grid form: ndop x nlor half-widths, log spaced between dmin .. dmax and
+lmin .. lmax (defaults: the Doppler half-widths of the TLI's isotopes over the kept line centres
+and tlow .. thigh, the Lorentz half-widths over the atmosphere file's layers at those two
+temperatures); a line takes the profile of the NEAREST grid widths (in the logarithm), centred on
+the sampling point nearest to its centre, reaching floor(nwidth max(aD_grid, aL_grid) / step)
+points either side; the profile values are Faddeeva values at the grid widths.
 """
 from __future__ import annotations
 
@@ -103,7 +112,7 @@ def downsample(fine: np.ndarray, dv: int) -> np.ndarray:
 
 
 class LblOracle:
-    def __init__(self, tcfg: str, osamp_rule: str = "divisor", wn_slice=None):
+    def __init__(self, tcfg: str, osamp_rule: str = "divisor", wn_slice=None, voigt=None):
         k = read_tcfg(tcfg)
         self.keys = k
         atm = read_atm(k["atm"])
@@ -124,8 +133,53 @@ class LblOracle:
         self.wndelt = d
         self.osamp = max(1, int(float(k.get("wnosamp", 1))))
         self.osamp_rule = osamp_rule
+        full = self.wn
         if wn_slice is not None:              # a block of the grid (its edges keep the full grid's)
             self.wn = self.wn[wn_slice[0]:wn_slice[1]]
+        self.voigt = voigt or k.get("voigt", "exact")
+        assert self.voigt in ("exact", "grid")
+        if self.voigt == "grid":
+            self._width_grids(k, full, atm)
+
+    def _width_grids(self, k, full, atm):
+        """The Doppler and Lorentz half-width grids as Engine / lbl_init lays them out."""
+        kept = np.concatenate([db["wn"][(db["wn"] >= full[0] - 500.0) & (db["wn"] <= full[-1] + 500.0)]
+                               for db in self.dbs])
+        nu_lo, nu_hi = (kept.min(), kept.max()) if len(kept) else (full[0], full[-1])
+        tlo, thi = float(k.get("tlow", 500.0)), float(k.get("thigh", 3000.0))
+        ih2 = self.species.index("H2") if "H2" in self.species else -1
+        ihe = self.species.index("He") if "He" in self.species else -1
+        dmin, dmax, lmin, lmax = np.inf, 0.0, np.inf, 0.0
+        for db in self.dbs:
+            sp = self.species.index(db["molecule"])
+            for info in db["isotopes"]:
+                mi = info["mass"] * AMU
+                dop = lambda T: np.sqrt(2.0 * np.log(2.0) * KB * T / mi) / LS
+                dmin, dmax = min(dmin, nu_lo * dop(tlo)), max(dmax, nu_hi * dop(thi))
+                for l in range(len(self.press)):
+                    s = sum(self.abund0[l][c] * (0.5 * (self.diam[sp] + self.diam[c])) ** 2
+                            * np.sqrt(1.0 / mi + 1.0 / (self.mass[c] * AMU)) for c in (ih2, ihe) if c >= 0)
+                    lor = lambda T: np.sqrt(2.0) / (LS * np.sqrt(np.pi * KB * T)) * self.press[l] * s
+                    if s > 0:
+                        lmin, lmax = min(lmin, lor(thi)), max(lmax, lor(tlo))
+        if not lmax > 0:
+            lmin = lmax = 1e-30
+        dmin, dmax = float(k.get("dmin", dmin)), float(k.get("dmax", dmax))
+        lmin, lmax = float(k.get("lmin", lmin)), float(k.get("lmax", lmax))
+        nd, nl = int(float(k.get("ndop", 40))), int(float(k.get("nlor", 40)))
+
+        def logspace(a, b, n):
+            ln0 = np.log(a) if n > 1 else 0.5 * (np.log(a) + np.log(b))
+            dln = (np.log(b) - np.log(a)) / (n - 1) if n > 1 else 0.0
+            return np.exp(ln0 + dln * np.arange(n)), ln0, dln
+        self.dgrid, self.d_ln0, self.d_dln = logspace(dmin, dmax, nd)
+        self.lgrid, self.l_ln0, self.l_dln = logspace(lmin, lmax, nl)
+
+    @staticmethod
+    def _nearest(a, ln0, dln, n):
+        if n <= 1 or not dln > 0:
+            return np.zeros(np.shape(a), int)
+        return np.clip(np.floor((np.log(a) - ln0) / dln + 0.5), 0, n - 1).astype(int)
 
     def layer_dv(self, T, p, q):
         """Oversampling factor of a layer (module docstring)."""
@@ -157,7 +211,7 @@ class LblOracle:
         """Extinction per database at one state, on the output grid: list of [W]
         arrays (evaluated dv times finer and reduced, see the module docstring)."""
         dv = self.layer_dv(T, p, q)
-        if dv == 1:
+        if dv == 1 and self.voigt == "exact":
             return self._layer_on(self.wn, T, p, q, per_gram)
         # fine grid over this block plus half an output spacing either side, clipped to the full grid
         h = dv // 2
@@ -170,7 +224,12 @@ class LblOracle:
         if dv % 2 == 0:
             w[0] = w[-1] = 0.5
         out = []
-        for fine in self._layer_on(fine_x, T, p, q, per_gram):
+        fines = (self._layer_on(fine_x, T, p, q, per_gram) if self.voigt == "exact"
+                 else self._layer_grid(ka, kb, dv, T, p, q, per_gram))
+        for fine in fines:
+            if dv == 1:
+                out.append(np.array(fine[k0 - ka: k1 - ka + 1]))
+                continue
             o = np.zeros(len(self.wn))
             for i in range(len(self.wn)):
                 c = k0 + i * dv
@@ -178,6 +237,57 @@ class LblOracle:
                 ww = w[lo - (c - h): hi - (c - h) + 1]
                 o[i] = np.dot(ww, fine[lo - ka: hi - ka + 1]) / ww.sum()
             out.append(o)
+        return out
+
+    def _strengths(self, db, T, p, q, per_gram):
+        """Per line of a database at one state: strength, Doppler and Lorentz half-widths."""
+        ih2 = self.species.index("H2") if "H2" in self.species else -1
+        ihe = self.species.index("He") if "He" in self.species else -1
+        sp = self.species.index(db["molecule"])
+        nu0, iso = db["wn"], db["iso"]
+        S = np.zeros(len(nu0)); aD = np.zeros(len(nu0)); aL = np.zeros(len(nu0))
+        for i, info in enumerate(db["isotopes"]):
+            m = iso == i
+            mi = info["mass"] * AMU
+            Z = np.interp(T, db["temps"], info["Z"])
+            scale = info["ratio"] / (Z * self.mass[sp] * AMU) if per_gram else info["ratio"] * q[sp] * p / (KB * T) / Z
+            S[m] = (SIGCTE * scale * db["gf"][m] * np.exp(-EXPCTE * db["elow"][m] / T)
+                    * (1.0 - np.exp(-EXPCTE * nu0[m] / T)))
+            aD[m] = nu0[m] / LS * np.sqrt(2.0 * np.log(2.0) * KB * T / mi)
+            s = sum(q[c] * (0.5 * (self.diam[sp] + self.diam[c])) ** 2 * np.sqrt(1.0 / mi + 1.0 / (self.mass[c] * AMU))
+                    for c in (ih2, ihe) if c >= 0)
+            aL[m] = np.sqrt(2.0) / (LS * np.sqrt(np.pi * KB * T)) * p * s
+        return S, aD, aL
+
+    def _layer_grid(self, ka, kb, dv, T, p, q, per_gram):
+        """Width-grid form (module docstring) on the sampling points ka .. kb of the full grid's
+        dv-fold refinement: list of arrays, one per database."""
+        step, inv_step = self.wndelt / dv, dv / self.wndelt
+        sl2 = np.sqrt(np.log(2.0))
+        out, cache = [], {}
+        for db in self.dbs:
+            e = np.zeros(kb - ka + 1)
+            inr = (db["wn"] >= self.wn_first - 500.0) & (db["wn"] <= self.wn_last + 500.0)   # the lines the engine keeps
+            S, aD, aL = self._strengths(db, T, p, q, per_gram)
+            S = np.where(inr, S, 0.0)
+            keep = (S >= self.ethresh * S.max()) & (S > 0)
+            iD = self._nearest(np.where(keep, aD, 1.0), self.d_ln0, self.d_dln, len(self.dgrid))
+            iL = self._nearest(np.where(keep, np.maximum(aL, 1e-300), 1.0), self.l_ln0, self.l_dln, len(self.lgrid))
+            for j in np.where(keep)[0]:
+                gd, gl = self.dgrid[iD[j]], self.lgrid[iL[j]]
+                K = int(np.floor(self.nwidth * max(gd, gl) / step))
+                kc = int(np.floor((db["wn"][j] - self.wn_first) * inv_step + 0.5))
+                lo, hi = max(kc - K, ka), min(kc + K, kb)
+                if lo > hi:
+                    continue
+                key = (iD[j], iL[j])
+                if key not in cache:
+                    o = np.arange(K + 1)
+                    cache[key] = sl2 / np.sqrt(np.pi) / gd * wofz(sl2 * (o * step + 1j * gl) / gd).real
+                prof = cache[key]
+                k = np.arange(lo, hi + 1)
+                e[lo - ka: hi - ka + 1] += S[j] * prof[np.abs(k - kc)]
+            out.append(e)
         return out
 
     def _layer_on(self, grid, T, p, q, per_gram):

@@ -176,6 +176,92 @@ def test_wnosamp_oversampling_matches_oracle(tmp_path, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(wnosamp=1),                                            # profiles on the output points
+    dict(wnosamp=4),
+    dict(wnosamp=2160),                                         # the reference cfgs' value
+    dict(wnosamp=2160, wndelt=1.0, nwave=40, nlines=150),       # 1 cm-1 sampling (demo): dv in the hundreds
+    dict(wnosamp=6, extra_keys=dict(ndop=7, nlor=5)),           # a coarse width grid
+    dict(wnosamp=6, extra_keys=dict(ndop=1, nlor=1)),           # one width each
+    dict(wnosamp=12, cia=True, ptop=1e-4, pbottom=30.0, nwidth=5, ethresh=1e-3),
+])
+def test_voigt_width_grid_matches_oracle(tmp_path, kw):
+    """`voigt grid` (SURVEY.md App. A-5 as recalled): profiles tabulated on a grid
+    of Doppler x Lorentz half-widths, a line takes the nearest widths' profile centred on the
+    sampling point nearest to its centre.  The table-lookup kernels against the oracle's
+    statement of the same rule (scipy Faddeeva values at the grid widths) -- extinction of the
+    whole engine and of its wavenumber blocks (bit for bit), the spectrum on top of it, and the
+    switch's other value: the exact evaluation differs, and is what `voigt exact` returns."""
+    import os
+    import subprocess
+    import sys
+    from bart_amd import synth_lbl
+    from oracle import lbl_oracle, rt_oracle as orc
+    kw = dict(kw)
+    extra = dict(kw.pop("extra_keys", {}), voigt="grid")
+    kw.setdefault("nlines", 900)
+    kw.setdefault("nwave", 150)
+    kw.setdefault("nlayers", 10)
+    c = synth_lbl.make_lbl_case(str(tmp_path), extra_keys=extra, **kw)
+    assert "voigt grid" in open(c.tcfg).read()
+    prof = c.profiles()
+    np.save(os.path.join(c.dir, "p.npy"), prof)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = lambda n: os.path.join(c.dir, n)
+    code = ("import numpy as np, sys, os; sys.path.insert(0, %r)\n"
+            "from bart_amd import engine, transit_module as trm\n"
+            "p = np.load(%r); out = []\n"
+            "for sh in (None, (0, 3), (1, 3), (2, 3)):\n"
+            "    engine.init(%r, shard=sh); out.append(engine.lbl_extinction(p))\n"
+            "    if sh is None: np.save(%r, engine.run_batch(np.array([p.ravel(), p.ravel()])))\n"
+            "    trm.free_memory()\n"
+            "np.save(%r, out[0]); np.save(%r, np.concatenate(out[1:], axis=1))\n"
+            "os.environ['BARTRT_VOIGT'] = 'exact'\n"
+            "engine.init(%r); np.save(%r, engine.lbl_extinction(p)); trm.free_memory()\n"
+            % (root, f("p.npy"), c.tcfg, f("spec.npy"), f("e.npy"), f("s.npy"), c.tcfg, f("x.npy")))
+    subprocess.check_call([sys.executable, "-c", code], timeout=600)
+    ext = np.load(f("e.npy"))
+    o = lbl_oracle.LblOracle(c.tcfg)
+    assert o.voigt == "grid"
+    ref = o.extinction(prof)
+    assert ref.max() > 0
+    np.testing.assert_allclose(ext, ref, rtol=RTOL, atol=1e-30 + 1e-13 * ref.max())
+    assert np.array_equal(np.load(f("s.npy")), ext)                     # sharded blocks: bit for bit
+    exact = lbl_oracle.LblOracle(c.tcfg, voigt="exact").extinction(prof)
+    np.testing.assert_allclose(np.load(f("x.npy")), exact, rtol=RTOL, atol=1e-30 + 1e-13 * exact.max())
+    assert np.abs(exact - ref).max() > 1e-4 * ref.max()                  # the two values of the switch differ
+    # the spectrum over the width-grid extinction (the oracle's RT on the oracle's extinction)
+    spec = np.load(f("spec.npy"))
+    assert np.array_equal(spec[0], spec[1]) and np.all(np.isfinite(spec))
+    oe = orc.OracleEngine(c.tcfg)
+    oe.set_extra_extinction(ref)
+    want = oe.run(prof)
+    np.testing.assert_allclose(spec[0], want, rtol=1e-6, atol=1e-9 * np.abs(want).max())
+
+
+@pytest.mark.gpu
+def test_voigt_width_grid_in_the_generated_opacity_grid(tmp_path):
+    """The `--justOpacity` step under `voigt grid`: the table mode of the same kernels."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle, rt_oracle as orc
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=300, nwave=90, nlayers=5, with_table=True, wnosamp=12,
+                                tlow=700.0, thigh=1900.0, tempdelt=600.0, ptop=1e-4, pbottom=1.0,
+                                extra_keys=dict(voigt="grid", ndop=12, nlor=9))
+    engine.init(c.tcfg)
+    try:
+        op = orc.read_opacity(c.keys["opacityfile"])
+        ref = lbl_oracle.LblOracle(c.tcfg).opacity_table(op["temps"])
+        np.testing.assert_allclose(op["kappa"], ref, rtol=RTOL, atol=1e-300 + 1e-13 * ref.max())
+        with pytest.raises(trm.TransitError, match="voigt"):
+            cfg2 = c.tcfg + ".bad"
+            open(cfg2, "w").write(open(c.tcfg).read().replace("voigt grid", "voigt lookup"))
+            trm.free_memory()
+            trm.transit_init(3, ["transit", "-c", cfg2])
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
 def test_wnosamp_in_the_generated_opacity_grid(tmp_path):
     """The `--justOpacity` step honours wnosamp too: grid mode of the same kernels."""
     from bart_amd import engine, synth_lbl, transit_module as trm

@@ -727,21 +727,27 @@ __global__ __launch_bounds__(256) void lbl_grid_profiles(LblDev d, const double 
 // sampling point nearest to its centre), then each kept line adds strength x profile[|k - kc|]
 // with lane = sampling point -- one load and one multiply-add per (line, point) instead of a
 // Faddeeva evaluation.  Every point adds its lines in list order, whatever the tiling.
+constexpr int kGridTile = 512;   // output points per workgroup of lbl_accumulate_grid on coarsely sampled states
 __global__ __launch_bounds__(64) void lbl_accumulate_grid(LblDev d, AccArgs a, int nfmax) {
   extern __shared__ double s_dyn[];
   double *s_fine = s_dyn;                                     // [nfmax]
-  double *s_amp = s_dyn + nfmax;                              // [64] line strengths
-  long *s_tab = reinterpret_cast<long *>(s_amp + 64);         // [64] profile offsets in ptab
-  int *s_rng = reinterpret_cast<int *>(s_tab + 64);           // [64][3]: first point, centre, last point (sub-tile index)
   const int st = blockIdx.y;
-  const int tile0 = blockIdx.x * 64;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
   const int dv = (int)sv[1], h = dv / 2;
+  // The launch has one workgroup per 64 output points.  A state sampled on (or near) the output
+  // points gives a line one step of 64 lanes per such tile: there every eighth workgroup takes
+  // 512 points and the others leave (eight steps per staged line: 7.4 -> 6.1 ms on config 5 at
+  // wnosamp 1).  Finely sampled states keep the small tiles (many short workgroups balance the
+  // chip better: 512-point tiles took config 5 at wnosamp 2160 from 22.6 to 27.7 ms).
+  const int tile = dv <= 8 ? kGridTile : 64;
+  if ((blockIdx.x * 64) % tile != 0) return;
+  const int tile0 = blockIdx.x * 64;
   const double invT = 1.0 / sv[0], step = d.wndelt / dv, inv_step = dv / d.wndelt;
   const int lane = threadIdx.x;
   const long kmax = (long)(d.wfull - 1) * dv;            // last sampling point of the full grid
-  const int tile_end = min(tile0 + 64, a.W);
-  const int TO = min(64, max(1, kFineTarget / dv));      // output points per sub-tile
+  const int tile_end = min(tile0 + tile, a.W);
+  // output points per sub-tile: about kFineTarget sampling points
+  const int TO = min(tile, max(1, kFineTarget / dv));
   const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
   const int *gi_st = a.ginfo + (size_t)st * d.niso * 3;
   const long base_st = a.gbase[st];
@@ -793,30 +799,26 @@ __global__ __launch_bounds__(64) void lbl_accumulate_grid(LblDev d, AccArgs a, i
             }
           }
         }
-        const unsigned long long keep = __ballot(keep1);
-        const int cnt = __popcll(keep);
-        if (cnt == 0) continue;
-        if (keep1) {
-          const int pos = __popcll(keep & ((1ull << lane) - 1ull));   // list order
-          s_amp[pos] = Sj; s_tab[pos] = toff;
-          s_rng[3 * pos] = r0; s_rng[3 * pos + 1] = rc; s_rng[3 * pos + 2] = r1;
-        }
-        wave_sync();
-        for (int t = 0; t < cnt; t++) {
-          const double l_amp = s_amp[t];
-          const double *tab = a.ptab + s_tab[t];
-          const int klo = __builtin_amdgcn_readfirstlane(s_rng[3 * t]);
-          const int kc = __builtin_amdgcn_readfirstlane(s_rng[3 * t + 1]);
-          const int khi = __builtin_amdgcn_readfirstlane(s_rng[3 * t + 2]);
+        // the kept lines one after the other, in list order; a line's strength, table and range
+        // come out of its staging lane's registers (v_readlane): no LDS traffic, no compaction
+        const int t_lo = (int)(unsigned)toff, t_hi = (int)(unsigned)((unsigned long long)toff >> 32);
+        const int s_lo = __double2loint(Sj), s_hi = __double2hiint(Sj);
+        for (unsigned long long live = __ballot(keep1); live; live &= live - 1) {
+          const int t = __builtin_ctzll(live);
+          const double l_amp = __hiloint2double(__builtin_amdgcn_readlane(s_hi, t), __builtin_amdgcn_readlane(s_lo, t));
+          const long off = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(t_hi, t) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane(t_lo, t));
+          const double *tab = a.ptab + off;
+          const int klo = __builtin_amdgcn_readlane(r0, t), kc = __builtin_amdgcn_readlane(rc, t);
+          const int khi = __builtin_amdgcn_readlane(r1, t);
           for (int k = klo + lane; k <= khi; k += 64)
             s_fine[k] = add_rounded(s_fine[k], mul_rounded(l_amp, tab[abs(k - kc)]));
         }
-        wave_sync();
       }
     }
     wave_sync();
-    if (lane < o1 - o0) {
-      const int o = o0 + lane;
+    for (int ob = o0 + lane; ob < o1; ob += 64) {
+      const int o = ob;
       const long c = (long)(d.i_off + o) * dv;
       const long lo = max(c - h, 0L), hi = min(c + h, kmax);
       const bool even = (dv & 1) == 0;
@@ -1198,9 +1200,9 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
     HIPCHK(hipGetLastError());
     aa.ginfo = b->d_ginfo; aa.gK = b->d_gK; aa.goff = b->d_goff; aa.gbase = b->d_gsize; aa.ptab = b->d_ptab;
     const int nfmax = std::max(kFineTarget, std::max(dvmax, 1)) + 1;
-    const size_t sh = sizeof(double) * ((size_t)nfmax + 64) + sizeof(long) * 64 + sizeof(int) * 3 * 64;
-    hipLaunchKernelGGL(lbl_accumulate_grid, dim3((aa.W + 63) / 64, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(64),
-                       sh, st, d, aa, nfmax);
+    const size_t sh = sizeof(double) * (size_t)nfmax;
+    hipLaunchKernelGGL(lbl_accumulate_grid, dim3((aa.W + 63) / 64, sa.nstate, aa.per_group ? d.ngroup : 1),
+                       dim3(64), sh, st, d, aa, nfmax);
     HIPCHK(hipGetLastError());
     return;
   }

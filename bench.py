@@ -415,7 +415,7 @@ def main():
     integ = trm.get_integ() if trm is not None else -1
     lo, hi = engine.local_range()
 
-    def timed(nwalk, steps, warmup, record, repeats=0, gather=None, prefetch=None):
+    def timed(nwalk, steps, warmup, record, repeats=0, gather=None, prefetch=None, before=None):
         """The contract's window -- `steps` passes of the hot path over batches of nwalk
         walkers between barriers -- and `repeats` more windows of the same length.  The
         batches cycle through a.nsets distinct seeded sets so that consecutive steps do
@@ -475,6 +475,8 @@ def main():
             sync()
             return time.perf_counter() - t0, t2 - t1, out_
 
+        if before is not None:       # untimed set-up work on the same batches (the byte model's passes)
+            before(profs_h, d_prof)
         out = None
         for i in range(warmup):
             out = step(i)
@@ -525,7 +527,24 @@ def main():
     nwalk = a.walkers * world if (sharded or world == 1) else a.walkers
     nspectra_per_step = a.walkers * world
     extras = not a.no_extras and not dry
-    main_run = timed(nwalk, a.steps, a.warmup, True, repeats=a.repeats if extras else 0)
+    models, kname_box = [], [""]
+
+    def byte_model_passes(profs_h, d_prof):
+        """What one launch has to move: untimed passes over the run's own batches with the kernels
+        recording how deep each wave walked (bartrt_walked_*).  Run BEFORE the warm-up and the
+        timed windows: set-up work, and the device is at its working clocks when the
+        contract's window starts."""
+        l0, h0 = engine.local_range()
+        d_out = torch.empty((profs_h.shape[1], h0 - l0), dtype=torch.float64, device=dev)
+        for sset in range(profs_h.shape[0]):
+            engine.walked_begin()
+            engine.run_batch_dev(d_prof[sset], d_out)
+            torch.cuda.synchronize()
+            walked, wpc, kname_box[0] = engine.walked_end()
+            models.append(launch_byte_model(case, profs_h[sset], walked, wpc, h0 - l0))
+
+    main_run = timed(nwalk, a.steps, a.warmup, True, repeats=a.repeats if extras else 0,
+                     before=byte_model_passes if (rank == 0 and not dry) else None)
     dt, kern_ms, nlaunch, ok, profs_all = (main_run[k] for k in ("dt", "kern_ms", "nlaunch", "ok", "profs"))
     profs0 = profs_all[0]
 
@@ -575,17 +594,9 @@ def main():
         value = nspectra_per_step * a.steps / dt
         alg = engine.algorithmic_bytes(nwalk)          # SURVEY 8d bytes per RT launch on this GPU
         per_launch_s = kern_ms / 1e3 / max(nlaunch, 1)
-        # ---- what one launch has to move: untimed passes over the same batches with
-        # the kernels recording how deep each wave walked (bartrt_walked_*)
         nsets = profs_all.shape[0]
-        models, kname = [], ""
+        kname = kname_box[0]
         d_out = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
-        for sset in range(nsets):
-            engine.walked_begin()
-            engine.run_batch_dev(main_run["d_prof"][sset], d_out)
-            torch.cuda.synchronize()
-            walked, wpc, kname = engine.walked_end()
-            models.append(launch_byte_model(case, profs_all[sset], walked, wpc, hi - lo))
         mean = lambda key: float(np.mean([m[key] for m in models]))
         uniq, eff, wfrac = mean("unique_bytes"), mean("effective_bytes"), mean("layers_walked_frac")
         # ---- cold launches: a 1 GiB scratch sweep in front of each (L2 and the 256 MiB Infinity

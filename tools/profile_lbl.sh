@@ -14,7 +14,13 @@ rocprofv3 --kernel-trace --stats -d "$out/stats_o1" --output-format csv -- pytho
 rocprofv3 --kernel-trace --stats -d "$out/stats_o2160" --output-format csv -- python3 "$root/tools/lbl_bench.py" --wnosamp 2160 > "$out/o2160.json" 2> "$out/o2160.err"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d "$out/sq_o1" --output-format csv -- python3 "$root/tools/lbl_bench.py" --reps 2 > "$out/sq_o1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d "$out/sq_o2160" --output-format csv -- python3 "$root/tools/lbl_bench.py" --reps 2 --wnosamp 2160 > "$out/sq_o2160.log" 2>&1
+# the width-grid evaluation (cfg `voigt grid`)
+BARTRT_VOIGT=grid rocprofv3 --kernel-trace --stats -d "$out/stats_grid_o1" --output-format csv -- python3 "$root/tools/lbl_bench.py" > "$out/grid_o1.json" 2> "$out/grid_o1.err"
+BARTRT_VOIGT=grid rocprofv3 --kernel-trace --stats -d "$out/stats_grid_o2160" --output-format csv -- python3 "$root/tools/lbl_bench.py" --wnosamp 2160 > "$out/grid_o2160.json" 2> "$out/grid_o2160.err"
 cd "$root"
+python3 tools/collect_profiles.py "${tag}_lbl_grid" "$out/stats_grid_o1"
+python3 tools/collect_profiles.py "${tag}_lbl_grid_o2160" "$out/stats_grid_o2160"
+grep -h '^{' "$out/grid_o1.json" "$out/grid_o2160.json" > "profiles/${tag}_lbl_grid_bench.jsonl"
 python3 tools/collect_profiles.py "${tag}_lbl" "$out/stats_o1"
 python3 tools/collect_profiles.py "${tag}_lbl_o2160" "$out/stats_o2160"
 grep -h '^{' "$out/o1.json" "$out/o2160.json" > "profiles/${tag}_lbl_bench.jsonl"

@@ -11,6 +11,13 @@ export TMPDIR=/tmp
 B="--steps 200 --warmup 20 --no-cpu --no-extras"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$out/stats_w10" --output-format csv -- python3 "$root/bench.py" $B > "$out/stats_w10.log" 2>&1
+# the integration rules side by side: rule 0 and rule 1 (the default) at 10 and 256 walkers
+rocprofv3 --kernel-trace --stats -d "$out/stats_w10_i0" --output-format csv -- python3 "$root/bench.py" $B --integ 0 > "$out/stats_w10_i0.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w10_i1" --output-format csv -- python3 "$root/bench.py" $B --integ 1 > "$out/stats_w10_i1.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w256_i0" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras --walkers 256 --integ 0 > "$out/stats_w256_i0.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_w256_i1" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras --walkers 256 --integ 1 > "$out/stats_w256_i1.log" 2>&1
+# the plain sequence (every step its own prep_profiles launch) for the per-kernel split of a step
+rocprofv3 --kernel-trace --stats -d "$out/stats_w10_nopf" --output-format csv -- python3 "$root/bench.py" $B --no-prefetch > "$out/stats_w10_nopf.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/stats_w1" --output-format csv -- python3 "$root/bench.py" $B --walkers 1 > "$out/stats_w1.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/stats_w256" --output-format csv -- python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras --walkers 256 > "$out/stats_w256.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu --no-extras > "$out/pmc_fetch.log" 2>&1
@@ -24,6 +31,10 @@ python3 tools/collect_profiles.py "${tag}_6mol2cia" "$out/stats_6mol2cia"
 cp "$out/stats_transit.log" "profiles/${tag}_transit_bench.jsonl"; cp "$out/stats_6mol2cia.log" "profiles/${tag}_6mol2cia_bench.jsonl"
 python3 tools/collect_profiles.py "${tag}_w10" "$out/stats_w10" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_calib"
 python3 tools/collect_profiles.py "${tag}_w1" "$out/stats_w1"
+for v in w10_i0 w10_i1 w256_i0 w256_i1 w10_nopf; do python3 tools/collect_profiles.py "${tag}_$v" "$out/stats_$v"; done
+# L2 hits / misses of the RT launch (the figures DESIGN.md section 6 quotes)
+bash tools/pmc_pass.sh tcc "TCC_HIT_sum TCC_MISS_sum" > "profiles/${tag}_tcc.jsonl" 2>&1
+grep -q '"kernel"' "profiles/${tag}_tcc.jsonl" || bash tools/pmc_pass.sh tcc "TCC_HIT TCC_MISS" > "profiles/${tag}_tcc.jsonl" 2>&1
 python3 tools/collect_profiles.py "${tag}_w256" "$out/stats_w256"
 # instruction mix of the build (the bench line's fp64 figure is computed from it)
 python3 tools/isa_stats.py > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq.txt"

@@ -105,6 +105,20 @@ int bartrt_set_integ(int rule) {
   return BARTRT_OK;
 }
 
+int bartrt_set_cut(int slant) {
+  NEED_ENGINE();
+  if (slant != 0 && slant != 1) return fail(BARTRT_EINVAL, "set_cut: 0 (vertical) or 1 (slant)");
+  g_eng->cut_slant = slant != 0;
+  return BARTRT_OK;
+}
+
+int bartrt_get_cut(int *slant) {
+  NEED_ENGINE();
+  if (!slant) return fail(BARTRT_EINVAL, "get_cut: null output pointer");
+  *slant = g_eng->cut_slant ? 1 : 0;
+  return BARTRT_OK;
+}
+
 int bartrt_prefetch_profiles_dev(const double *d_prof_next, int nwalkers) {
   NEED_ENGINE();
   if (nwalkers < 0 || (nwalkers > 0 && !d_prof_next)) return fail(BARTRT_EINVAL, "prefetch_profiles_dev: null buffer");

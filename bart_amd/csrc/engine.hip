@@ -136,6 +136,13 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   // not this engine ends up reading the lines
   if (cfg_has(cfg, "voigt") && cfg["voigt"] != "exact" && cfg["voigt"] != "grid")
     throw IoError{"voigt: '" + cfg["voigt"] + "' is neither exact nor grid"};
+  // `cut vertical | slant`: which optical depth `toomuch` is compared with
+  {
+    std::string v = cfg_has(cfg, "cut") ? cfg["cut"] : "vertical";
+    if (const char *ev = std::getenv("BARTRT_CUT")) if (*ev) v = ev;
+    if (v != "vertical" && v != "slant") throw IoError{"cut: '" + v + "' is neither vertical nor slant"};
+    cut_slant = v == "slant";
+  }
   atm = read_atm(cfg["atm"]);
   mol = read_molfile(cfg["molfile"]);
   L = (int)atm.press.size();
@@ -453,7 +460,7 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
   // per-walker workspaces (records, flags) are sized by cap_walkers; the
   // caller's profile and spectrum buffers are used in place
   if (n > cap_walkers && d_prof_in != d_prof) ensure_walkers(n);
-  if (lbl && solution == 0 && !want_tau && !want_intens && !lbl_eager && integ == 0) {
+  if (lbl && solution == 0 && !want_tau && !want_intens && !lbl_eager && integ == 0 && !cut_slant) {
     // lazy fused path: layers' line sums are evaluated only as deep as the
     // optical depth requires
     run_chunk(d_prof_in, n, d_spec_out, d_okp, st, false, nullptr, true);
@@ -556,6 +563,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   }
   r.cloud_on = has_cloud || over_cloud;
   r.integ = integ;
+  r.cut_slant = cut_slant ? 1 : 0;
   r.toomuch = toomuch;
   r.spec = d_spec_out;
   r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;

@@ -35,6 +35,7 @@ struct Engine {
   int scat_flag = 0, iH2 = -1, iHe = -1, has_cloud = 0;
   int solution = 0;       // 0 eclipse (emergent flux), 1 transit (modulation)
   int integ = 0;          // integration rule of the eclipse geometry (integ.hpp); cfg `integ`, BARTRT_INTEG
+  bool cut_slant = false; // cfg `cut slant` / BARTRT_CUT: the toomuch cut per ray angle, on its slant depth (C19)
   double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;
   double cloud_rup = 0, cloud_rdown = 0, cloud_ext = 0;  // radius-ramp cloud (cm, cm, cm-1); 0 = none

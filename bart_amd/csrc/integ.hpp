@@ -267,6 +267,52 @@ struct ColumnIntens<kIntegSimpson, AMAX> {
   }
 };
 
+// One ray angle's emergent intensity with the `toomuch` cut on ITS slant depth (cfg `cut slant`,
+// DESIGN.md C19; generic kernel only): the angle has its own last layer and, under rule 1, its own
+// padded point one unit of SLANT depth further.  Works in the slant depth x = tau / mu throughout,
+// so the result is I_a itself.  point(live, x, B, E): layer by layer from the top.
+template <int INTEG>
+struct SlantRay {
+  double I = 0.0, P1 = 0.0, y1 = 0.0, y2 = 0.0, x1 = 0.0, x2 = 0.0, Bprev = 0.0, Eprev = 1.0;
+  int n = 0;
+  __device__ __forceinline__ void simpson_point(bool live, double x, double y) {
+    const double h0 = x1 - x2, h1 = x - x1;
+    double w0, w1, w2;
+    simpson_tau_weights(h0, h1, w0, w1, w2);
+    const bool second = n == 1, odd = (n & 1) != 0;
+    w0 = second ? 0.0 : w0;
+    w1 = second ? 0.5 * h1 : w1;
+    w2 = second ? 0.5 * h1 : w2;
+    const double c = fma(w0, y2, fma(w1, y1, w2 * y));
+    I += (live && n >= 2 && !odd) ? c : 0.0;      // panels that end on even points
+    P1 += (live && n >= 1 && odd) ? c : 0.0;      // ... on odd points (starts with the first interval's trapezoid)
+    y2 = live ? y1 : y2; y1 = live ? y : y1;
+    x2 = live ? x1 : x2; x1 = live ? x : x1;
+    n += live ? 1 : 0;
+  }
+  __device__ __forceinline__ void point(bool live, double x, double B, double E) {
+    if (INTEG == kIntegTransmittance) {
+      I += live ? 0.5 * (Bprev + B) * (Eprev - E) : 0.0;
+    } else if (INTEG == kIntegTrapzTau) {
+      I += live ? 0.5 * (y1 + B * E) * (x - x1) : 0.0;
+      y1 = live ? B * E : y1; x1 = live ? x : x1;
+    } else {
+      simpson_point(live, x, B * E);
+    }
+    Bprev = live ? B : Bprev;
+    Eprev = live ? E : Eprev;
+  }
+  // deck: the ray reached the cloud deck below toomuch (its surface term B E of the last layer)
+  __device__ __forceinline__ double result(bool deck, int L) {
+    double r = I;
+    if (INTEG == kIntegSimpson) {
+      simpson_point(!deck && n < L, x1 + 1.0, 0.0);
+      r = ((n - 1) & 1) ? P1 : I;
+    }
+    return deck ? r + Bprev * Eprev : r;
+  }
+};
+
 // sum_a (w_a / mu_a) E_a
 template <int AMAX>
 __device__ __forceinline__ double angle_sum_q(const RtArgs &p, const double (&E)[AMAX]) {

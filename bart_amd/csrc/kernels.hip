@@ -87,17 +87,17 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
 
   constexpr int AMAX = AT > 0 ? AT : kMaxAngles;
   TauColumn<INTEG> tc;
-  ColumnIntens<INTEG, AMAX> ci;
   double Bprev = 0.0;
   bool active = true;
   int last = 0;
   const int kraw = p.kstop[w], kend = kstop_layer(kraw);
   const bool deck_on = kstop_deck(kraw);
   int k = 0;
-  for (; k <= kend; ++k) {
-    const double *c = sC + k * NC;
-    const idx_t *ix = sI + k * NI;
-    const int l = L - 1 - k;
+  // extinction of layer k for this lane
+  auto extinction = [&](int kk) {
+    const double *c = sC + kk * NC;
+    const idx_t *ix = sI + kk * NI;
+    const int l = L - 1 - kk;
     double e = c[2 + 2 * M + 2 * C] * nu4 + c[3 + 2 * M + 2 * C];   // Rayleigh + grey cloud
     if (p.ext) e += p.ext[((size_t)w * L + l) * W + ii];
     // grid [plane][W][M], CIA [pair plane][W][2] (kernels.hpp, "Table layout")
@@ -113,25 +113,64 @@ __global__ __launch_bounds__(256) void rt_eclipse(RtArgs p) {
       const double *ab = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.cia) + ix[1 + cc]) + 2 * (size_t)ii;
       e += c[2 + 2 * M + 2 * cc] * ab[0] + c[3 + 2 * M + 2 * cc] * ab[1];
     }
-    tc.layer(k, active, active ? 0.5 : 0.0, e, c[0], sW);
-    const double B = bnum * rcp_n1(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
-    double E[AMAX];
+    return e;
+  };
+  double Ia[AMAX];
+  double F = 0.0;
+  if (p.cut_slant) {
+    // `cut slant`: every ray angle ends on the first layer whose SLANT depth passes
+    // toomuch; the column is walked while any of them is alive (the vertical ray is the last to go)
+    SlantRay<INTEG> ray[AMAX];
+    bool alive[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) alive[a] = a < A;
+    for (; k <= kend; ++k) {
+      const double *c = sC + k * NC;
+      tc.layer(k, active, active ? 0.5 : 0.0, extinction(k), c[0], sW);
+      const double B = bnum * rcp_n1(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
+      bool any = false;
+#pragma unroll
+      for (int a = 0; a < AMAX; a++) {
+        if (AT <= 0 && a >= A) continue;
+        const double x = tc.tau * p.invmu[a];
+        ray[a].point(alive[a], x, B, exp_rt(fmax(-x, kExpMin)));
+        alive[a] = alive[a] && !(x > p.toomuch);
+        any = any || alive[a];
+      }
+      if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tc.tau;
+      if (active) last = k;
+      active = any;     // the optical depth is needed while a ray is alive
+      if (!__any(active)) break;
+    }
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
-      if (AT <= 0 && a >= A) { E[a] = 0.0; continue; }
-      E[a] = exp_rt(fmax(-tc.tau * p.invmu[a], kExpMin));
+      if (AT <= 0 && a >= A) { Ia[a] = 0.0; continue; }
+      Ia[a] = ray[a].result(deck_on && alive[a], L);
+      F += p.wgt[a] * Ia[a];
     }
-    ci.layer(A, active, active ? 0.5 : 0.0, tc.tau, Bprev, B, E);
-    Bprev = B;
-    if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tc.tau;
-    if (active) {
-      last = k;
-      if (tc.tau > p.toomuch) active = false;
+  } else {
+    ColumnIntens<INTEG, AMAX> ci;
+    for (; k <= kend; ++k) {
+      const double *c = sC + k * NC;
+      tc.layer(k, active, active ? 0.5 : 0.0, extinction(k), c[0], sW);
+      const double B = bnum * rcp_n1(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
+      double E[AMAX];
+#pragma unroll
+      for (int a = 0; a < AMAX; a++) {
+        if (AT <= 0 && a >= A) { E[a] = 0.0; continue; }
+        E[a] = exp_rt(fmax(-tc.tau * p.invmu[a], kExpMin));
+      }
+      ci.layer(A, active, active ? 0.5 : 0.0, tc.tau, Bprev, B, E);
+      Bprev = B;
+      if (p.tau_out && valid) p.tau_out[(size_t)i * L + k] = tc.tau;
+      if (active) {
+        last = k;
+        if (tc.tau > p.toomuch) active = false;
+      }
+      if (!__any(active)) break;
     }
-    if (!__any(active)) break;
+    F = ci.flux(p, A, deck_on && active, Bprev, L, Ia);
   }
-  double Ia[AMAX];
-  const double F = ci.flux(p, A, deck_on && active, Bprev, L, Ia);
   if (p.intens_out && valid) {
     for (int a = 0; a < A; a++) p.intens_out[(size_t)a * W + i] = Ia[a];
   }
@@ -206,7 +245,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *i
     const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
     return !(e && e[0] == '0');
   }();
-  if (kmode != "generic") {
+  if (kmode != "generic" && !a.cut_slant) {   // (the per-angle cut lives in the generic kernel)
     hipError_t err = hipSuccess;
     bool done = false;
     switch (a.integ) {

@@ -182,6 +182,7 @@ struct RtArgs {
   const int *kstop;        // per walker: last layer to integrate to, | kDeckBit when it is a cloud deck
   int cloud_on;            // some walker of the launch may carry a deck (wave-uniform hint; the deck itself is per walker)
   int integ;               // integration rule of the eclipse geometry (integ.hpp: 0 / 1 / 2)
+  int cut_slant;           // `toomuch` acts on each ray's slant depth tau / mu (cfg `cut slant`): generic kernel
   double toomuch;
   double invmu[kMaxAngles];
   double wgt[kMaxAngles];  // pi (sin^2 hi - sin^2 lo)

@@ -87,6 +87,8 @@ def lib():
         L.bartrt_timing_end.argtypes = [C.POINTER(d), C.POINTER(i)]
         L.bartrt_timing_begin_sampled.argtypes = [i]
         L.bartrt_set_integ.argtypes = [i]
+        L.bartrt_set_cut.argtypes = [i]
+        L.bartrt_get_cut.argtypes = [C.POINTER(i)]
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
@@ -157,6 +159,18 @@ def set_integ(rule):
     if isinstance(rule, str):
         rule = INTEG_RULES.index(rule)
     check(lib().bartrt_set_integ(int(rule)))
+
+
+def set_cut(cut):
+    """'vertical' (default) or 'slant': which optical depth `toomuch` is compared with
+    (include/bartrt.h, bartrt_set_cut)."""
+    check(lib().bartrt_set_cut({"vertical": 0, "slant": 1, 0: 0, 1: 1}[cut]))
+
+
+def get_cut() -> str:
+    v = C.c_int(-1)
+    check(lib().bartrt_get_cut(C.byref(v)))
+    return "slant" if v.value else "vertical"
 
 
 def get_integ() -> int:

@@ -565,15 +565,25 @@ def main():
         if a.integ is not None:
             trm.set_integ(a.integ)
 
+    def guarded(name, fn):
+        """An extra leg must not take the contract's line down (single rank only: it has no collectives)."""
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001
+            print("bench.py: extra leg %s failed: %r" % (name, e), file=sys.stderr)
+            return {"error": repr(e)}
+
     sweep = {}
     if world == 1 and a.sweep and extras:
-        for b in [int(x) for x in a.sweep.split(",") if x]:
+        def one_batch(b):
             k = max(16, min(50, 4000 // b))
             r = timed(b, k, 8, True)
             skm, snl = r["kern_ms"], r["nlaunch"]
-            sweep[str(b)] = {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
-                             "rt_kernel_ms": skm / max(snl, 1),
-                             "survey8d_algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
+            return {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
+                    "rt_kernel_ms": skm / max(snl, 1),
+                    "survey8d_algorithmic_GBps": engine.algorithmic_bytes(b) / (skm / max(snl, 1) / 1e3) / 1e9}
+        for b in [int(x) for x in a.sweep.split(",") if x]:
+            sweep[str(b)] = guarded("batch_sweep %d" % b, lambda: one_batch(b))
 
     if rank == 0 and dry:
         assert ok
@@ -602,7 +612,8 @@ def main():
         # ---- cold launches: a 1 GiB scratch sweep in front of each (L2 and the 256 MiB Infinity
         # Cache hold nothing of the tables: every compulsory byte comes from HBM)
         cold = None
-        if extras and world == 1:
+
+        def cold_pass():
             scratch = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
             cms = []
             for j in range(12):
@@ -615,12 +626,14 @@ def main():
                 cms.append(ms / max(n, 1))
             del scratch
             cmed = float(np.median(cms))
-            cold = {"launch_ms": _stats(cms), "achieved_GBps": uniq / (cmed / 1e3) / 1e9,
+            return {"launch_ms": _stats(cms), "achieved_GBps": uniq / (cmed / 1e3) / 1e9,
                     "frac": uniq / (cmed / 1e3) / 1e9 / PEAK_HBM_GBS,
                     "note": "RT kernel after a 1 GiB read-modify-write of a scratch buffer (4x the Infinity Cache): "
                             "the launch's compulsory bytes all come from HBM; the warm figure above is taken in "
                             "the timed loop, where consecutive batches share most table planes through the "
                             "256 MiB Infinity Cache, and is an upper bound on DRAM utilisation"}
+        if extras and world == 1:
+            cold = guarded("cold", cold_pass)
         # ---- committed profiler figures of THIS build (tools/profile_round.sh), if any
         sid = source_id()
         same = lambda j: (j.get("source_id") == sid and j.get("walkers") == nwalk and j.get("nwave") == a.nwave
@@ -725,13 +738,15 @@ def main():
             "source_id": sid,
         }
         if extras and world == 1 and not a.no_prefetch:
-            r = timed(nwalk, a.steps, a.warmup, True, repeats=4, prefetch=False)
-            res["no_prefetch"] = {
-                "note": "the same windows with every step launching its own prep_profiles kernel (what an MCMC "
-                        "step whose proposal depends on the previous spectra has to do)",
-                "ms_per_step": _stats(r["windows_ms"]),
-                "spectra_per_s_median": nspectra_per_step / (np.median(r["windows_ms"]) / 1e3),
-                "rt_kernel_ms": r["kern_ms"] / max(r["nlaunch"], 1)}
+            def plain():
+                r = timed(nwalk, a.steps, a.warmup, True, repeats=4, prefetch=False)
+                return {
+                    "note": "the same windows with every step launching its own prep_profiles kernel (what an MCMC "
+                            "step whose proposal depends on the previous spectra has to do)",
+                    "ms_per_step": _stats(r["windows_ms"]),
+                    "spectra_per_s_median": nspectra_per_step / (np.median(r["windows_ms"]) / 1e3),
+                    "rt_kernel_ms": r["kern_ms"] / max(r["nlaunch"], 1)}
+            res["no_prefetch"] = guarded("no_prefetch", plain)
         if main_run["diag"]:
             res["scaling_diag"] = main_run["diag"]
         if replicas:
@@ -742,26 +757,30 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
             # the three rules at 10 and 256 walkers
-            isw = {}
-            for rule in (0, 1, 2):
-                trm.set_integ(rule)
-                isw[str(rule)] = {"rule": INTEG_NAMES[rule]}
-                for b in (10, 256):
-                    k = 150 if b == 10 else 25
-                    r = timed(b, k, 10, True)
-                    isw[str(rule)][str(b)] = {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
-                                              "rt_kernel_us": r["kern_ms"] / max(r["nlaunch"], 1) * 1e3}
-            trm.set_integ(integ)
-            for b in ("10", "256"):
-                isw["rule1_over_rule0_rt_kernel_" + b] = isw["1"][b]["rt_kernel_us"] / isw["0"][b]["rt_kernel_us"]
-            res["integ_sweep"] = isw
+            def rules():
+                isw = {}
+                try:
+                    for rule in (0, 1, 2):
+                        trm.set_integ(rule)
+                        isw[str(rule)] = {"rule": INTEG_NAMES[rule]}
+                        for b in (10, 256):
+                            k = 150 if b == 10 else 25
+                            r = timed(b, k, 10, True)
+                            isw[str(rule)][str(b)] = {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
+                                                      "rt_kernel_us": r["kern_ms"] / max(r["nlaunch"], 1) * 1e3}
+                finally:
+                    trm.set_integ(integ)
+                for b in ("10", "256"):
+                    isw["rule1_over_rule0_rt_kernel_" + b] = isw["1"][b]["rt_kernel_us"] / isw["0"][b]["rt_kernel_us"]
+                return isw
+            res["integ_sweep"] = guarded("integ_sweep", rules)
             trm.free_memory()
             if a.kappa == "forest":
-                res["survey8d_workload"] = bench_configs.survey8d_leg(a, wd, integ, make_profiles, launch_byte_model,
-                                                                      PEAK_HBM_GBS)
-            res["configs"] = bench_configs.run_all(integ)
+                res["survey8d_workload"] = guarded("survey8d", lambda: bench_configs.survey8d_leg(
+                    a, wd, integ, make_profiles, launch_byte_model, PEAK_HBM_GBS))
+            res["configs"] = guarded("configs", lambda: bench_configs.run_all(integ))
         if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(case, integ)
+            res["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(case, integ))
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

@@ -90,6 +90,16 @@ int bartrt_free_memory(void);
 int bartrt_set_integ(int rule);
 int bartrt_get_integ(int *rule);
 
+/* Which optical depth `toomuch` is compared with (no counterpart in the reference's
+ * module).  0 (default) = the vertical depth: the column ends on one layer for every ray angle --
+ * the form every specialised kernel is built on.  1 = each ray's SLANT depth tau / mu: SURVEY.md
+ * App. A-4 read literally ("slant path ds = dr / cos(theta) ... stops where tau > toomuch"); every
+ * angle ends on its own layer and rule 1 pads one unit of slant depth; runs the generic kernel
+ * (3-10x slower).  The two differ by about exp(-toomuch) of the flux.  Also the cfg key
+ * `cut vertical|slant` and BARTRT_CUT. */
+int bartrt_set_cut(int slant);
+int bartrt_get_cut(int *slant);
+
 /* Prefetched preparation.  Names the profile batch of the bartrt_run_transit_batch_dev call
  * AFTER the next one: the next call's RT launch prepares that batch's layer records
  * (hydrostatic radii, densities, interpolation weights) in extra workgroups of its own grid,

@@ -263,15 +263,30 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
     last = k;
   }
   if (kend == 0) last = 0;
+  /* The `toomuch` cut (cfg `cut`).  vertical (default): the column ends on the
+   * first layer whose vertical optical depth passes toomuch, for every ray angle.  slant: App.
+   * A-4 read literally -- "slant path ds = dr / cos(theta); tau accumulated from the top; the
+   * loop stops where tau > toomuch" -- each ray ends on the first layer whose SLANT depth
+   * tau / mu passes toomuch (its own `last`), and rule 1's padded point sits one unit of SLANT
+   * depth further.  The optical depths themselves are the same numbers either way. */
+  int last_v = last;   /* (the slant cuts lie at or above the vertical one: mu <= 1) */
   for (int k = last + 1; k < L; k++) tau[k] = tau[last]; /* not computed deeper */
-  const int deck = kcloud >= 0 && last == kcloud && !(tau[last] > c->toomuch);
   double *f = (double *)malloc(sizeof(double) * (L + 1));
   double *bk = (double *)malloc(sizeof(double) * L);
   double *ek = (double *)malloc(sizeof(double) * L);
   double *hx = (double *)malloc(sizeof(double) * (L + 1));
-  for (int k = 0; k <= last; k++) bk[k] = orc_planck(wn, t_col[k]);
+  for (int k = 0; k <= last_v; k++) bk[k] = orc_planck(wn, t_col[k]);
   for (int a = 0; a < A; a++) {
     double mu = cos(c->angles_deg[a] * ORC_PI / 180.0);
+    int last = last_v;
+    if (c->cut_slant) {
+      last = kend;
+      for (int k = 1; k <= kend; k++)
+        if (tau[k] / mu > c->toomuch) { last = k; break; }
+      if (last > last_v) last = last_v;
+    }
+    const int deck = kcloud >= 0 && last == kcloud &&
+                     !((c->cut_slant ? tau[last] / mu : tau[last]) > c->toomuch);
     for (int k = 0; k <= last; k++) {
       ek[k] = exp(-tau[k] / mu);
       f[k] = bk[k] * ek[k];
@@ -280,8 +295,8 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
     if (c->integ == ORC_INTEG_SIMPSON) {
       int n = last + 1;
       for (int k = 0; k < last; k++) hx[k] = tau[k + 1] - tau[k];
-      if (!deck && last + 1 < L) { /* one padded point: integrand 0, one unit of tau further */
-        hx[last] = 1.0;
+      if (!deck && last + 1 < L) { /* one padded point: integrand 0, one unit of (vertical / slant) tau further */
+        hx[last] = c->cut_slant ? mu : 1.0;
         f[last + 1] = 0.0;
         n = last + 2;
       }
@@ -291,7 +306,7 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
       for (int k = 1; k <= last; k++) I += 0.5 * (f[k - 1] + f[k]) * (tau[k] - tau[k - 1]);
       I /= mu;
     } else {
-      /* default: I = int B d(exp(-tau/mu)), trapezoid in the transmittance.
+      /* I = int B d(exp(-tau/mu)), trapezoid in the transmittance.
        * Exact for an isothermal column, never exceeds the hottest layer's
        * Planck function (a trapezoid in tau does when tau jumps by >> 1
        * across one layer), and is the discretisation BART's own
@@ -303,6 +318,7 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
     if (deck) I += f[last];
     intens[a] = I;
   }
+  last = last_v;
   free(bk);
   free(ek);
   free(f);

@@ -55,7 +55,8 @@ typedef struct {
   int solution;             /* ORC_SOL_* */
   int scat_flag;            /* 0 none, 1 scaled lambda^-4, 2 polarisability */
   int has_cloud;            /* grey opaque deck below cloudtop */
-  int reserved;
+  int cut_slant;            /* the `toomuch` cut (column_eclipse): 0 on the vertical optical depth, one `last`
+                             * for every ray angle; 1 on each ray's SLANT depth tau / mu, its own `last` per angle */
   /* atmosphere (atm-file order: layer 0 = bottom, L-1 = top) */
   const double *press;      /* [L] barye */
   const double *mass;       /* [S] amu, species order of the atm file */

@@ -26,7 +26,7 @@ class _Cfg(C.Structure):
         ("nlayers", C.c_int), ("nspecies", C.c_int), ("nmol", C.c_int),
         ("ntemp", C.c_int), ("nwave", C.c_int), ("nangles", C.c_int),
         ("ncia", C.c_int), ("integ", C.c_int), ("solution", C.c_int),
-        ("scat_flag", C.c_int), ("has_cloud", C.c_int), ("reserved", C.c_int),
+        ("scat_flag", C.c_int), ("has_cloud", C.c_int), ("cut_slant", C.c_int),
         ("press", C.c_void_p), ("mass", C.c_void_p), ("opmol", C.c_void_p),
         ("tgrid", C.c_void_p), ("kappa", C.c_void_p), ("wn", C.c_void_p),
         ("cia_s1", C.c_void_p), ("cia_s2", C.c_void_p), ("cia_nt", C.c_void_p),
@@ -151,7 +151,7 @@ class OracleEngine:
     """Oracle counterpart of the product engine: built from a transit cfg."""
 
     def __init__(self, tcfg: str, wn_lo: int | None = None, wn_hi: int | None = None,
-                 integ: int | None = None):
+                 integ: int | None = None, cut: str | None = None):
         k = read_tcfg(tcfg)
         self.keys = k
         atm = read_atm(k["atm"])
@@ -207,6 +207,9 @@ class OracleEngine:
             integ = {"transmittance": 0, "simpson": 1, "trapz_tau": 2, "trapz": 2}.get(v)
             integ = int(v) if integ is None else integ
         c.integ = int(integ)
+        cut = cut or k.get("cut", "vertical")       # the product's cfg key
+        assert cut in ("vertical", "slant")
+        c.cut_slant = int(cut == "slant")
         c.solution = 0 if k.get("solution", "eclipse") == "eclipse" else 1
         c.press, c.mass, c.opmol = _p(self.press), _p(self.mass), _p(self.opmol)
         c.tgrid, c.kappa, c.wn = _p(self.tgrid), _p(self.kappa), _p(self.wn)
@@ -241,6 +244,10 @@ class OracleEngine:
 
     def set_scattering(self, flag, value):
         self.c.scat_flag, self.c.scat_value = int(flag), float(value)
+
+    def set_cut(self, cut):
+        """'vertical' (one cut for all ray angles) or 'slant' (each angle's own slant depth)."""
+        self.c.cut_slant = int({"vertical": 0, "slant": 1}[cut])
 
     def set_integ(self, rule):
         """0 transmittance trapezoid, 1 Simpson hybrid (App. A-4), 2 trapezoid in tau."""

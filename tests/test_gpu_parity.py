@@ -474,3 +474,56 @@ def test_ray_grids_of_other_sizes(tmp_path, nang):
             trm.set_cloudtop(3.0); o.set_cloudtop(3.0)      # below the bottom layer: no deck
     finally:
         trm.free_memory()
+
+
+@pytest.mark.parametrize("integ", [1, 0, 2])
+def test_cut_on_the_slant_depth(tmp_path, integ):
+    """`cut slant`: the toomuch cut on each ray's slant depth -- its own last layer per
+    angle, rule 1's padded point one unit of SLANT depth further.  Through the cfg key and the
+    setter, with toomuch from "the second layer" to "never", with a cloud deck, with ray grids
+    with and without a vertical ray; the per-angle intensities of a single profile too.  With
+    toomuch out of reach the two cuts are the same numbers; at toomuch = 10 they differ by
+    about exp(-10) of the flux."""
+    import re
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    for grid in ((0, 20, 40, 60, 80), (15, 45, 75)):
+        c = synth.make_case(str(tmp_path / ("g%d" % len(grid))), nlayers=44, nwave=200, raygrid=grid,
+                            tlow=400.0, thigh=3000.0, tempdelt=650.0, extra_keys={"cut": "slant"})
+        profs = walkers(c, 7, seed=3)
+        txt = open(c.tcfg).read()
+        for i, tm in enumerate((1e-3, 0.3, 2.0, 10.0, 1e30)):
+            cfg = c.tcfg + ".tm%d" % i
+            open(cfg, "w").write(re.sub(r"(?m)^toomuch .*$", "toomuch %r" % tm, txt))
+            engine.init(cfg)
+            try:
+                assert trm.get_cut() == "slant"
+                trm.set_integ(integ)
+                o = orc.OracleEngine(cfg, integ=integ)
+                assert o.c.cut_slant == 1
+                ref = o.run_batch(profs)
+                tol = dict(rtol=RTOL, atol=1e-12 * np.abs(ref).max() if integ == 1 else 0.0)
+                np.testing.assert_allclose(engine.run_batch(profs), ref, **tol)
+                trm.run_transit(profs[0], trm.get_no_samples())
+                inten = np.zeros((len(grid), trm.get_no_samples()))
+                trm.check(trm.lib().bartrt_get_intensity(trm._ptr(inten), len(grid), inten.shape[1]))
+                refi = o.intensity(profs[0])
+                np.testing.assert_allclose(inten, refi, rtol=RTOL, atol=1e-12 * np.abs(refi).max() if integ == 1 else 0.0)
+                lp = np.log10(c.press_bar)
+                trm.set_cloudtop(float(lp[17])); o.set_cloudtop(float(lp[17]))
+                refc = o.run_batch(profs)
+                np.testing.assert_allclose(engine.run_batch(profs), refc, rtol=RTOL,
+                                           atol=1e-12 * np.abs(refc).max() if integ == 1 else 0.0)
+                # the other value of the switch
+                trm.set_cut("vertical"); o.set_cut("vertical")
+                assert trm.get_cut() == "vertical"
+                refv = o.run_batch(profs)
+                np.testing.assert_allclose(engine.run_batch(profs), refv, rtol=RTOL,
+                                           atol=1e-12 * np.abs(refv).max() if integ == 1 else 0.0)
+                d = np.abs(refv / refc - 1).max()
+                if tm == 1e30:
+                    assert d < 1e-12
+                elif tm == 10.0:
+                    assert 1e-7 < d < 1e-2
+            finally:
+                trm.free_memory()

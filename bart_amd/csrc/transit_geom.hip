@@ -13,7 +13,7 @@
 //     M = (r_top^2 - 2 int exp(-tau(b)) b db) / R_star^2      (trapezoid in b)
 //
 // rt_transit is the generic form (any layer count, runtime molecule / CIA
-// counts, line-by-line extinction, tau output).  rt_transit_mfma is the one the
+// counts, tau output).  rt_transit_mfma is the one the
 // batched path runs.  Per wavenumber the chord depths are a lower-triangular
 // matrix-vector product tau = DS P (L^2/2 multiply-adds, P_j = e_{j-1} + e_j), so
 // for 16 wavenumbers at a time it is a [16 x L] x [L x 16-chord tile] matrix
@@ -125,7 +125,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kMfmaTiles = 8;      // row tiles of 16 chords: L <= 128
 constexpr int kMfmaTilesDeep = 16;  // L <= 256: twice the pair-sum registers, half the waves per SIMD
 
-template <int MT, int CT, int KT>
+// EXT: the line-by-line hand-off -- the layer's line extinction ext[w][l][W] (atm layer order) is
+// one more 8-byte load per (layer, wavenumber) and one more addend (such engines have no table).
+template <int MT, int CT, int KT, bool EXT = false>
 __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int M = MT, C = CT;
@@ -180,6 +182,10 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   double integ[4] = {0.0, 0.0, 0.0, 0.0};
   double gcarry[4];          // exp(-tau) r of the last chord of the previous tile
   bool active[4] = {true, true, true, true};
+  // `transparent` (no opaque core): exp(-tau) r^2 of the deepest chord counted, per lane; the
+  // deepest among a wavenumber's lanes is picked at the end
+  int klast[4] = {-1, -1, -1, -1};
+  double vlast[4] = {0.0, 0.0, 0.0, 0.0};
   const double r_top = sRt[0];
 #pragma unroll
   for (int r = 0; r < 4; r++) gcarry[r] = r_top;
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
       double e = fma(c[2 + 2 * M + 2 * C], nu4, c[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
 #pragma unroll
       for (int x = 0; x < NLD; x++) e = fma(c[2 + x], rv[x], e);
+      if constexpr (EXT) e += p.ext[((size_t)w * L + (size_t)(L - 1 - jc)) * W + ii];
       const double below = __shfl(e, (lane + 48) & 63);  // row q - 1, i.e. layer j - 1 (q >= 1)
       const double eprev = q == 0 ? ecarry : below;
       ecarry = below;
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
       const unsigned rowbits = (unsigned)(over >> (16 * q)) & 0xffffu;
       const bool counts = kvalid && active[r] && (rowbits & ((1u << m) - 1u)) == 0u;
       integ[r] += counts ? 0.5 * (gprev + g) * dr : 0.0;
+      if (counts) { klast[r] = k; vlast[r] = g * rk; }
       active[r] = active[r] && rowbits == 0u;
       gcarry[r] = __shfl(g, 16 * q + 15);
       any_active = any_active || active[r];
@@ -240,8 +248,19 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   for (int r = 0; r < 4; r++) {
     double s = integ[r];
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+    double core = 0.0;   // transparent: the rays below the last chord keep its transmission
+    if (p.transparent) {
+      int kl = klast[r];
+      double vl = vlast[r];
+      for (int o = 8; o > 0; o >>= 1) {
+        const int ko = __shfl_xor(kl, o, 16);
+        const double vo = __shfl_xor(vl, o, 16);
+        if (ko > kl) { kl = ko; vl = vo; }
+      }
+      core = kl >= 0 ? vl : r_top * r_top;   // no chord below the top: tau = 0 there
+    }
     const int iw = i0 + q + 4 * r;
-    if (m == 0 && iw < W) p.spec[(size_t)w * W + iw] = (r_top * r_top - 2.0 * s) * p.inv_starrad2;
+    if (m == 0 && iw < W) p.spec[(size_t)w * W + iw] = (r_top * r_top - 2.0 * s - core) * p.inv_starrad2;
   }
 }
 
@@ -297,7 +316,26 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   static const bool force_window = std::getenv("BARTRT_WINDOW") != nullptr;  // (tests)
   const bool window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
   const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!window || window_fits(a, 4));
-  if (!generic_only && !a.ext && !a.tau_out && !a.transparent && fits32 && a.L <= 16 * kMfmaTilesDeep) {
+  if (!generic_only && a.ext && a.M == 0 && a.C <= 2 && !a.tau_out && a.cia_bytes < (1ull << 32) - 4096 &&
+      a.L <= 16 * kMfmaTilesDeep) {
+    // line-by-line engines (no table): the matrix-tile kernel with the extinction array as input
+    RtArgs b = a;
+    b.window = 0;
+    b.ntiles = (a.W + 63) / 64;
+    const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
+    const size_t shm = sizeof(double) * ((size_t)a.L * coef_stride(0, a.C) + (size_t)a.L * idx_stride(a.C) + (size_t)a.L);
+#define BARTRT_TRANSIT_EXT(CC)                                                                       \
+  if (a.C == CC) {                                                                                   \
+    if (a.L <= 16 * kMfmaTiles)                                                                      \
+      BARTRT_RT_LAUNCH((rt_transit_mfma<0, CC, kMfmaTiles, true>), dim3(nb), dim3(256), shm, st, b);  \
+    else                                                                                             \
+      BARTRT_RT_LAUNCH((rt_transit_mfma<0, CC, kMfmaTilesDeep, true>), dim3(nb), dim3(256), shm, st, b); \
+    return hipGetLastError();                                                                        \
+  }
+    BARTRT_TRANSIT_EXT(0) BARTRT_TRANSIT_EXT(1) BARTRT_TRANSIT_EXT(2)
+#undef BARTRT_TRANSIT_EXT
+  }
+  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesDeep) {
     RtArgs b = a;
     b.window = window;
     b.ntiles = (a.W + 63) / 64;

@@ -526,3 +526,32 @@ def test_config5_size_properties(tmp_path):
         parts.append(engine.lbl_extinction(prof))
         trm.free_memory()
     assert np.array_equal(np.concatenate(parts, axis=1), ext)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlayers,transparent", [(16, 0), (40, 1), (150, 0)])
+def test_line_by_line_in_transit_geometry(tmp_path, nlayers, transparent):
+    """On-the-fly line-by-line extinction through the transit geometry: the extinction array feeds the
+    matrix-tile kernel (rt_transit_mfma with the array as one more load; 150 layers: its deep form) --
+    modulation spectra of a batch against the oracle's chord integration over the oracle's extinction,
+    with and without an opaque core."""
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle, rt_oracle as orc
+    extra = {"solution": "transit", "starrad": 1.145}
+    if transparent:
+        extra["transparent"] = 1
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=900, nwave=200, nlayers=nlayers, cia=True, extra_keys=extra)
+    engine.init(c.tcfg)
+    try:
+        profs = [c.profiles(), c.profiles(temp=c.temp0 * 1.15), c.profiles(temp=c.temp0 * 0.9)]
+        got = engine.run_batch(np.array([p.ravel() for p in profs]))
+        lo = lbl_oracle.LblOracle(c.tcfg)
+        o = orc.OracleEngine(c.tcfg)
+        assert o.c.solution == 1 and o.c.transparent == transparent
+        for w, p in enumerate(profs):
+            o.set_extra_extinction(lo.extinction(p))
+            ref = o.run(p)
+            assert 0 < ref.min() and ref.max() < 1
+            np.testing.assert_allclose(got[w], ref, rtol=1e-9)
+    finally:
+        trm.free_memory()

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "engine.hpp"
+#include "imw_tab.hpp"
 #include "voigt_coef.hpp"
 
 namespace bartrt {
@@ -41,15 +42,133 @@ __device__ __forceinline__ double add_rounded(double a, double b) {
 }
 
 // |z| >= 100 (almost every line-point pair of a pressure-broadened layer): three terms
-// of voigt_k's asymptotic series, written out in real arithmetic with 1/z = c - i s --
-//   sqrt(pi) K = s [1 + (3 c^2 - s^2)/2 + 3/4 (5 c^4 - 10 c^2 s^2 + s^4)]   (<= 1.4e-11)
-__device__ __forceinline__ double voigt_far(double x, double y, double r2) {
+// of voigt_k's asymptotic series in real arithmetic.  With 1/z = c - i s, C = c^2, S = s^2:
+//   sqrt(pi) K = s [1 + (3 C - S)/2 + 3/4 (5 C^2 - 10 C S + S^2)]   (<= 1.4e-11)
+// and, as C + S = 1/|z|^2 =: v, a polynomial in C alone,
+//   = s [(1 - v/2 + 3 v^2/4) + (2 - 9 v) C + 12 C^2]:  12 operations after the reciprocal instead of 17.
+__device__ __forceinline__ double voigt_far(double x2, double y, double r2) {
 #pragma clang fp contract(off)
-  const double inv = rcp_n1(r2);                      // reciprocal + Newton: no IEEE divide per pair
-  const double c = x * inv, s = y * inv, C = c * c, S = s * s;
-  const double p1 = fma(1.5, C, -0.5 * S);
-  const double p2 = fma(C, fma(5.0, C, -10.0 * S), S * S);
-  return kInvSqrtPi * s * (fma(0.75, p2, p1) + 1.0);
+  const double v = rcp_n1(r2);                        // reciprocal + Newton: no IEEE divide per pair
+  const double C = x2 * (v * v);
+  const double t1 = fma(-9.0, v, 2.0), t0 = fma(fma(0.75, v, -0.5), v, 1.0);
+  return (kInvSqrtPi * (y * v)) * fma(fma(12.0, C, t1), C, t0);
+}
+
+// ---------------------------------------------------------------------------
+// Small y, |z| < 8 (Doppler cores: nine in ten core samples of a hot-Jupiter column have y <= 0.1):
+// Taylor expansion of w about the real axis,
+//     w(x + i y) = sum_n a_n,   a_n = (i y)^n w^(n)(x) / n!,
+//     a_0 = w(x) = exp(-x^2) + i D(x),          a_1 = i y (2 i / sqrt(pi) - 2 x w(x)),
+//     a_(n+1) = (2 y^2 a_(n-1) - 2 i x y a_n) / (n + 1)            (from w' = -2 z w + 2 i / sqrt(pi)),
+// K = sum Re a_n.  exp(-x^2) is the kernels' own exp; D(x) = Im w(x) = 2 F(x) / sqrt(pi) (Dawson's integral)
+// comes from a table of degree-7 polynomials on pieces of width 1/16 (imw_tab.hpp), copied into LDS by every
+// kernel that evaluates the function.  The lanes of a step are points of one line a few pieces apart, 64
+// different rows: a row is 48 bytes (four doubles, four floats), so that neighbouring rows start on different
+// banks -- 64-byte rows cost 1.2e10 bank-conflict cycles per spectrum of config 5, these 1.6e9.
+// 7 operations per order; the order follows y alone (voigt_order: 2 for y <= 6e-6 ... 10 for y <= 0.13, each
+// chosen so that the first omitted term is below 3e-12 of K over the whole of |z| < 8): <= 2.5e-12 relative
+// everywhere, against 1e-10 of the rational approximation it replaces there, at 47 - 100 VALU operations
+// per sample against 96.  (The same expansion for the wings, 8 <= |z| < 17 with exp(-x^2) dropped, was built
+// and measured: the table index and the cancellation-safe form cost what the eleven-term series costs, 40.)
+constexpr double kTwoInvSqrtPi = 1.1283791670955126;
+constexpr double kTaylorYmax = 0.13;
+constexpr double kSeriesR2 = 17.0 * 17.0;   // from here six terms of the asymptotic series do
+
+// Order of the expansion for a line of this y; 0: not small (Weideman's approximation, asymptotic series).
+__device__ double g_taylor_ymax = kTaylorYmax;   // BARTRT_VOIGT_TAYLOR=0 sets it to 0: no expansion for any y
+__device__ __forceinline__ int voigt_order(double y) {
+  if (!(y <= g_taylor_ymax)) return 0;
+  return 2 + (y > 6.0e-6) + (y > 5.0e-4) + (y > 3.0e-3) + (y > 9.5e-3) + (y > 2.2e-2) + (y > 4.0e-2) +
+         (y > 6.5e-2) + (y > 9.5e-2);
+}
+
+// The table in LDS (kImwDoubles doubles at `tab`, rows of 48 bytes); callers put a barrier after it.
+constexpr int kImwDoubles = kImwPieces * (int)(sizeof(ImwRow) / sizeof(double));
+static_assert(sizeof(ImwRow) == 48, "ImwRow: four doubles and four floats");
+__device__ __forceinline__ void load_imw_table(double *tab) {
+  const double *src = reinterpret_cast<const double *>(kImwTab);
+  for (int i = threadIdx.x; i < kImwDoubles; i += blockDim.x) tab[i] = src[i];
+}
+
+// D at local coordinate t of row i
+__device__ __forceinline__ double imw_row(const double *tab, int i, double t) {
+#pragma clang fp contract(off)
+  const ImwRow *row = reinterpret_cast<const ImwRow *>(tab) + i;
+  const float4 hi = *reinterpret_cast<const float4 *>(row->f);
+  const double2 c01 = *reinterpret_cast<const double2 *>(row->c), c23 = *reinterpret_cast<const double2 *>(row->c + 2);
+  double D = fma((double)hi.w, t, (double)hi.z);
+  D = fma(D, t, (double)hi.y);
+  D = fma(D, t, (double)hi.x);
+  D = fma(D, t, c23.y);
+  D = fma(D, t, c23.x);
+  D = fma(D, t, c01.y);
+  return fma(D, t, c01.x);
+}
+
+constexpr double kInvN[12] = {0.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11};
+
+// |z| < 8: straight-line code per order (a wave-uniform order takes one scalar branch; where the lanes of a
+// wave hold different lines -- lbl_accumulate_pairs -- the orders present run one after the other, which
+// measured faster than predicating the terms of one unrolled loop: 3.5 against 3.9 ms on config 5).
+template <int ORDER>
+__device__ __forceinline__ double voigt_taylor_n(double x, double y, double x2, const double *tab) {
+#pragma clang fp contract(off)
+  const double xs = x * (double)(kImwPieces / 8);
+  const int i = min((int)xs, kImwPieces - 1);
+  const double D = imw_row(tab, i, xs - ((double)i + 0.5));
+  const double E = exp_rt(-x2);
+  const double al = (x + x) * y, be = (y + y) * y;
+  // (p0, q0) and (p1, q1) hold Re, Im of two successive terms; each step overwrites the older one
+  double p0 = E, q0 = D;
+  double p1 = fma(al, D, -(kTwoInvSqrtPi * y)), q1 = -(al * E);
+  double K = E + p1;
+#pragma unroll
+  for (int n = 1; n < ORDER; n += 2) {
+    const double pe = fma(al, q1, be * p0) * kInvN[n + 1];
+    if (n + 1 < ORDER) q0 = fma(-al, p1, be * q0) * kInvN[n + 1];     // the last term's imaginary part is not needed
+    p0 = pe;
+    K = K + p0;
+    if (n + 1 < ORDER) {
+      const double po = fma(al, q0, be * p1) * kInvN[n + 2];
+      if (n + 2 < ORDER) q1 = fma(-al, p0, be * q1) * kInvN[n + 2];
+      p1 = po;
+      K = K + p1;
+    }
+  }
+  return K;
+}
+
+__device__ __forceinline__ double voigt_taylor(double x, double y, double x2, int order, const double *tab) {
+  switch (order) {
+    case 2: return voigt_taylor_n<2>(x, y, x2, tab);
+    case 3: return voigt_taylor_n<3>(x, y, x2, tab);
+    case 4: return voigt_taylor_n<4>(x, y, x2, tab);
+    case 5: return voigt_taylor_n<5>(x, y, x2, tab);
+    case 6: return voigt_taylor_n<6>(x, y, x2, tab);
+    case 7: return voigt_taylor_n<7>(x, y, x2, tab);
+    case 8: return voigt_taylor_n<8>(x, y, x2, tab);
+    case 9: return voigt_taylor_n<9>(x, y, x2, tab);
+    default: return voigt_taylor_n<10>(x, y, x2, tab);
+  }
+}
+
+// s(t) = sum_k (2k-1)!!/2^k t^k, NT terms, for complex t = tr + i ti: synthetic division by the argument's real
+// quadratic (see voigt_k); the value is sr + i si.
+template <int NT>
+__device__ __forceinline__ void asym_series(double tr, double ti, double &sr, double &si) {
+#pragma clang fp contract(off)
+  constexpr double c[11] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625,
+                            67303.564453125, 639383.8623046875};
+  const double p = tr + tr, q = fma(tr, tr, ti * ti);
+  double a = c[NT - 1], b = c[NT - 2];
+#pragma unroll
+  for (int k = NT - 3; k >= 0; k--) {
+    const double an = fma(p, a, b);
+    b = fma(-q, a, c[k]);
+    a = an;
+  }
+  sr = fma(a, tr, b);
+  si = a * ti;
 }
 
 // Re w(x + i y), x >= 0, y > 0.  Contraction is switched off inside and every
@@ -58,36 +177,34 @@ __device__ __forceinline__ double voigt_far(double x, double y, double r2) {
 // on them (a layer state can be summed by either accumulation kernel).  Which
 // branch a point takes depends on (x, y) alone, never on the other lanes.
 //
-// Both approximations are polynomials with REAL coefficients in a complex
-// argument (t = 1/z^2, resp. Weideman's Z).  Those are evaluated by synthetic
-// division by the argument's real quadratic  u^2 - 2 Re(u) u + |u|^2  (Knuth,
-// TAOCP 4.6.4): two real FMAs per coefficient instead of the five operations of a
-// complex Horner step; the remainder a u + b is the value.
-__device__ inline double voigt_k(double x, double y) {
+// The asymptotic series and Weideman's approximation are polynomials with REAL
+// coefficients in a complex argument (t = 1/z^2, resp. Weideman's Z).  Those are
+// evaluated by synthetic division by the argument's real quadratic
+// u^2 - 2 Re(u) u + |u|^2  (Knuth, TAOCP 4.6.4): two real FMAs per coefficient
+// instead of the five operations of a complex Horner step; the remainder a u + b is
+// the value.  `order` hands in voigt_order(y) where the caller has it per line (it is
+// called only for |z| < 8); `tab` is the LDS copy of the Im w table.
+template <class OrderFn>
+__device__ __forceinline__ double voigt_k(double x, double y, const double *tab, OrderFn order) {
 #pragma clang fp contract(off)
   const double x2 = x * x, y2 = y * y;
   const double r2 = x2 + y2;
-  if (r2 >= 1.0e4) return voigt_far(x, y, r2);
+  if (r2 >= 1.0e4) return voigt_far(x2, y, r2);
   if (r2 >= 64.0) {
-    // 8 <= |z| < 100: asymptotic series  w = i/(sqrt(pi) z) * s(1/z^2),
-    // s(t) = sum_k (2k-1)!!/2^k t^k, eleven terms (<= 2.6e-12 at |z| = 8; the Laplace
-    // continued fraction with eight levels that stood here gave 1.7e-12 at eight reciprocals)
+    // asymptotic series  w = i/(sqrt(pi) z) * s(1/z^2): eleven terms from |z| = 8 (<= 2.6e-12 there; the
+    // Laplace continued fraction with eight levels that stood here gave 1.7e-12 at eight reciprocals), six
+    // from |z| = 17 (<= 3e-13)
     const double inv = rcp_n1(r2), inv2 = inv * inv;
     const double tr = (x2 - y2) * inv2, ti = (-2.0 * x) * y * inv2;  // t = 1/z^2
-    const double p = tr + tr, q = fma(tr, tr, ti * ti);
-    double a = 639383.8623046875, b = 67303.564453125;         // c_10, c_9
-#pragma unroll
-    for (int k = 8; k >= 0; k--) {
-      constexpr double c[9] = {1.0, 0.5, 0.75, 1.875, 6.5625, 29.53125, 162.421875, 1055.7421875, 7918.06640625};
-      const double an = fma(p, a, b);
-      b = fma(-q, a, c[k]);
-      a = an;
-    }
-    const double sr = fma(a, tr, b), si = a * ti;
+    double sr, si;
+    if (r2 >= kSeriesR2) asym_series<6>(tr, ti, sr, si);
+    else asym_series<11>(tr, ti, sr, si);
     // Re[i s / z] = (y s_r - x s_i) / |z|^2
     return kInvSqrtPi * fma(y, sr, -(x * si)) * inv;
   }
-  // Weideman N = 40: Z = ((L - y) + i x) / ((L + y) - i x)
+  const int ord = order();
+  if (ord) return voigt_taylor(x, y, x2, ord, tab);
+  // y > 0.13: Weideman N = 36: Z = ((L - y) + i x) / ((L + y) - i x)
   const double ar = kWeidL - y, br = kWeidL + y;
   const double den = rcp_core(fma(br, br, x2));
   const double Zr = fma(ar, br, -x2) * den, Zi = fma(x, br, ar * x) * den;
@@ -105,11 +222,17 @@ __device__ inline double voigt_k(double x, double y) {
   const double q2r = fma(qr, qr, -(qi * qi)), q2i = 2.0 * qr * qi;
   return fma(2.0, fma(pr, q2r, -(pi * q2i)), kInvSqrtPi * qr);
 }
+__device__ __forceinline__ double voigt_k(double x, double y, const double *tab) {
+  return voigt_k(x, y, tab, [&] { return voigt_order(y); });
+}
 
 // Diagnostics (bartrt_voigt): the kernels' Voigt function on n (x, y) pairs.
 __global__ void voigt_probe(const double *x, const double *y, double *k, long n) {
+  __shared__ double s_tab[kImwDoubles];
+  load_imw_table(s_tab);
+  __syncthreads();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) k[i] = voigt_k(x[i], y[i]);
+  if (i < n) k[i] = voigt_k(x[i], y[i], s_tab);
 }
 
 void lbl_voigt_probe(const double *x, const double *y, double *k, long n) {
@@ -312,14 +435,18 @@ __device__ __forceinline__ LineRec stage_line(const LblDev &d, const double *sv,
 // list is staged through LDS 256 lines at a time; lines below the strength
 // threshold (two thirds of a typical list at ethresh 1e-6) are dropped while
 // staging (ordered compaction: ballot + prefix), so no lane ever tests them.
-__global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void lbl_accumulate(LblDev d, AccArgs a) {
   __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
+  __shared__ double s_tab[kImwDoubles];
+  __shared__ int s_ord[256];
   __shared__ int s_wcount[4];
   const int st = blockIdx.y;
   const int tile0 = blockIdx.x * 256;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
   if (sv[1] > 1.0) return;                    // an oversampled state: lbl_accumulate_fine owns it
   if (narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate_pairs owns it
+  load_imw_table(s_tab);
+  __syncthreads();
   const double invT = 1.0 / sv[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = tile0 + threadIdx.x;
@@ -345,6 +472,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
       const int cnt = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
       if (r.cut >= 0.0) {
         s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
+        s_ord[pos] = voigt_order(r.y);
       }
       __syncthreads();
       // product rounded on its own (no fma into the sum): the pair kernel stores
@@ -352,7 +480,8 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
       // two tilings of the grid -- the bits must not
       auto one = [&](int t) {
         const double dv = fabs(nu - s_nu0[t]);
-        if (dv <= s_cut[t]) acc = add_rounded(acc, mul_rounded(s_amp[t], voigt_k(dv * s_xs[t], s_y[t])));
+        if (dv <= s_cut[t])
+          acc = add_rounded(acc, mul_rounded(s_amp[t], voigt_k(dv * s_xs[t], s_y[t], s_tab, [&] { return __builtin_amdgcn_readfirstlane(s_ord[t]); })));
       };
       for (int t = 0; t < cnt; t++) one(t);
       __syncthreads();
@@ -389,13 +518,14 @@ __global__ __launch_bounds__(256) void lbl_accumulate(LblDev d, AccArgs a) {
 // config 5, the 80 layers above 3 bar: 7: 4.5 ms, 12: 4.0, 20: 3.9, 31: 3.5, 48: 3.5 --
 // with lane = point a line of 2 * 31 points still leaves half of a wave's lanes idle).
 constexpr int kPairReach = 31;
-constexpr int kPairCap = 256;                       // pairs per round (LDS buffer)
+constexpr int kPairCap = 240;                       // pairs per round (LDS buffer; four waves' scratch + the Im w table fit 40 KB)
 
 struct PairScratch {                        // per wave
   double wnu[64];                           // the wave's points
   double nu0[128], amp[128], xs[128], y[128], cut[128];   // queue of kept lines that reach the wave, list order
   double val[kPairCap];                     // pair contributions of the round
-  int off[64], first[64];                   // pair offset and first point of each line of the round
+  unsigned short off[64], first[64];        // pair offset and first point of each line of the round
+  unsigned char ord[128];                   // voigt_order(y) of the queued lines
   unsigned char line[kPairCap];             // the line (queue slot) a pair belongs to
 };
 
@@ -405,13 +535,16 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lbl_accumulate_pairs(LblDev d, AccArgs a) {
   __shared__ PairScratch s_pairs[4];
+  __shared__ double s_tab[kImwDoubles];
   const int st = blockIdx.y;
   const int tile0 = blockIdx.x * 256;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
   if (sv[1] > 1.0) return;                     // an oversampled state: lbl_accumulate_fine owns it
   if (!narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate owns it
+  load_imw_table(s_tab);
+  __syncthreads();                             // the only workgroup barrier: the waves part ways here
   const double invT = 1.0 / sv[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w0 = tile0 + wave * 64;
@@ -458,15 +591,17 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
       const int total = __builtin_amdgcn_readlane(incl, m - 1);
       const int offv = incl - n;
       if (total > 0) {
-        ws.off[lane] = offv;
-        ws.first[lane] = first;
+        ws.off[lane] = (unsigned short)offv;
+        ws.first[lane] = (unsigned short)first;
         for (int k = 0; k < n; k++) ws.line[offv + k] = (unsigned char)lane;
         wave_sync();
         // ---- B
         for (int p = lane; p < total; p += 64) {
           const int x = ws.line[p];
           const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
-          ws.val[p] = dv <= ws.cut[x] ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x])) : 0.0;
+          ws.val[p] = dv <= ws.cut[x]
+                          ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x], s_tab, [&] { return (int)ws.ord[x]; }))
+                          : 0.0;
         }
         wave_sync();
         // ---- C  (a line's range comes from the registers of its A2 lane, so a point no
@@ -481,12 +616,13 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
       // the queue moves up by the m lines taken
       const int rem = pending - m;
       double q0[5], q1[5];
+      int o0 = 0, o1 = 0;
       const bool h0 = lane < rem, h1 = lane + 64 < rem;
-      if (h0) { q0[0] = ws.nu0[m + lane]; q0[1] = ws.amp[m + lane]; q0[2] = ws.xs[m + lane]; q0[3] = ws.y[m + lane]; q0[4] = ws.cut[m + lane]; }
-      if (h1) { q1[0] = ws.nu0[m + 64 + lane]; q1[1] = ws.amp[m + 64 + lane]; q1[2] = ws.xs[m + 64 + lane]; q1[3] = ws.y[m + 64 + lane]; q1[4] = ws.cut[m + 64 + lane]; }
+      if (h0) { q0[0] = ws.nu0[m + lane]; q0[1] = ws.amp[m + lane]; q0[2] = ws.xs[m + lane]; q0[3] = ws.y[m + lane]; q0[4] = ws.cut[m + lane]; o0 = ws.ord[m + lane]; }
+      if (h1) { q1[0] = ws.nu0[m + 64 + lane]; q1[1] = ws.amp[m + 64 + lane]; q1[2] = ws.xs[m + 64 + lane]; q1[3] = ws.y[m + 64 + lane]; q1[4] = ws.cut[m + 64 + lane]; o1 = ws.ord[m + 64 + lane]; }
       wave_sync();
-      if (h0) { ws.nu0[lane] = q0[0]; ws.amp[lane] = q0[1]; ws.xs[lane] = q0[2]; ws.y[lane] = q0[3]; ws.cut[lane] = q0[4]; }
-      if (h1) { ws.nu0[64 + lane] = q1[0]; ws.amp[64 + lane] = q1[1]; ws.xs[64 + lane] = q1[2]; ws.y[64 + lane] = q1[3]; ws.cut[64 + lane] = q1[4]; }
+      if (h0) { ws.nu0[lane] = q0[0]; ws.amp[lane] = q0[1]; ws.xs[lane] = q0[2]; ws.y[lane] = q0[3]; ws.cut[lane] = q0[4]; ws.ord[lane] = o0; }
+      if (h1) { ws.nu0[64 + lane] = q1[0]; ws.amp[64 + lane] = q1[1]; ws.xs[64 + lane] = q1[2]; ws.y[64 + lane] = q1[3]; ws.cut[64 + lane] = q1[4]; ws.ord[64 + lane] = o1; }
       wave_sync();
       pending = rem;
     }
@@ -508,6 +644,7 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
       if (in) {
         const int pos = pending + __popcll(keep & ((1ull << lane) - 1ull));
         ws.nu0[pos] = r.nu0; ws.amp[pos] = r.amp; ws.xs[pos] = r.xs; ws.y[pos] = r.y; ws.cut[pos] = r.cut;
+        ws.ord[pos] = (unsigned char)voigt_order(r.y);
       }
       pending += __popcll(keep);
       wave_sync();
@@ -542,21 +679,31 @@ __global__ __launch_bounds__(256) void lbl_accumulate_pairs(LblDev d, AccArgs a)
 // smaller sub-tiles (more resident waves) measured faster than larger ones (512: 55 ms,
 // 1 024: 56, 2 048: 63, 4 096: 92).
 constexpr int kFineTarget = 512;
-__global__ __launch_bounds__(64) void lbl_accumulate_fine(LblDev d, AccArgs a, int nfmax) {
+// Doubles of LDS one wave of lbl_accumulate_fine needs: the fine sums, a staged batch of 64 lines (five
+// doubles, four range ints and the Voigt order each).
+__host__ __device__ inline size_t fine_wave_doubles(int nfmax) { return (size_t)nfmax + 5 * 64 + (4 * 64 + 64) / 2; }
+
+__global__ __launch_bounds__(1024) void lbl_accumulate_fine(LblDev d, AccArgs a, int nfmax, int ftarget) {
   extern __shared__ double s_dyn[];
-  double *s_fine = s_dyn;                                           // [nfmax]
-  double *s_nu0 = s_dyn + nfmax, *s_amp = s_nu0 + 64, *s_xs = s_amp + 64, *s_y = s_xs + 64, *s_cut = s_y + 64;
-  int *s_rng = reinterpret_cast<int *>(s_cut + 64);                 // [64][4]: first point, core first / last, last point
+  // the workgroup's waves (1 or 4, the host decides by nfmax) share the Im w table and nothing else
+  double *s_tab = s_dyn;
   const int st = blockIdx.y;
-  const int tile0 = blockIdx.x * 64;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
   if (!(sv[1] > 1.0)) return;             // evaluated on the output points: the other two kernels
+  load_imw_table(s_tab);
+  __syncthreads();                        // the only workgroup barrier
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * 64;
+  if (tile0 >= a.W) return;
+  double *s_fine = s_dyn + kImwDoubles + (size_t)wave * fine_wave_doubles(nfmax);   // [nfmax]
+  double *s_nu0 = s_fine + nfmax, *s_amp = s_nu0 + 64, *s_xs = s_amp + 64, *s_y = s_xs + 64, *s_cut = s_y + 64;
+  int *s_rng = reinterpret_cast<int *>(s_cut + 64);                 // [64][4]: first point, core first / last, last point
+  int *s_ord = s_rng + 4 * 64;                                      // [64]
   const int dv = (int)sv[1], h = dv / 2;
   const double invT = 1.0 / sv[0], step = d.wndelt / dv, inv_step = dv / d.wndelt;
-  const int lane = threadIdx.x;
   const long kmax = (long)(d.wfull - 1) * dv;            // last fine point of the full grid
   const int tile_end = min(tile0 + 64, a.W);
-  const int TO = min(64, max(1, kFineTarget / dv));      // output points per sub-tile
+  const int TO = min(64, max(1, ftarget / dv));          // output points per sub-tile
   const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
   for (int o0 = tile0; o0 < tile_end; o0 += TO) {
     const int o1 = min(o0 + TO, tile_end);               // output points [o0, o1)
@@ -567,7 +714,8 @@ __global__ __launch_bounds__(64) void lbl_accumulate_fine(LblDev d, AccArgs a, i
     // fine point k of the full grid: wn_first + k * step, product and sum rounded one
     // after the other (a fused multiply-add would move points that sit exactly on a
     // line's cut to the other side of it)
-    const double nu_a = add_rounded(d.wn_first, mul_rounded((double)fa, step));
+    const double fa_d = (double)fa;       // fine indices are integers below 2^53: fa_d + k is exact
+    const double nu_a = add_rounded(d.wn_first, mul_rounded(fa_d, step));
     const double nu_b = add_rounded(d.wn_first, mul_rounded((double)fb, step));
     wave_sync();
     for (int g = g_lo; g < g_hi; g++) {
@@ -604,18 +752,21 @@ __global__ __launch_bounds__(64) void lbl_accumulate_fine(LblDev d, AccArgs a, i
           const int pos = __popcll(keep & ((1ull << lane) - 1ull));   // list order
           s_nu0[pos] = r.nu0; s_amp[pos] = r.amp; s_xs[pos] = r.xs; s_y[pos] = r.y; s_cut[pos] = r.cut;
           s_rng[4 * pos] = r0; s_rng[4 * pos + 1] = r1; s_rng[4 * pos + 2] = r2; s_rng[4 * pos + 3] = r3;
+          s_ord[pos] = voigt_order(r.y);
         }
         wave_sync();
         for (int t = 0; t < cnt; t++) {
           const double l_nu0 = s_nu0[t], l_amp = s_amp[t], l_xs = s_xs[t], l_y = s_y[t], l_cut = s_cut[t];
+          const int l_ord = __builtin_amdgcn_readfirstlane(s_ord[t]);
           const int klo = __builtin_amdgcn_readfirstlane(s_rng[4 * t]);
           const int kc0 = __builtin_amdgcn_readfirstlane(s_rng[4 * t + 1]);
           const int kc1 = __builtin_amdgcn_readfirstlane(s_rng[4 * t + 2]);
           const int khi = __builtin_amdgcn_readfirstlane(s_rng[4 * t + 3]);
           auto point = [&](int k) {
-            const double nu = add_rounded(d.wn_first, mul_rounded((double)(fa + k), step));
+            const double nu = add_rounded(d.wn_first, mul_rounded(add_rounded(fa_d, (double)k), step));
             const double dx = fabs(nu - l_nu0);
-            if (dx <= l_cut) s_fine[k] = add_rounded(s_fine[k], mul_rounded(l_amp, voigt_k(dx * l_xs, l_y)));
+            if (dx <= l_cut)
+              s_fine[k] = add_rounded(s_fine[k], mul_rounded(l_amp, voigt_k(dx * l_xs, l_y, s_tab, [&] { return l_ord; })));
           };
           const int nl = kc0 - klo, nw = nl + (khi - kc1);
           for (int b = lane; b < nw; b += 64) point(b < nl ? klo + b : kc1 + 1 + (b - nl));
@@ -708,9 +859,12 @@ __global__ void lbl_grid_scan(long *gsize, int nstate) {
 // P_j = sqrt(ln 2 / pi) / aD * Re w(sqrt(ln 2) (j step + i aL) / aD) at the GRID widths.
 __global__ __launch_bounds__(256) void lbl_grid_profiles(LblDev d, const double *state, const int *ginfo, const int *gK,
                                                          const long *goff, const long *gbase, double *ptab) {
+  __shared__ double s_tab[kImwDoubles];
   const int j = blockIdx.x, k = blockIdx.y, st = blockIdx.z;
   const int *gi = ginfo + ((size_t)st * d.niso + k) * 3;
   if (j >= gi[2]) return;
+  load_imw_table(s_tab);
+  __syncthreads();
   const double *sv = state + (size_t)st * (2 + 3 * d.niso);
   const double step = d.wndelt / sv[1];
   const double aD = d.dgrid[gi[1] + j], aL = d.lgrid[gi[0]];
@@ -718,7 +872,7 @@ __global__ __launch_bounds__(256) void lbl_grid_profiles(LblDev d, const double 
   const int K = gK[((size_t)st * d.niso + k) * d.dspan + j];
   double *out = ptab + gbase[st] + goff[((size_t)st * d.niso + k) * d.dspan + j];
   for (int o = threadIdx.x; o <= K; o += blockDim.x)
-    out[o] = mul_rounded(amp, voigt_k(mul_rounded(mul_rounded((double)o, step), xs), y));
+    out[o] = mul_rounded(amp, voigt_k(mul_rounded(mul_rounded((double)o, step), xs), y, s_tab));
 }
 
 // Accumulation by table lookup, every state (oversampled or not).  Line-major like
@@ -843,12 +997,14 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
                                                          const double *smax, RtArgs p) {
   extern __shared__ double smem[];
   __shared__ double s_nu0[256], s_amp[256], s_xs[256], s_y[256], s_cut[256];
+  __shared__ double s_tab[kImwDoubles];
   const int C = p.C, L = p.L, W = p.W, A = p.A;
   const int NC = coef_stride(0, C), NI = idx_stride(C);
   const int w = blockIdx.y;
   const int tile0 = blockIdx.x * 256;
   double *sC = smem;
   idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  load_imw_table(s_tab);
   {
     const double *gC = p.coef + (size_t)w * L * NC;
     const idx_t *gI = p.idx + (size_t)w * L * NI;
@@ -909,7 +1065,7 @@ __global__ __launch_bounds__(256) void lbl_rt_eclipse_k(LblDev d, const double *
           const int cnt = (int)min((long)256, j1 - base);
           for (int t = 0; t < cnt; t++) {
             const double dv = fabs(nu - s_nu0[t]);
-            if (dv <= s_cut[t]) acc += s_amp[t] * voigt_k(dv * s_xs[t], s_y[t]);
+            if (dv <= s_cut[t]) acc += s_amp[t] * voigt_k(dv * s_xs[t], s_y[t], s_tab);
           }
         }
         __syncthreads();
@@ -1073,6 +1229,12 @@ void lbl_init(Engine &e, const std::string &paths) {
   // opacity grid's keys); Lorentz half-widths over the atmosphere file's layers and
   // abundances at those two temperatures.
   {
+    // A/B switch: BARTRT_VOIGT_TAYLOR=0 evaluates every |z| < 8 sample with Weideman's approximation
+    const char *ty = std::getenv("BARTRT_VOIGT_TAYLOR");
+    const double ymax = ty && std::string(ty) == "0" ? 0.0 : kTaylorYmax;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_taylor_ymax), &ymax, sizeof(double)));
+  }
+  {
     std::string v = cfg_has(e.cfg, "voigt") ? e.cfg["voigt"] : "exact";
     if (const char *ev = std::getenv("BARTRT_VOIGT")) if (*ev) v = ev;
     if (v != "exact" && v != "grid") throw IoError{"voigt: '" + v + "' is neither exact nor grid"};
@@ -1217,10 +1379,15 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(&dvmax, b->d_dvmax, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (dvmax > 1) {
-      const int nfmax = std::max(kFineTarget, dvmax) + 1;
-      const size_t sh = sizeof(double) * ((size_t)nfmax + 5 * 64) + sizeof(int) * 4 * 64;
-      hipLaunchKernelGGL(lbl_accumulate_fine, dim3((aa.W + 63) / 64, sa.nstate, aa.per_group ? d.ngroup : 1),
-                         dim3(64), sh, st, d, aa, nfmax);
+      static const int ftarget = [] { const char *v = std::getenv("BARTRT_FINE_TARGET"); return v && *v ? std::max(64, atoi(v)) : kFineTarget; }();
+      static const int fwaves = [] { const char *v = std::getenv("BARTRT_FINE_WAVES"); return v && *v ? std::min(16, std::max(1, atoi(v))) : 4; }();
+      const int nfmax = std::max(ftarget, dvmax) + 1;
+      // four waves share a workgroup's copy of the Im w table unless their fine sums would not fit
+      const size_t per_wave = sizeof(double) * fine_wave_doubles(nfmax), tab = sizeof(double) * kImwDoubles;
+      const int nw = tab + fwaves * per_wave <= 64 * 1024 ? fwaves : 1;
+      const int ntile64 = (aa.W + 63) / 64;
+      hipLaunchKernelGGL(lbl_accumulate_fine, dim3((ntile64 + nw - 1) / nw, sa.nstate, aa.per_group ? d.ngroup : 1),
+                         dim3(64 * nw), tab + nw * per_wave, st, d, aa, nfmax, ftarget);
     }
     HIPCHK(hipGetLastError());
   }

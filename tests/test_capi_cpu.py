@@ -140,10 +140,15 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_generated_coefficient_tables_are_reproducible():
-    """csrc/voigt_coef.hpp is what tools/gen_voigt_coef.py produces (Weideman's FFT recipe)."""
+    """csrc/voigt_coef.hpp is what tools/gen_voigt_coef.py produces (Weideman's FFT recipe), csrc/imw_tab.hpp what
+    tools/gen_imw_table.py does (40-digit interpolants of Im w)."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_voigt_coef.py"), "--check"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max |recipe - header| = 0.0" in r.stdout
+    # csrc/imw_tab.hpp (Im w on the real axis, the small-y branch of the Voigt function) from tools/gen_imw_table.py
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_imw_table.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "identical to the header: True" in r.stdout, r.stdout + r.stderr

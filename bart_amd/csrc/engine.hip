@@ -272,14 +272,40 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     if (d_stage) (void)hipFree(d_stage);
     HIPCHK(er);
   }
-  // CIA: resample on the local grid (linear in wn, zero outside the file) and lay
-  // out, per table, nt-1 pair planes [W][2] = (alpha_j, alpha_j+1) per wavenumber:
-  // one 16-byte load per table and layer (kernels.hpp, "Table layout").
+  // CIA: resample on the local grid (zero outside the file) and lay out, per table, nt-1
+  // pair planes [W][2] = (alpha_j, alpha_j+1) per wavenumber: one 16-byte load per table and
+  // layer (kernels.hpp, "Table layout").  `cia_interp` (BARTRT_CIA_INTERP):
+  // linear (default) in wavenumber and temperature, or spline -- natural cubic splines in both;
+  // the temperature spline's second derivatives then ride as one more table per file, whose
+  // weights prep_body fills with the spline's curvature terms, so every RT kernel serves it.
   std::vector<double> cia_planes, cia_temp;
   PrepArgs &pa = prep;
+  {
+    std::string v = cfg_has(cfg, "cia_interp") ? cfg["cia_interp"] : "linear";
+    if (const char *ev = std::getenv("BARTRT_CIA_INTERP")) if (*ev) v = ev;
+    if (v != "linear" && v != "spline") throw IoError{"cia_interp: '" + v + "' is neither linear nor spline"};
+    cia_spline = v == "spline";
+  }
+  // second derivatives of the natural cubic spline through (x, y), n points (n < 3: zero)
+  auto spline_y2 = [](const double *x, const double *y, size_t n, size_t stride, double *y2) {
+    for (size_t i = 0; i < n; i++) y2[i * stride] = 0.0;
+    if (n < 3) return;
+    std::vector<double> u(n, 0.0);
+    for (size_t i = 1; i + 1 < n; i++) {
+      const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+      const double p = sig * y2[(i - 1) * stride] + 2.0;
+      y2[i * stride] = (sig - 1.0) / p;
+      const double d = (y[(i + 1) * stride] - y[i * stride]) / (x[i + 1] - x[i]) -
+                       (y[i * stride] - y[(i - 1) * stride]) / (x[i] - x[i - 1]);
+      u[i] = (6.0 * d / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+    }
+    for (size_t k = n - 1; k-- > 1;) y2[k * stride] = y2[k * stride] * y2[(k + 1) * stride] + u[k];
+  };
   if (cfg_has(cfg, "csfile")) {
     auto files = split_file_list(cfg["csfile"]);
-    if ((int)files.size() > kMaxCia) throw IoError{"csfile: too many cross-section files"};
+    if ((int)files.size() * (cia_spline ? 2 : 1) > kMaxCia)
+      throw IoError{cia_spline ? "csfile: too many cross-section files for cia_interp spline (two table slots each)"
+                               : "csfile: too many cross-section files"};
     for (auto &fn : files) {
       Cia c = read_cia(fn);
       int cc = C++;
@@ -291,14 +317,16 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
       pa.cia_s2[cc] = (int)(f2 - atm.species.begin());
       pa.cia_nt[cc] = (int)c.temp.size();
       pa.cia_toff[cc] = (int)cia_temp.size();
-      const size_t nw = c.wn.size();
+      pa.cia_kind[cc] = 0;
+      const size_t nw = c.wn.size(), ntc = c.temp.size();
       // resampled planes [nt][Wl] first, then the (lower, upper) pair planes
-      std::vector<double> planes(c.temp.size() * (size_t)Wl);
-      for (size_t t = 0; t < c.temp.size(); t++) {
+      std::vector<double> planes(ntc * (size_t)Wl), y2w(cia_spline ? nw : 0);
+      for (size_t t = 0; t < ntc; t++) {
         const double *al = c.alpha.data() + t * nw;
+        if (cia_spline) spline_y2(c.wn.data(), al, nw, 1, y2w.data());
         for (int i = 0; i < Wl; i++) {
           double x = wn_loc[i], v = 0.0;
-          if (x >= c.wn.front() && x <= c.wn.back()) {
+          if (x >= c.wn.front() && x <= c.wn.back() && nw > 1) {
             size_t j = std::upper_bound(c.wn.begin(), c.wn.end(), x) - c.wn.begin();
             if (j >= nw) j = nw - 1;
             if (j == 0) j = 1;
@@ -306,20 +334,42 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
             // np.interp form: slope * (x - x0) + y0
             v = (al[j] - al[j - 1]) / (x1 - x0) * (x - x0) + al[j - 1];
             if (x == x1) v = al[j];
+            if (cia_spline) {
+              const double h = x1 - x0, a = (x1 - x) / h, b = (x - x0) / h;
+              v = a * al[j - 1] + b * al[j] + ((a * a * a - a) * y2w[j - 1] + (b * b * b - b) * y2w[j]) * (h * h) / 6.0;
+            }
+          } else if (nw == 1 && x == c.wn.front()) {
+            v = al[0];
           }
           planes[t * Wl + i] = v;
         }
       }
-      pa.cia_poff[cc] = (int)(cia_planes.size() / ((size_t)2 * Wl));
-      const size_t npair = std::max<size_t>(c.temp.size() - 1, 1);
-      for (size_t t = 0; t < npair; t++) {
-        const size_t hi_t = std::min(t + 1, c.temp.size() - 1);
-        for (int i = 0; i < Wl; i++) {
-          cia_planes.push_back(planes[t * Wl + i]);
-          cia_planes.push_back(planes[hi_t * Wl + i]);
+      auto push_pairs = [&](const std::vector<double> &pl) {
+        const size_t npair = std::max<size_t>(ntc - 1, 1);
+        for (size_t t = 0; t < npair; t++) {
+          const size_t hi_t = std::min(t + 1, ntc - 1);
+          for (int i = 0; i < Wl; i++) {
+            cia_planes.push_back(pl[t * Wl + i]);
+            cia_planes.push_back(pl[hi_t * Wl + i]);
+          }
         }
-      }
+      };
+      pa.cia_poff[cc] = (int)(cia_planes.size() / ((size_t)2 * Wl));
+      push_pairs(planes);
       cia_temp.insert(cia_temp.end(), c.temp.begin(), c.temp.end());
+      if (cia_spline) {
+        // the second table of the file: second derivatives in T of the resampled planes
+        const int c2 = C++;
+        pa.cia_s1[c2] = pa.cia_s1[cc]; pa.cia_s2[c2] = pa.cia_s2[cc];
+        pa.cia_nt[c2] = pa.cia_nt[cc];
+        pa.cia_toff[c2] = (int)cia_temp.size();
+        pa.cia_kind[c2] = 1;
+        std::vector<double> y2t(planes.size(), 0.0);
+        for (int i = 0; i < Wl; i++) spline_y2(c.temp.data(), planes.data() + i, ntc, (size_t)Wl, y2t.data() + i);
+        pa.cia_poff[c2] = (int)(cia_planes.size() / ((size_t)2 * Wl));
+        push_pairs(y2t);
+        cia_temp.insert(cia_temp.end(), c.temp.begin(), c.temp.end());
+      }
     }
   }
   d_cia = dev_upload(cia_planes);

@@ -36,6 +36,7 @@ struct Engine {
   int solution = 0;       // 0 eclipse (emergent flux), 1 transit (modulation)
   int integ = 0;          // integration rule of the eclipse geometry (integ.hpp); cfg `integ`, BARTRT_INTEG
   bool cut_slant = false; // cfg `cut slant` / BARTRT_CUT: the toomuch cut per ray angle, on its slant depth (C19)
+  bool cia_spline = false; // cfg `cia_interp spline` / BARTRT_CIA_INTERP: natural cubic splines in wavenumber and T (C20)
   double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;
   double cloud_rup = 0, cloud_rdown = 0, cloud_ext = 0;  // radius-ramp cloud (cm, cm, cm-1); 0 = none

@@ -137,6 +137,8 @@ struct PrepArgs {
   int opmol[kMaxMol];      // [M] species index
   int cia_s1[kMaxCia], cia_s2[kMaxCia], cia_nt[kMaxCia], cia_toff[kMaxCia];
   int cia_poff[kMaxCia];   // first pair plane of table c in the CIA buffer
+  int cia_kind[kMaxCia];   // 0: the table's values; 1: their second derivatives in T (cfg `cia_interp spline`, the entry
+                           // after its values: weights (a^3 - a) h^2 / 6, (b^3 - b) h^2 / 6 instead of a, b)
   int ncia_temps;          // length of the concatenated CIA temperature grids
   // hydrostatic reference (code/makeatm.py:183-263)
   int ref_idx;             // layer closest to refpress

@@ -166,8 +166,15 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
       // pair plane jc of table cc holds (alpha_jc, alpha_jc+1) per wavenumber (a
       // single-temperature table: one pair plane with its values twice)
       ix[1 + cc] = (idx_t)(p.cia_poff[cc] + jc) * p.W * 16;
-      c[2 + 2 * M + 2 * cc] = n1 * n2 * (1.0 - fc);
-      c[3 + 2 * M + 2 * cc] = n1 * n2 * fc;
+      if (p.cia_kind[cc] == 0) {
+        c[2 + 2 * M + 2 * cc] = n1 * n2 * (1.0 - fc);
+        c[3 + 2 * M + 2 * cc] = n1 * n2 * fc;
+      } else {
+        // the spline's curvature terms on the planes of second derivatives (natural cubic spline in T)
+        const double sa = 1.0 - fc, h = nt > 1 ? tg[jc + 1] - tg[jc] : 0.0, s6 = n1 * n2 * h * h * (1.0 / 6.0);
+        c[2 + 2 * M + 2 * cc] = s6 * (sa * sa * sa - sa);
+        c[3 + 2 * M + 2 * cc] = s6 * (fc * fc * fc - fc);
+      }
     }
     double ray = 0.0;
     if (p.scat_flag == 1 && p.iH2 >= 0) {

@@ -161,6 +161,14 @@ int orc_extinction(const rt_oracle_cfg *c, const double *prof, double *ext,
         double wlo = n1 * n2 * (1.0 - f), whi = n1 * n2 * f;
         const double *alo = al + (size_t)j * W, *ahi = al + (size_t)(j + 1) * W;
         for (int i = 0; i < W; i++) e[i] += wlo * alo[i] + whi * ahi[i];
+        if (c->cia_spline && c->cia_y2) {
+          /* natural cubic spline through the file's temperatures (Numerical Recipes' splint):
+           * + ((a^3 - a) y2_j + (b^3 - b) y2_j+1) h^2 / 6, a = 1 - f, b = f */
+          double h = tg[j + 1] - tg[j], sa = 1.0 - f, sb = f;
+          double clo = n1 * n2 * (sa * sa * sa - sa) * h * h / 6.0, chi = n1 * n2 * (sb * sb * sb - sb) * h * h / 6.0;
+          const double *ylo = c->cia_y2 + aoff + (size_t)j * W, *yhi = c->cia_y2 + aoff + (size_t)(j + 1) * W;
+          for (int i = 0; i < W; i++) e[i] += clo * ylo[i] + chi * yhi[i];
+        }
       }
       toff += nt;
       aoff += (size_t)nt * W;

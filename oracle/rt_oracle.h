@@ -88,7 +88,9 @@ typedef struct {
    * cloud_ext below; cloud_ext = 0: none.  Unverified against transit's source. */
   double cloud_rup, cloud_rdown, cloud_ext;
   int transparent;          /* transit geometry: rays below the last chord keep its transmission */
-  int reserved2;
+  int cia_spline;           /* CIA interpolation (cfg `cia_interp`): 0 linear in wavenumber (at init)
+                             * and temperature; 1 natural cubic splines in both.  Unverified either way. */
+  const double *cia_y2;     /* cia_spline: second derivatives in T of cia_alpha, same layout; else NULL */
 } rt_oracle_cfg;
 
 /* Hydrostatic radii.  Follows code/makeatm.py:183-263 (radpress), in cgs and

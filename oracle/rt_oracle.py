@@ -37,7 +37,7 @@ class _Cfg(C.Structure):
         ("scat_value", C.c_double), ("scat_iH2", C.c_int), ("scat_iHe", C.c_int),
         ("starrad", C.c_double), ("extra_ext", C.c_void_p),
         ("cloud_rup", C.c_double), ("cloud_rdown", C.c_double), ("cloud_ext", C.c_double),
-        ("transparent", C.c_int), ("reserved2", C.c_int),
+        ("transparent", C.c_int), ("cia_spline", C.c_int), ("cia_y2", C.c_void_p),
     ]
 
 
@@ -151,7 +151,7 @@ class OracleEngine:
     """Oracle counterpart of the product engine: built from a transit cfg."""
 
     def __init__(self, tcfg: str, wn_lo: int | None = None, wn_hi: int | None = None,
-                 integ: int | None = None, cut: str | None = None):
+                 integ: int | None = None, cut: str | None = None, cia_interp: str | None = None):
         k = read_tcfg(tcfg)
         self.keys = k
         atm = read_atm(k["atm"])
@@ -183,13 +183,26 @@ class OracleEngine:
         self.wn = np.ascontiguousarray(wn[sl])
         self.kappa = np.ascontiguousarray(kap[:, :, :, sl]) if kap.shape[2] else np.zeros(1)
         W = len(self.wn)
-        s1, s2, cnt, ct, ca = [], [], [], [], []
+        s1, s2, cnt, ct, ca, cy = [], [], [], [], [], []
+        spline = (cia_interp or k.get("cia_interp", "linear")) == "spline"     # the product's cfg key
+        assert (cia_interp or k.get("cia_interp", "linear")) in ("linear", "spline")
         for f in [x for x in k.get("csfile", "").split(",") if x]:
             c = read_cia(f)
             s1.append(self.species.index(c["species"][0]))
             s2.append(self.species.index(c["species"][1]))
             cnt.append(len(c["temps"]))
             ct.append(c["temps"])
+            if spline:
+                # natural cubic spline in wn through the file's samples, zero outside the file; then the second
+                # derivatives in T of the resampled planes (natural spline through the file's temperatures)
+                from scipy.interpolate import CubicSpline
+                inside = (self.wn >= c["wn"][0]) & (self.wn <= c["wn"][-1])
+                pl = np.stack([np.where(inside, CubicSpline(c["wn"], a, bc_type="natural")(self.wn), 0.0)
+                               for a in c["alpha"]])
+                ca.append(pl)
+                cy.append(CubicSpline(c["temps"], pl, axis=0, bc_type="natural")(c["temps"], 2)
+                          if len(c["temps"]) > 2 else np.zeros_like(pl))
+                continue
             # resample on the spectrum grid: linear in wn, zero outside the file
             ca.append(np.stack([np.interp(self.wn, c["wn"], a, left=0.0, right=0.0)
                                 for a in c["alpha"]]))
@@ -215,6 +228,9 @@ class OracleEngine:
         c.tgrid, c.kappa, c.wn = _p(self.tgrid), _p(self.kappa), _p(self.wn)
         c.cia_s1, c.cia_s2, c.cia_nt = _p(self.cia_s1), _p(self.cia_s2), _p(self.cia_nt)
         c.cia_temp, c.cia_alpha = _p(self.cia_temp), _p(self.cia_alpha)
+        self.cia_y2 = np.ascontiguousarray(np.concatenate(cy)) if cy else None
+        c.cia_spline = int(bool(cy))
+        c.cia_y2 = _p(self.cia_y2) if cy else None
         c.angles_deg = _p(self.angles)
         c.toomuch = float(k.get("toomuch", 20.0))
         c.gsurf = float(k["gsurf"])

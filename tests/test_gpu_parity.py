@@ -2,6 +2,7 @@
 
 Tolerance: north_star states 1e-6 relative; the fp64 kernels are held to 1e-10
 here (differences come only from FMA contraction and libm vs ocml exp)."""
+import os
 import numpy as np
 import pytest
 
@@ -532,3 +533,57 @@ def test_cut_on_the_slant_depth(tmp_path, integ):
                     assert 1e-7 < d < 1e-2
             finally:
                 trm.free_memory()
+
+
+@pytest.mark.parametrize("npairs,solution", [(1, "eclipse"), (2, "eclipse"), (1, "transit")])
+def test_cia_interpolated_by_splines(tmp_path, npairs, solution):
+    """`cia_interp spline`: natural cubic splines in wavenumber (at init) and in temperature
+    (per layer) instead of linear interpolation.  CIA files with curvature in both directions, a coarse
+    wavenumber sampling and an uneven temperature grid; one file (the second-derivative planes ride as a
+    second table: the single-wave kernels run) and two (four table slots: the generic kernel); batches,
+    temperatures beyond the files' range (clamped), eclipse and transit geometry.  The product solves its own
+    tridiagonal systems; the oracle takes scipy's CubicSpline.  Against the linear rule the spectra move."""
+    from bart_amd import engine, synth, transit_module as trm
+    from oracle import rt_oracle as orc
+    extra = {"cia_interp": "spline"}
+    if solution == "transit":
+        extra.update({"solution": "transit", "starrad": 1.145})
+    c = synth.make_case(str(tmp_path), nlayers=30, nwave=260, cia=npairs, extra_keys=extra)
+    rng = np.random.default_rng(5)
+    for n, path in enumerate(c.cia):
+        s1, s2 = (("H2", "H2"), ("H2", "He"))[n]
+        ct = np.array([300.0, 450.0, 700.0, 1000.0, 1300.0, 1900.0, 2400.0]) + 30.0 * n
+        cw = np.arange(c.wn[0] - 30.0, c.wn[-1] + 41.0, 17.0 + 6.0 * n)
+        al = (3e-6 / (1 + n)) * (ct[:, None] / 1000.0) ** 1.7 * np.exp(-((ct[:, None] - 1200.0) / 900.0) ** 2) \
+            * (1.2 + np.sin(cw[None, :] / (23.0 + 5 * n))) * np.exp(0.1 * rng.normal(size=(1, len(cw))))
+        synth.write_cia(path, s1, s2, ct, cw, al)
+    profs = walkers(c, 6, seed=8)          # temperatures 400 .. 3000 K: both sides of the files' ranges
+    profs[0, :c.temp0.size] = 250.0 + 40.0 * np.arange(c.temp0.size)
+    o = orc.OracleEngine(c.tcfg)
+    assert o.c.cia_spline == 1 and o.c.ncia == npairs
+    ref = o.run_batch(profs)
+    lin = orc.OracleEngine(c.tcfg, cia_interp="linear").run_batch(profs)
+    assert np.abs(ref / lin - 1).max() > 1e-4           # the switch matters at the 1e-6 contract
+    engine.init(c.tcfg)
+    try:
+        tol = dict(rtol=RTOL, atol=1e-12 * np.abs(ref).max())
+        np.testing.assert_allclose(engine.run_batch(profs), ref, **tol)
+        np.testing.assert_allclose(engine.run_batch(profs[2:3]), ref[2:3], **tol)
+        for integ in ((0, 2) if solution == "eclipse" else ()):
+            trm.set_integ(integ)
+            np.testing.assert_allclose(engine.run_batch(profs), orc.OracleEngine(c.tcfg, integ=integ).run_batch(profs),
+                                       rtol=RTOL)
+    finally:
+        trm.free_memory()
+    # the other value, through the environment
+    os.environ["BARTRT_CIA_INTERP"] = "linear"
+    try:
+        engine.init(c.tcfg)
+        np.testing.assert_allclose(engine.run_batch(profs), lin, rtol=RTOL, atol=1e-12 * np.abs(lin).max())
+    finally:
+        del os.environ["BARTRT_CIA_INTERP"]
+        trm.free_memory()
+    bad = c.tcfg + ".bad"
+    open(bad, "w").write(open(c.tcfg).read().replace("cia_interp spline", "cia_interp cubic"))
+    with pytest.raises(Exception, match="cia_interp"):
+        engine.init(bad)

@@ -26,11 +26,6 @@ PEAK_HBM_GBS = 8000.0
 PEAK_L2_GBS = 34500.0          # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate
 PEAK_FP64_TFLOPS = 78.6        # vector fp64; the fp64 matrix pipe has the same peak on this part
 PEAK_FP64_TOPS = PEAK_FP64_TFLOPS / 2.0   # fp64 VALU lane-operations per second (an FMA is ONE operation)
-# fp64 VALU operations of one Voigt sample by branch of voigt_k (csrc/lbl.hip, counted in the source:
-# reciprocal + Newton steps, synthetic-division steps at two FMAs per coefficient, the accumulate):
-# far wing |z| >= 100 (three-term series, real arithmetic), 8 <= |z| < 100 (eleven-term series),
-# |z| < 8 (Weideman N = 40)
-VOIGT_OPS = {"far": 25, "mid": 42, "core": 110}
 
 
 def _time_launches(engine, torch, d_prof, out, steps, warm=5):
@@ -232,17 +227,17 @@ def lbl(integ, wnosamps=(1, 2160)):
     for o in wnosamps:
         with contextlib.redirect_stdout(io.StringIO()):
             r = lbl_bench.run(["--wnosamp", str(o), "--reps", "3"])
-        ops = sum(VOIGT_OPS[k] * r["voigt_samples_by_branch"][k] for k in VOIGT_OPS)
+        ops = r["voigt_fp64_ops"]
         out["lbl_wnosamp%d" % o] = {
             "workload": "BASELINE config 5: " + r["workload"],
             "value": r["value"], "unit": "spectra/s", "ms_per_step": r["seconds_per_spectrum"] * 1e3,
             "voigt_samples": r["voigt_samples"], "voigt_samples_per_s": r["voigt_samples_per_s"],
-            "roofline": {"bound": "fp64_valu (Voigt arithmetic: 25-110 fp64 operations per profile sample, under "
+            "roofline": {"bound": "fp64_valu (Voigt arithmetic: 19-105 fp64 operations per profile sample, under "
                                   "one byte per sample)",
                          "achieved": ops / r["seconds_per_spectrum"] / 1e12, "peak": PEAK_FP64_TOPS,
                          "unit": "Tops/s (fp64 VALU lane-operations; an FMA counts once; peak = 78.6 TFLOP/s / 2)",
                          "frac": ops / r["seconds_per_spectrum"] / 1e12 / PEAK_FP64_TOPS,
-                         "op_model": {"per_sample": VOIGT_OPS, "samples_by_branch": r["voigt_samples_by_branch"],
+                         "op_model": {"per_sample": r["voigt_ops_model"], "samples_by_branch": r["voigt_samples_by_branch"],
                                         "note": "samples inside the lines' cuts by branch of the Faddeeva evaluation "
                                                 "(tools/lbl_bench.py work_units) x the branch's fp64 operations; "
                                                 "staging, strengths and the reduction of oversampled layers are not "

@@ -24,6 +24,15 @@ H, LS, KB, AMU = 6.6260755e-27, 2.99792458e10, 1.380658e-16, 1.66053886e-24
 MOLS = ("H2O", "CO", "CO2", "CH4")
 
 
+# fp64 VALU operations of one Voigt sample by branch of voigt_k (csrc/lbl.hip; counted in the gfx950 assembly of
+# lbl_accumulate_fine, the function value and its accumulation, without the step's bookkeeping): far wing
+# |z| >= 100 (three series terms as a polynomial in one variable), 17 <= |z| < 100 (six terms), 8 <= |z| < 17
+# (eleven), |z| < 8: Weideman N = 36 for y > 0.13, else the expansion about the real axis (order 2-10 by y)
+VOIGT_OPS = {"far": 19, "series6": 32, "series11": 42, "weideman": 98, "taylor0": 42, "taylor_per_order": 7}
+TAYLOR_YMAX = 0.13
+TAYLOR_STEPS = np.array([6.0e-6, 5.0e-4, 3.0e-3, 9.5e-3, 2.2e-2, 4.0e-2, 6.5e-2, 9.5e-2])
+
+
 def work_units(case, nwidth, ethresh, wnosamp):
     """Kept (line, layer) pairs and Voigt samples inside their cuts (numpy; the widths
     of scripts/broadening.py:121-143 and the sampling rule of DESIGN.md C15)."""
@@ -39,6 +48,7 @@ def work_units(case, nwidth, ethresh, wnosamp):
     divs = [d for d in range(1, wnosamp + 1) if wnosamp % d == 0]
     kept = samples = 0.0
     branch = {"far": 0.0, "mid": 0.0, "core": 0.0}   # by branch of voigt_k (csrc/lbl.hip): |z| >= 100, 8 .. 100, < 8
+    ops = 0.0                                        # fp64 VALU operations of those samples (VOIGT_OPS below)
     dvs = []
     for l in range(len(press)):
         per_db, wmin = [], np.inf
@@ -75,10 +85,17 @@ def work_units(case, nwidth, ethresh, wnosamp):
             y2 = (aLv[keep] / sc) ** 2
             in8 = np.minimum(cut, sc * np.sqrt(np.maximum(64.0 - y2, 0.0)))
             in100 = np.minimum(cut, sc * np.sqrt(np.maximum(1e4 - y2, 0.0)))
+            in17 = np.minimum(cut, sc * np.sqrt(np.maximum(289.0 - y2, 0.0)))
             branch["core"] += (2 * in8 / step).sum()
             branch["mid"] += (2 * (in100 - in8) / step).sum()
             branch["far"] += (2 * (cut - in100) / step).sum()
-    return kept, samples, dvs, branch
+            yy = np.sqrt(y2)
+            order = np.where(yy <= TAYLOR_YMAX, 2 + (yy[:, None] > TAYLOR_STEPS[None, :]).sum(axis=1), 0)
+            core_ops = np.where(order > 0, VOIGT_OPS["taylor0"] + VOIGT_OPS["taylor_per_order"] * (order - 1),
+                                VOIGT_OPS["weideman"])
+            ops += (2 * in8 / step * core_ops).sum() + VOIGT_OPS["series11"] * (2 * (in17 - in8) / step).sum() \
+                + VOIGT_OPS["series6"] * (2 * (in100 - in17) / step).sum() + VOIGT_OPS["far"] * (2 * (cut - in100) / step).sum()
+    return kept, samples, dvs, branch, ops
 
 
 def run(argv=None):
@@ -117,7 +134,7 @@ def run(argv=None):
     best = min(ts)
     integ = trm.get_integ()
     trm.free_memory()
-    kept, samples, dvs, branch = work_units(case, 20.0, 1e-6, a.wnosamp)
+    kept, samples, dvs, branch, ops = work_units(case, 20.0, 1e-6, a.wnosamp)
     pairs = 4 * a.lines * a.nlayers
     res = {
         "metric": "line-by-line spectra/sec (1e6 lines x 1e5 wavenumbers x 100 layers, BASELINE config 5)",
@@ -128,7 +145,7 @@ def run(argv=None):
         "seconds_per_spectrum": best, "all_runs_s": ts, "init_s": t_init, "input_generation_s": t_gen,
         "line_layer_pairs_per_s": pairs / best,
         "kept_line_layer_pairs": kept, "voigt_samples": samples, "voigt_samples_per_s": samples / best,
-        "voigt_samples_by_branch": branch, "integ": integ,
+        "voigt_samples_by_branch": branch, "voigt_fp64_ops": ops, "voigt_ops_model": VOIGT_OPS, "integ": integ,
         # 24 B per line per layer (wavenumber, E_low, gf; + 4 B isotope id here) + the
         # extinction array written once and read once by the RT kernel
         "algorithmic_bytes": 28.0 * pairs + 2 * 8.0 * a.nlayers * n,

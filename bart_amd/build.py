@@ -13,7 +13,7 @@ CLI = os.path.join(HERE, "transit")
 SOURCES = ["rt_eclipse_angles.hip", "rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
            "transit_geom.hip",
            "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "io.cpp"]   # longest first
-HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
+HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
 
 

@@ -488,16 +488,22 @@ def main():
         # set-up above leaves the GPU idle for seconds (host-side byte model, event pool) and its clocks low;
         # a warm-up of W = 20 steps is 1.5 ms, and the first window after it measured 81 us per step against
         # 71-73 in the fifteen windows that followed.  A retrieval runs for hours: steady state is the figure.
-        if a.spinup_ms > 0 and not dry:
+        if a.spinup_ms > 0 and (gather or not dry):   # (the dry run walks the collective form with 16 calls)
             t_end = time.perf_counter() + a.spinup_ms * 1e-3
             i = 0
-            while time.perf_counter() < t_end:
-                for _ in range(16):
-                    out = step(i)
-                    i += 1
-                sync()
             if gather:
-                out = (drain(i - 1) or [out])[-1]
+                # collectives inside: every rank must make the same number of calls -- a fixed count (about the
+                # same time at the single-GPU step rate) instead of each rank's own clock
+                nspin = 16 if dry else max(16, int(a.spinup_ms * 1e-3 / 75e-6 / max(1, nwalk / 10.0)) // 16 * 16)
+                for i in range(nspin):
+                    out = step(i)
+                out = (drain(nspin - 1) or [out])[-1]
+            else:
+                while time.perf_counter() < t_end:
+                    for _ in range(16):
+                        out = step(i)
+                        i += 1
+                    sync()
         for i in range(warmup):
             out = step(i)
         if gather and warmup:

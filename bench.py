@@ -494,7 +494,7 @@ def main():
             if gather:
                 # collectives inside: every rank must make the same number of calls -- a fixed count (about the
                 # same time at the single-GPU step rate) instead of each rank's own clock
-                nspin = 16 if dry else max(16, int(a.spinup_ms * 1e-3 / 75e-6 / max(1, nwalk / 10.0)) // 16 * 16)
+                nspin = 16 if dry else max(16, int(a.spinup_ms * 1e-3 / 75e-6 / max(1.0, a.walkers / 10.0)) // 16 * 16)
                 for i in range(nspin):
                     out = step(i)
                 out = (drain(nspin - 1) or [out])[-1]

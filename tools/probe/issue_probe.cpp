@@ -1,6 +1,7 @@
 // What can ONE wave issue on a SIMD, and what do two?  fp64 FMA chains (1, 2, 4, 8 independent accumulators per
 // lane) timed with the shader clock, one or two waves per SIMD (grid sized to the 1024 SIMDs), plus the other
-// instruction kinds of the RT kernel's layer loop (v_mul / v_add / v_rcp_f64, 64-bit selects, ds_read broadcast).
+// instruction kinds of the RT kernel's layer loop (v_mul / v_add / v_rcp_f64, 64-bit selects, ds_read broadcast,
+// scalar instructions between the FMAs).
 //   hipcc -O2 --offload-arch=gfx950 tools/probe/issue_probe.cpp -o tools/probe/issue_probe
 #include <hip/hip_runtime.h>
 
@@ -29,6 +30,16 @@ __global__ __launch_bounds__(64) void chains(double *out, long long *cyc, int it
         if (KIND == 3) a[c] = __builtin_amdgcn_rcp(a[c]);
         if (KIND == 4) a[c] = a[c] > 1.5 ? a[c] * m : b;     // compare + 64-bit select + mul
         if (KIND == 5) a[c] = fma(a[c], lds[(u * CH + c) & 63], b);   // broadcast LDS read feeding an FMA
+        if (KIND == 6) {   // an FMA and two independent scalar moves (what a 64-bit literal costs)
+          int t0_, t1_;
+          asm volatile("s_mov_b32 %0, 0x12345678\n\ts_mov_b32 %1, 0x3ff00000" : "=s"(t0_), "=s"(t1_));
+          a[c] = fma(a[c], m, b);
+        }
+        if (KIND == 7) {   // an FMA and an independent scalar ALU instruction
+          int t;
+          asm volatile("s_add_u32 %0, 1, 2" : "=s"(t) : : "scc");
+          a[c] = fma(a[c], m, b);
+        }
       }
     }
   }
@@ -61,7 +72,7 @@ int main() {
   long long *d_cyc;
   (void)hipMalloc(&d_out, sizeof(double) * 64 * 4096);
   (void)hipMalloc(&d_cyc, sizeof(long long) * 2 * 4096);
-  for (int nwg : {1024, 2048, 3072}) {
+  for (int nwg : {1024, 2048}) {
     run<1, 0>("v_fma_f64 dependent", nwg, d_out, d_cyc);
     run<2, 0>("v_fma_f64", nwg, d_out, d_cyc);
     run<4, 0>("v_fma_f64", nwg, d_out, d_cyc);
@@ -71,6 +82,8 @@ int main() {
     run<4, 3>("v_rcp_f64", nwg, d_out, d_cyc);
     run<4, 4>("cmp + select64 + mul", nwg, d_out, d_cyc);
     run<4, 5>("ds_read broadcast + fma", nwg, d_out, d_cyc);
+    run<4, 6>("2 s_mov + fma", nwg, d_out, d_cyc);
+    run<4, 7>("s_add + fma", nwg, d_out, d_cyc);
   }
   return 0;
 }

@@ -39,7 +39,7 @@ if __name__ == "__main__":
         a, L = coef(len(tab))
         print("N =", len(tab), "max |recipe - header| =", np.abs(a - tab).max())
         sys.exit(0 if np.array_equal(a, tab) else 1)
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 36
     a, L = coef(N)
     from scipy.special import wofz
     rng = np.random.default_rng(3)

@@ -61,7 +61,10 @@ def _run(tmp_path, seed, integ=0, ramp=False):
         spec, ok = engine.run_batch(profs, want_ok=True)
         assert ok.all()
         ref = o.run_batch(profs)
-        np.testing.assert_allclose(spec, ref, rtol=RTOL, atol=1e-300,
+        # rule 1 on coarse columns (13 layers, optical-depth steps >> 1) sums panels of alternating sign a thousand
+        # times the result: there the kernel's difference form and the restatement's agree to 1e-12 of the
+        # largest sample, not of each (tools/fuzz_sweep.py 200-560: five such columns, <= 8e-13 of the maximum)
+        np.testing.assert_allclose(spec, ref, rtol=RTOL, atol=1e-12 * np.abs(ref).max() if integ == 1 else 1e-300,
                                    err_msg="%s %s walkers=%d cloud=%s integ=%d" % (geometry, kw, nwalk, cloud, integ))
     finally:
         trm.free_memory()

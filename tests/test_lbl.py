@@ -557,3 +557,34 @@ def test_line_by_line_in_transit_geometry(tmp_path, nlayers, transparent):
             np.testing.assert_allclose(got[w], ref, rtol=1e-9)
     finally:
         trm.free_memory()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wnosamp,ptop,pbottom", [(1, 1e-6, 1e-2), (90, 1e-6, 1e-2), (1, 1e-3, 30.0)])
+def test_voigt_expansion_switch(tmp_path, wnosamp, ptop, pbottom):
+    """`BARTRT_VOIGT_TAYLOR=0` (A/B runs) evaluates every |z| < 8 sample with Weideman's rational approximation, the
+    default takes the expansion about the real axis where y <= 0.13 -- Doppler-dominated layers, on the output
+    grid and oversampled, and pressure-broadened ones where the switch must change nothing but rounding.  The two
+    agree to the rational approximation's own accuracy, and each with the oracle (scipy's wofz)."""
+    import os
+    from bart_amd import engine, synth_lbl, transit_module as trm
+    from oracle import lbl_oracle
+    c = synth_lbl.make_lbl_case(str(tmp_path), nlines=1200, nwave=250, nlayers=10, wndelt=0.05, ptop=ptop,
+                                pbottom=pbottom, wnosamp=wnosamp)
+    prof = c.profiles()
+    ref = lbl_oracle.LblOracle(c.tcfg).extinction(prof)
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["BARTRT_VOIGT_TAYLOR"] = flag
+        try:
+            engine.init(c.tcfg)
+            out[flag] = engine.lbl_extinction(prof)
+        finally:
+            del os.environ["BARTRT_VOIGT_TAYLOR"]
+            trm.free_memory()
+        np.testing.assert_allclose(out[flag], ref, rtol=RTOL, atol=1e-30)
+    # (N = 36 is good to 8e-10 where K > 1e-6 of the line centre and loses from there down: samples that a single
+    # line's far core dominates differ by up to 1e-8 -- the rational approximation's error, the expansion's is 3e-12)
+    np.testing.assert_allclose(out["1"], out["0"], rtol=5e-8, atol=1e-30)
+    if pbottom < 1.0:
+        assert not np.array_equal(out["1"], out["0"])      # the branch is taken

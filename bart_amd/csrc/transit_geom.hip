@@ -124,6 +124,8 @@ __global__ __launch_bounds__(64) void rt_transit(RtArgs p) {
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kMfmaTiles = 8;      // row tiles of 16 chords: L <= 128
 constexpr int kMfmaTilesDeep = 16;  // L <= 256: twice the pair-sum registers, half the waves per SIMD
+constexpr int kMfmaTilesMax = 20;   // L <= 320 (the most layers the transit geometry takes at all): one wave per SIMD,
+                                    // the pair sums spill into AGPRs -- still the matrix tiles, not the scalar kernel
 
 // EXT: the line-by-line hand-off -- the layer's line extinction ext[w][l][W] (atm layer order) is
 // one more 8-byte load per (layer, wavenumber) and one more addend (such engines have no table).
@@ -317,7 +319,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   const bool window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
   const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!window || window_fits(a, 4));
   if (!generic_only && a.ext && a.M == 0 && a.C <= 2 && !a.tau_out && a.cia_bytes < (1ull << 32) - 4096 &&
-      a.L <= 16 * kMfmaTilesDeep) {
+      a.L <= 16 * kMfmaTilesMax) {
     // line-by-line engines (no table): the matrix-tile kernel with the extinction array as input
     RtArgs b = a;
     b.window = 0;
@@ -328,14 +330,16 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   if (a.C == CC) {                                                                                   \
     if (a.L <= 16 * kMfmaTiles)                                                                      \
       BARTRT_RT_LAUNCH((rt_transit_mfma<0, CC, kMfmaTiles, true>), dim3(nb), dim3(256), shm, st, b);  \
-    else                                                                                             \
+    else if (a.L <= 16 * kMfmaTilesDeep)                                                             \
       BARTRT_RT_LAUNCH((rt_transit_mfma<0, CC, kMfmaTilesDeep, true>), dim3(nb), dim3(256), shm, st, b); \
+    else                                                                                             \
+      BARTRT_RT_LAUNCH((rt_transit_mfma<0, CC, kMfmaTilesMax, true>), dim3(nb), dim3(256), shm, st, b); \
     return hipGetLastError();                                                                        \
   }
     BARTRT_TRANSIT_EXT(0) BARTRT_TRANSIT_EXT(1) BARTRT_TRANSIT_EXT(2)
 #undef BARTRT_TRANSIT_EXT
   }
-  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesDeep) {
+  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesMax) {
     RtArgs b = a;
     b.window = window;
     b.ntiles = (a.W + 63) / 64;
@@ -346,8 +350,10 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   if (a.M == MM && a.C == CC) {                                                             \
     if (a.L <= 16 * kMfmaTiles)                                                             \
       BARTRT_RT_LAUNCH((rt_transit_mfma<MM, CC, kMfmaTiles>), dim3(nb), dim3(256), shm, st, b); \
-    else                                                                                    \
+    else if (a.L <= 16 * kMfmaTilesDeep)                                                    \
       BARTRT_RT_LAUNCH((rt_transit_mfma<MM, CC, kMfmaTilesDeep>), dim3(nb), dim3(256), shm, st, b); \
+    else                                                                                    \
+      BARTRT_RT_LAUNCH((rt_transit_mfma<MM, CC, kMfmaTilesMax>), dim3(nb), dim3(256), shm, st, b); \
     return hipGetLastError();                                                               \
   }
     BARTRT_MC_LIST(BARTRT_TRANSIT)

@@ -105,11 +105,11 @@ def test_device_matches_oracle(tmp_path, kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nlayers,nwave", [(16, 15), (17, 65), (100, 130), (128, 64), (129, 40), (200, 70),
-                                          (256, 33), (257, 20)])
+                                          (256, 33), (257, 20), (300, 70), (320, 17)])
 def test_matrix_tiles_and_cloud_deck(tmp_path, nlayers, nwave):
     """The batched transit kernel works in 16-chord x 16-wavenumber matrix tiles
-    (up to 128 layers, a deeper instantiation up to 256; 257 falls through to the
-    generic kernel): layer counts at
+    (up to 128 layers, deeper instantiations up to 256 and up to 320 -- the most layers the
+    transit geometry takes): layer counts at
     tile edges, fewer wavenumbers than a wave, and an opaque cloud deck moved
     through the column so the stop layer lands in every row tile."""
     from bart_amd import engine, transit_module as trm

@@ -105,6 +105,26 @@ __device__ __forceinline__ double imw_row(const double *tab, int i, double t) {
   return fma(D, t, c01.x);
 }
 
+// exp_rt's arithmetic (kernels.hpp) with the Horner steps spelled as three-operand v_fma_f64: in these kernels
+// the nine coefficients live in VGPRs (no scalar registers left), and the compiler's two-address form
+// (v_fmac after a copy of the coefficient) costs a v_mov per step.  Same operations, same bits.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double exp_rt_fma3(double x) {
+  const double t = fma(x, 1.4426950408889634074, kExpShift);
+  const double r = fma(t - kExpShift, -6.93147180559945286227e-01, x);
+  constexpr double cf[9] = {2.4867870179687727e-05, 0.00019841224599656011, 0.0013888839110572009,
+                            0.0083333333442029804,  0.041666666786265731,   0.16666666666662586,
+                            0.49999999999955108,    1.0,                    1.0};
+  double q = 2.7617564785876086e-06;
+#pragma unroll
+  for (int j = 0; j < 9; j++) q = fma3(q, r, cf[j]);
+  return exp_scale(q, t);
+}
+
 constexpr double kInvN[12] = {0.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11};
 
 // |z| < 8: straight-line code per order (a wave-uniform order takes one scalar branch; where the lanes of a
@@ -116,7 +136,7 @@ __device__ __forceinline__ double voigt_taylor_n(double x, double y, double x2, 
   const double xs = x * (double)(kImwPieces / 8);
   const int i = min((int)xs, kImwPieces - 1);
   const double D = imw_row(tab, i, xs - ((double)i + 0.5));
-  const double E = exp_rt(-x2);
+  const double E = exp_rt_fma3(-x2);
   const double al = (x + x) * y, be = (y + y) * y;
   // (p0, q0) and (p1, q1) hold Re, Im of two successive terms; each step overwrites the older one
   double p0 = E, q0 = D;
@@ -769,7 +789,8 @@ __global__ __launch_bounds__(1024) void lbl_accumulate_fine(LblDev d, AccArgs a,
               s_fine[k] = add_rounded(s_fine[k], mul_rounded(l_amp, voigt_k(dx * l_xs, l_y, s_tab, [&] { return l_ord; })));
           };
           const int nl = kc0 - klo, nw = nl + (khi - kc1);
-          for (int b = lane; b < nw; b += 64) point(b < nl ? klo + b : kc1 + 1 + (b - nl));
+          const int gap = kc1 + 1 - nl - klo;     // what the right wing's points lie beyond the left wing's run
+          for (int b = lane; b < nw; b += 64) point(klo + b + (b < nl ? 0 : gap));
           for (int k = kc0 + lane; k <= kc1; k += 64) point(k);
         }
         wave_sync();

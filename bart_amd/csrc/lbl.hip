@@ -93,9 +93,14 @@ __device__ __forceinline__ void load_imw_table(double *tab) {
 // D at local coordinate t of row i
 __device__ __forceinline__ double imw_row(const double *tab, int i, double t) {
 #pragma clang fp contract(off)
-  const ImwRow *row = reinterpret_cast<const ImwRow *>(tab) + i;
-  const float4 hi = *reinterpret_cast<const float4 *>(row->f);
-  const double2 c01 = *reinterpret_cast<const double2 *>(row->c), c23 = *reinterpret_cast<const double2 *>(row->c + 2);
+  // (an LDS pointer and a 32-bit row offset: through the generic pointer the row address is a 64-bit multiply-add)
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  const unsigned base = (unsigned)(unsigned long long)tab;   // the low half of a generic pointer into LDS is its LDS address
+  const unsigned row = base + __umul24((unsigned)i, (unsigned)sizeof(ImwRow));
+  const f4_t hi = *(const f4_t __attribute__((address_space(3))) *)(size_t)(row + 32);
+  const d2_t c01 = *(const d2_t __attribute__((address_space(3))) *)(size_t)(row),
+             c23 = *(const d2_t __attribute__((address_space(3))) *)(size_t)(row + 16);
   double D = fma((double)hi.w, t, (double)hi.z);
   D = fma(D, t, (double)hi.y);
   D = fma(D, t, (double)hi.x);

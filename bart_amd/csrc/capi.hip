@@ -352,7 +352,7 @@ int bartrt_timing_begin_sampled(int stride) {
   return guarded([&] {
     // the events of the sampled launches are created here, outside the caller's timed region (created on
     // demand inside it they cost the first window of bench.py 10 us per step: 81 against 71)
-    while (g_eng->ev.size() < 512) {
+    while (g_eng->ev.size() < 4096) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
       g_eng->ev.push_back(e);

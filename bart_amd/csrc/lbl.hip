@@ -67,7 +67,7 @@ __device__ __forceinline__ double voigt_far(double x2, double y, double r2) {
 // banks -- 64-byte rows cost 1.2e10 bank-conflict cycles per spectrum of config 5, these 1.6e9.
 // 7 operations per order; the order follows y alone (voigt_order: 2 for y <= 6e-6 ... 10 for y <= 0.13, each
 // chosen so that the first omitted term is below 3e-12 of K over the whole of |z| < 8): <= 2.5e-12 relative
-// everywhere, against 1e-10 of the rational approximation it replaces there, at 47 - 100 VALU operations
+// everywhere, against 1e-10 of the rational approximation it replaces there, at 40 - 93 VALU operations
 // per sample against 96.  (The same expansion for the wings, 8 <= |z| < 17 with exp(-x^2) dropped, was built
 // and measured: the table index and the cancellation-safe form cost what the eleven-term series costs, 40.)
 constexpr double kTwoInvSqrtPi = 1.1283791670955126;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
   double *sRt = smem + (size_t)L * NC + (size_t)L * NI;  // radii top -> bottom, [L]
   stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
                 threadIdx.x, 256);
-  if ((int)threadIdx.x < L) sRt[threadIdx.x] = p.rtop[(size_t)w * L + threadIdx.x];
+  for (int l = threadIdx.x; l < L; l += 256) sRt[l] = p.rtop[(size_t)w * L + l];   // (L can exceed the 256 lanes)
   __syncthreads();
 
   const int lane = threadIdx.x & 63;

@@ -40,14 +40,28 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", 
              "-Wall", "-Wno-unused-result", *os.environ.get("BARTRT_CXXFLAGS", "").split()]
+    def stale(obj: str, src: str) -> bool:
+        """The object is older than its source, this script (the flags) or a header it includes (the
+        compiler's own dependency file, written next to the object; without one: any header)."""
+        if force or not os.path.exists(obj):
+            return True
+        t = os.path.getmtime(obj)
+        deps = [os.path.join(CSRC, src), os.path.abspath(__file__)]
+        try:
+            txt = open(obj + ".d").read().replace("\\\n", " ")
+            deps += [d for d in txt.split(":", 1)[1].split() if d.startswith(HERE) or d.startswith(os.path.dirname(HERE))]
+        except (OSError, IndexError):
+            deps += [os.path.join(CSRC, h) for h in HEADERS]
+        return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
     def compile_one(job) -> str:
         src, name, extra = job
         obj = os.path.join(CSRC, name + ".o")
-        cmd = [_hipcc(), *flags, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if not stale(obj, src):
+            return obj
+        cmd = [_hipcc(), *flags, *extra, "-MD", "-MF", obj + ".d", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -62,11 +76,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # translation units are independent: a few compilers side by side
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, jobs))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
-    subprocess.check_call(cmd)
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
+        subprocess.check_call(cmd)
     # the standalone `transit` executable (C ABI only), found next to the library
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(CSRC, "transit_main.cpp"),
-                           "-o", CLI, "-L" + HERE, "-lbartrt", "-Wl,-rpath,$ORIGIN"])
+    main_cpp = os.path.join(CSRC, "transit_main.cpp")
+    if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < max(os.path.getmtime(LIB), os.path.getmtime(main_cpp)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", main_cpp,
+                               "-o", CLI, "-L" + HERE, "-lbartrt", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -119,6 +119,13 @@ int bartrt_get_cut(int *slant) {
   return BARTRT_OK;
 }
 
+int bartrt_get_cia_interp(int *spline) {
+  NEED_ENGINE();
+  if (!spline) return fail(BARTRT_EINVAL, "get_cia_interp: null output pointer");
+  *spline = g_eng->cia_spline ? 1 : 0;
+  return BARTRT_OK;
+}
+
 int bartrt_prefetch_profiles_dev(const double *d_prof_next, int nwalkers) {
   NEED_ENGINE();
   if (nwalkers < 0 || (nwalkers > 0 && !d_prof_next)) return fail(BARTRT_EINVAL, "prefetch_profiles_dev: null buffer");
@@ -228,6 +235,10 @@ int bartrt_run_transit_batch_dev(const double *d_prof, int nwalkers, double *d_s
   if (!d_prof || !d_spec || nwalkers < 0) return fail(BARTRT_EINVAL, "run_transit_batch_dev: null buffer");
   return guarded([&] {
     hipStream_t st = stream ? (hipStream_t)stream : g_eng->stream;
+    // device-buffer calls keep no profile: the optical-depth / intensity getters must not fall
+    // back on an older host-buffer call's
+    g_eng->last_prof = nullptr;
+    g_eng->last_n = 0;
     g_eng->run_dev(d_prof, nwalkers, d_spec, d_ok, st, false);
     return BARTRT_OK;
   });

@@ -549,9 +549,21 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   // prefetched preparation: only the plain table path of the eclipse geometry takes part
   const bool pf_ok = !prep_hook && !prep_over_once && !lbl_fused && !d_ext && solution == 0 && !want_tau &&
                      !want_intens && !lbl;
-  const bool want_next = pf_ok && pf_req_prof && pf_req_n > 0;
-  if (want_next && pf_req_n > cap_walkers) ensure_walkers(pf_req_n);   // (drops prefetched records)
-  const bool have = pf_ok && pf_have_prof && pf_have_prof == d_prof_in && pf_have_n == n;
+  bool want_next = pf_ok && pf_req_prof && pf_req_n > 0;
+  if (want_next && pf_req_n > cap_walkers) {
+    // the workspaces have to grow for the named batch: not under a call whose own buffers are the
+    // engine's (a host-buffer batch: growing frees what it is about to read and write) -- such a
+    // request is dropped, the named batch is prepared by its own call
+    const bool own = d_prof_in == d_prof || d_spec_out == d_spec || d_okp == d_ok;
+    if (own) want_next = false;
+    else ensure_walkers(pf_req_n);   // (drops prefetched records)
+  }
+  // the settings the layer records are built from, as they stand for THIS call: records prefetched
+  // under other settings (a bartrt_set_radius / _cloudtop / _scattering in between) or on another
+  // stream are not used -- the call prepares its own
+  const PrepSettings now{refradius, gsurf, cloudtop, scat_value, cloud_rup, cloud_rdown, cloud_ext, has_cloud, scat_flag};
+  const bool have = pf_ok && pf_have_prof && pf_have_prof == d_prof_in && pf_have_n == n && pf_have_stream == st &&
+                    pf_have_set == now;
   const int bset = have ? pf_have_buf : 0;        // record buffers this call's RT kernel reads
   pf_have_prof = nullptr;
   if (want_next) {
@@ -608,6 +620,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     pn.coef = coef_b[1 - bset]; pn.idx = idx_b[1 - bset]; pn.kstop = kstop_b[1 - bset];
     pn.ok = ok_b[1 - bset];
     pn.over = nullptr;
+    pn.rad_out = nullptr;   // (bartrt_get_radius: the radii of the batch this call computes)
     r.nprep = pf_req_n;
     r.prep_next = pn;
   }
@@ -672,6 +685,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     if (want_walked) walked_info = li;
     if (want_next && li.prep_fused) {
       pf_have_prof = pf_req_prof; pf_have_n = pf_req_n; pf_have_buf = 1 - bset;
+      pf_have_stream = st; pf_have_set = now;
     }
   }
   pf_req_prof = nullptr;

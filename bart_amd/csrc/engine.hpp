@@ -95,6 +95,18 @@ struct Engine {
   int pf_req_n = 0;
   const double *pf_have_prof = nullptr;  // records of this batch are in buffer set pf_have_buf
   int pf_have_n = 0, pf_have_buf = 0;
+  // ... built on this stream under these settings (everything of PrepArgs a setter can change)
+  struct PrepSettings {
+    double refradius, gsurf, cloudtop, scat_value, cloud_rup, cloud_rdown, cloud_ext;
+    int has_cloud, scat_flag;
+    bool operator==(const PrepSettings &o) const {
+      return refradius == o.refradius && gsurf == o.gsurf && cloudtop == o.cloudtop && scat_value == o.scat_value &&
+             cloud_rup == o.cloud_rup && cloud_rdown == o.cloud_rdown && cloud_ext == o.cloud_ext &&
+             has_cloud == o.has_cloud && scat_flag == o.scat_flag;
+    }
+  };
+  hipStream_t pf_have_stream = nullptr;
+  PrepSettings pf_have_set{};
   double *d_coef2 = nullptr;
   idx_t *d_idx2 = nullptr;
   int *d_kstop2 = nullptr;

@@ -8,8 +8,9 @@
 //  rt_eclipse_quad   1-4 walkers: 16 wavenumbers x 4 layers (or 8 x 8) per wave
 //                    and step, the optical depth by a lane-row prefix scan.
 //
-// INTEG: the integration rule (integ.hpp).  Rule 0 is the tuned default; rules 1
-// and 2 are the same walks with another accumulation (the bench runs rule 0).
+// INTEG: the integration rule (integ.hpp).  Rule 1 is the default and what the bench
+// runs; its single-wave walk is its own kernel (rt_eclipse_s1.hpp, rt_eclipse_s1s.hpp for
+// the per-angle `cut slant`); rules 0 and 2 are the walks below with their accumulators.
 #pragma once
 #include "integ.hpp"
 #include "kernels.hpp"

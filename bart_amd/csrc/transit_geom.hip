@@ -339,13 +339,16 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
     BARTRT_TRANSIT_EXT(0) BARTRT_TRANSIT_EXT(1) BARTRT_TRANSIT_EXT(2)
 #undef BARTRT_TRANSIT_EXT
   }
-  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesMax) {
+  // (the matrix-tile kernels run on the default 64 kB of dynamic LDS: a column whose records need more --
+  // eight molecules + two CIA pairs from 293 layers, seven from 316 -- takes the scalar kernel, which opts in)
+  const size_t shm_tab = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
+                                           (size_t)a.L * idx_stride(a.C) + (size_t)a.L);
+  if (!generic_only && !a.ext && !a.tau_out && fits32 && a.L <= 16 * kMfmaTilesMax && shm_tab <= 64 * 1024) {
     RtArgs b = a;
     b.window = window;
     b.ntiles = (a.W + 63) / 64;
     const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
-    const size_t shm = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
-                                         (size_t)a.L * idx_stride(a.C) + (size_t)a.L);
+    const size_t shm = shm_tab;
 #define BARTRT_TRANSIT(MM, CC)                                                              \
   if (a.M == MM && a.C == CC) {                                                             \
     if (a.L <= 16 * kMfmaTiles)                                                             \

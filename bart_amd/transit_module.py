@@ -89,6 +89,7 @@ def lib():
         L.bartrt_set_integ.argtypes = [i]
         L.bartrt_set_cut.argtypes = [i]
         L.bartrt_get_cut.argtypes = [C.POINTER(i)]
+        L.bartrt_get_cia_interp.argtypes = [C.POINTER(i)]
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
@@ -171,6 +172,14 @@ def get_cut() -> str:
     v = C.c_int(-1)
     check(lib().bartrt_get_cut(C.byref(v)))
     return "slant" if v.value else "vertical"
+
+
+def get_cia_interp() -> str:
+    """'linear' or 'spline': how the engine resampled the cross-section files at init
+    (cfg key `cia_interp`)."""
+    v = C.c_int(-1)
+    check(lib().bartrt_get_cia_interp(C.byref(v)))
+    return "spline" if v.value else "linear"
 
 
 def get_integ() -> int:

@@ -17,13 +17,20 @@ itself as a CHILD process (before torch or HIP are touched here), relays the
 child's output and exits with its code.
 
 The contract's figure (`value`, `ms_per_step`) is the FIRST timed window: exactly K
-steps between barriers.  Around it the default run adds, outside that window:
+steps between barriers, on SURVEY 8d's opacities to the letter (exp(N(-25,3)) cm2/g: every
+layer of every column is walked, no credit from the `toomuch` cut), every step launching its
+own prep_profiles kernel -- the form an MCMC step takes.  The line
+certifies itself: `parity` = the spectra of the LAST step of that window against the CPU
+oracle on the same walkers (whole spectra; the run fails above 1e-9) and, bit for bit,
+against a fresh plain launch.  Around the window the default run adds, outside it:
   * `windows`: --repeats further windows of K steps (median / min / max);
   * `roofline.cold`: launches after a 1 GiB scratch sweep (nothing in L2 / Infinity Cache);
-  * `integ_sweep`: the three integration rules at 10 and 256 walkers;
-  * `batch_sweep`; `survey8d_workload` (SURVEY 8d's literal transparent opacities);
-  * `configs`: BASELINE.json configs 2, 4 (per-GPU work), transit geometry, 5;
-  * `cpu_baseline`; for N > 1 `scaling_diag` and a `replicas` comparison.
+  * `integ_sweep` / `cut_sweep`: the integration rules and the two `toomuch` cuts at 10 and 256 walkers;
+  * `batch_sweep`; `forest_workload` (a line-forest opacity model whose photosphere lies inside
+    the column, plain and with the next batch's preparation prefetched);
+  * `configs`: BASELINE.json configs 2, 4 (per-GPU work), transit geometry, 5, MC3-style worker processes;
+  * `cpu_baseline` (the oracle on the timed run's own walkers); for N > 1 `scaling_diag` and a
+    `replicas` comparison.
 --no-extras keeps only the contract's window (what the profiling scripts run).
 
 --dry-gloo replaces the GPU engine by a stub (spectra = a known function of the
@@ -109,23 +116,29 @@ def make_profiles(case, n, seed):
     return out
 
 
-def cpu_baseline(case, integ, seconds_target=8.0):
-    """The CPU oracle (a restatement, NOT reference transit: its source is an empty
-    submodule) timed on this host's cores, one walker per thread, same integration
-    rule as the GPU line: a warm-up pass (thread pool, page faults), then passes of
-    growing size until one runs for at least 5 s."""
+def oracle_engine(case, conv):
+    """The CPU oracle under the conventions the GPU engine runs with (conv: integ, cut, cia_interp)."""
     from oracle import rt_oracle as orc
+    return orc.OracleEngine(case.tcfg, integ=conv["integ"], cut=conv["cut"], cia_interp=conv["cia_interp"])
+
+
+def cpu_baseline(case, conv, walkers, seconds_target=8.0):
+    """The CPU oracle (a restatement, NOT reference transit: its source is an empty
+    submodule) timed on this host's cores, one walker per thread, same conventions as
+    the GPU line, on the timed run's OWN walkers (`walkers`: every profile of the cycled
+    batches, repeated in order to fill the sample): a warm-up pass (thread pool, page
+    faults), then passes of growing size until one runs for at least 5 s."""
     cores = os.cpu_count() or 1
-    eng = orc.OracleEngine(case.tcfg, integ=integ)
-    warm = make_profiles(case, cores, seed=20260104)
+    eng = oracle_engine(case, conv)
+    take = lambda n: walkers[np.arange(n) % len(walkers)]
     t0 = time.perf_counter()
-    eng.run_batch(warm, threads=cores)
+    eng.run_batch(take(cores), threads=cores)
     rate = cores / max(time.perf_counter() - t0, 1e-3)          # includes the pool's start: an underestimate
     n = dt = 0
     for _ in range(4):
         n = int(min(16384, max(cores, rate * seconds_target)))
         n = max(cores, (n // cores) * cores)
-        profs = make_profiles(case, n, seed=20260105)
+        profs = take(n)
         t0 = time.perf_counter()
         eng.run_batch(profs, threads=cores)
         dt = time.perf_counter() - t0
@@ -133,8 +146,30 @@ def cpu_baseline(case, integ, seconds_target=8.0):
         if dt >= 5.0 or n >= 16384:
             break
     return {"value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
-            "sample": f"{n} spectra of the same workload (100x1e4, 4 molecules, integ {integ}), one walker per "
-                      f"thread on {cores} threads, {dt:.1f} s wall after a warm-up pass of {cores} spectra"}
+            "sample": f"{n} spectra = the timed run's own {len(walkers)} walkers, repeated in order (100x1e4, 4 "
+                      f"molecules, integ {conv['integ']}, cut {conv['cut']}, cia_interp {conv['cia_interp']}), one "
+                      f"walker per thread on {cores} threads, {dt:.1f} s wall after a warm-up pass of {cores} spectra"}
+
+
+def parity_record(case, conv, profs, spec_gpu, plain_equal, what, max_walkers=16, tol=1e-9):
+    """The timed run's own output against the CPU oracle: whole spectra of up to max_walkers of the
+    step's walkers (evenly spread over the batch), every sample.  Relative error per sample against
+    the larger of |reference| and 1e-12 of the spectrum's largest sample (rule 1's panels change sign
+    on coarse columns: samples that cancel to nothing are held to the spectrum's scale, as the parity
+    tests hold them)."""
+    nw = profs.shape[0]
+    pick = np.unique(np.linspace(0, nw - 1, min(nw, max_walkers)).round().astype(int))
+    ref = oracle_engine(case, conv).run_batch(profs[pick], threads=min(len(pick), os.cpu_count() or 1))
+    got = spec_gpu[pick]
+    scale = np.maximum(np.abs(ref), 1e-12 * np.abs(ref).max(axis=1, keepdims=True))
+    err = np.abs(got - ref) / np.maximum(scale, 1e-300)
+    rec = {"max_rel_err": float(err.max()), "tolerance": tol, "n_samples": int(ref.size), "walkers": int(len(pick)),
+           "walkers_in_step": int(nw), "against": "oracle/rt_oracle.c (CPU restatement; RT parity unpinned: the "
+                                                  "reference's engine is an empty submodule)",
+           "what": what, "bit_equal_to_plain_launch": bool(plain_equal),
+           "spectrum_max": float(np.abs(ref).max()), "all_finite": bool(np.isfinite(got).all())}
+    rec["ok"] = bool(rec["max_rel_err"] <= tol and plain_equal and rec["all_finite"])
+    return rec
 
 
 RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "prep.hpp", "engine.hpp",
@@ -323,13 +358,19 @@ def main():
                     help="table: the headline opacity-table workload (BASELINE config 3, the contract's line); "
                          "lbl: BASELINE config 5, on-the-fly Voigt line-by-line (tools/lbl_bench.py's line)")
     ap.add_argument("--wnosamp", type=int, default=1, help="--config lbl: oversampling of the line sums")
-    ap.add_argument("--kappa", default="forest", choices=["forest", "survey8d"],
-                    help="opacity model of the headline run (survey8d: SURVEY 8d's literal exp(N(-25,3)); the "
-                         "default run reports it as the extra `survey8d_workload`)")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="do not name the next batch to the engine (bartrt_prefetch_profiles_dev): every step then "
-                         "launches its own prep_profiles kernel, as an MCMC step whose proposal depends on the "
-                         "previous step's spectra has to")
+    ap.add_argument("--kappa", default="survey8d", choices=["forest", "survey8d"],
+                    help="opacity model of the headline run.  survey8d (default): SURVEY 8d's literal exp(N(-25,3)) "
+                         "cm2/g -- a transparent column, every layer walked; forest: a log-normal line forest of median "
+                         "~1 cm2/g whose photosphere lies inside the column (the default run reports it as the extra "
+                         "`forest_workload`)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="name the next batch to the engine with every call (bartrt_prefetch_profiles_dev): the RT "
+                         "launch prepares the next batch's layer records in extra workgroups.  For a grid or population "
+                         "of independent models; NOT the form of an MCMC step (its proposal depends on the previous "
+                         "spectra), so not the default")
+    ap.add_argument("--no-prefetch", action="store_true", help="(the default since round 4; accepted for old scripts)")
+    ap.add_argument("--cut", default=None, choices=["vertical", "slant"],
+                    help="which depth `toomuch` cuts (default: the engine's; DESIGN.md C19)")
     ap.add_argument("--same-walkers", action="store_true",
                     help="diagnostic: every walker of a batch carries the batch's first profile (all table "
                          "planes shared: what the launch costs without its own HBM traffic); not a benchmark")
@@ -413,9 +454,16 @@ def main():
     sharded = world > 1 and a.mode == "shard"
     use_gather = sharded or (in_group and a.force_collective and a.mode == "shard")
     engine.init(case.tcfg, shard=(rank, world) if sharded else None, device=local_rank)
-    if trm is not None and a.integ is not None:
-        trm.set_integ(a.integ)
+    def apply_conventions():
+        if a.integ is not None:
+            trm.set_integ(a.integ)
+        if a.cut is not None:
+            trm.set_cut(a.cut)
+    if trm is not None:
+        apply_conventions()
     integ = trm.get_integ() if trm is not None else -1
+    # the conventions the engine runs under: the oracle of the parity record and of cpu_baseline follows them
+    conv = {"integ": integ, "cut": trm.get_cut(), "cia_interp": trm.get_cia_interp()} if trm is not None else None
     lo, hi = engine.local_range()
 
     def timed(nwalk, steps, warmup, record, repeats=0, gather=None, prefetch=None, before=None):
@@ -426,7 +474,7 @@ def main():
         over ranks), windows_ms (per-step time of every window), kern_ms / nlaunch (RT
         kernel time of the sampled launches of all windows), ok, profs, diag (N > 1)."""
         gather = use_gather if gather is None else gather
-        prefetch = (not a.no_prefetch) if prefetch is None else prefetch
+        prefetch = a.prefetch if prefetch is None else prefetch
         l0, h0 = engine.local_range()
         nsets = max(1, min(a.nsets, 4096 // max(nwalk, 1) or 1))
         profs_h = make_profiles(case, nwalk * nsets, seed=20260103 + (0 if gather or world == 1 else rank))
@@ -511,6 +559,9 @@ def main():
         if record:
             engine.timing_begin(a.event_stride)
         dt_local, drain_s, out = window(steps)
+        # the contract's window has ended: its LAST step's spectra, set aside for the parity record
+        last_set = (steps - 1) % nsets
+        out_first = out.clone() if (out is not None and not dry) else out
         wins = [dt_local]
         for _ in range(repeats):
             wins.append(window(steps)[0])
@@ -546,7 +597,8 @@ def main():
             ok = ok and bool(torch.equal(out, StubEngine.expected(d_prof[(steps - 1) % nsets], 0 if gather else l0,
                                                                   a.nwave if gather else h0)))
         return {"dt": dt, "windows_ms": [w / steps * 1e3 for w in wins], "kern_ms": kern_ms, "nlaunch": nlaunch,
-                "ok": ok, "profs": profs_h, "d_prof": d_prof, "diag": diag}
+                "ok": ok, "profs": profs_h, "d_prof": d_prof, "diag": diag, "last_out": out_first, "last_set": last_set,
+                "gathered": bool(gather)}
 
     # weak scaling: per-GPU work is fixed.  Sharded: every rank evaluates all B*N walkers on its
     # wavenumber block; replicas: every rank evaluates its own B walkers on the whole grid.
@@ -574,13 +626,30 @@ def main():
     dt, kern_ms, nlaunch, ok, profs_all = (main_run[k] for k in ("dt", "kern_ms", "nlaunch", "ok", "profs"))
     profs0 = profs_all[0]
 
+    # ---- the line certifies its own output: the LAST step of the contract's window against the CPU oracle on
+    # the same walkers (whole spectra), and bit for bit against a fresh launch of that batch with nothing prefetched
+    parity = None
+    if rank == 0 and not dry:
+        lset = main_run["last_set"]
+        got = main_run["last_out"]                       # [nwalk][whole grid if gathered, else this rank's block]
+        plain = torch.empty((nwalk, hi - lo), dtype=torch.float64, device=dev)
+        engine.run_batch_dev(main_run["d_prof"][lset], plain)
+        torch.cuda.synchronize()
+        plain_equal = bool(torch.equal(got[:, lo:hi] if main_run["gathered"] else got, plain))
+        parity = parity_record(
+            case, conv, profs_all[lset], got.cpu().numpy(), plain_equal,
+            "spectra of step %d (the last) of the contract's window = batch %d of the %d cycled"
+            % (a.steps - 1, lset, profs_all.shape[0]))
+        if not parity["ok"]:
+            print(json.dumps({"error": "parity of the timed run's spectra failed", "parity": parity}), flush=True)
+            sys.exit(3)
+
     # ---- N > 1, sharded: the same per-GPU work as independent replicas (SURVEY 8e's baseline)
     replicas = None
     if extras and world > 1 and sharded:
         trm.free_memory()
         engine.init(case.tcfg, shard=None, device=local_rank)
-        if a.integ is not None:
-            trm.set_integ(a.integ)
+        apply_conventions()
         rr = timed(a.walkers, a.steps, a.warmup, True, gather=False)
         replicas = {"value": nspectra_per_step * a.steps / rr["dt"], "unit": "spectra/s",
                     "ms_per_step": rr["dt"] / a.steps * 1e3, "walkers_per_rank": a.walkers,
@@ -588,8 +657,7 @@ def main():
                             "spectra per step as the sharded line", "diag": rr["diag"]}
         trm.free_memory()
         engine.init(case.tcfg, shard=(rank, world), device=local_rank)
-        if a.integ is not None:
-            trm.set_integ(a.integ)
+        apply_conventions()
 
     def guarded(name, fn):
         """An extra leg must not take the contract's line down (single rank only: it has no collectives)."""
@@ -664,7 +732,8 @@ def main():
         sid = source_id()
         same = lambda j: (j.get("source_id") == sid and j.get("walkers") == nwalk and j.get("nwave") == a.nwave
                           and j.get("nlayers") == a.nlayers and j.get("integ", 0) == integ and world == 1
-                          and a.kappa == "forest")
+                          and j.get("kappa", "forest") == a.kappa and j.get("cut", "vertical") == conv["cut"]
+                          and bool(j.get("prefetch", True)) == bool(a.prefetch))
         traffic = traffic_src = None
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
@@ -708,24 +777,27 @@ def main():
                 "workload": "H2O+CO+CO2+CH4 eclipse, %d layers x %d wavenumbers, %d walkers "
                             "batched per GPU per step, opacity-table path, 27 T planes, "
                             "H2-H2 CIA, 5 ray angles, toomuch 10, integration rule %d (%s); "
+                            "`toomuch` cut on the %s depth, CIA interpolation %s; "
                             "walkers: PT_line T(p) with parameters uniform in the demo "
                             "retrieval's prior box, %d distinct batches cycled.  %s"
-                            % (a.nlayers, a.nwave, a.walkers, integ, INTEG_NAMES[integ], nsets,
-                               "Departure from SURVEY 8d: the synthetic opacities are a log-normal line forest of "
-                               "median ~1 cm2/g (bart_amd/synth.py kappa_layer) instead of exp(N(-25,3)) cm2/g, which "
-                               "is a transparent atmosphere (timed as the extra `survey8d_workload`); with the forest "
+                            % (a.nlayers, a.nwave, a.walkers, integ, INTEG_NAMES[integ], conv["cut"], conv["cia_interp"],
+                               nsets,
+                               "DEPARTURE from SURVEY 8d (--kappa forest): the opacities are a log-normal line forest of "
+                               "median ~1 cm2/g (bart_amd/synth.py kappa_layer) instead of exp(N(-25,3)) cm2/g; "
                                "the photosphere lies inside the column and the `toomuch` cut skips the fraction of "
                                "layers reported as 1 - roofline.layers_walked_frac" if a.kappa == "forest" else
-                               "Opacities: SURVEY 8d's literal exp(N(-25,3)) cm2/g (transparent column)"),
+                               "Opacities: SURVEY 8d's literal exp(N(-25,3)) cm2/g, CIA 1e-45 exp(N(0,1)) -- a "
+                               "transparent column, every layer of every wavenumber walked"),
                 "walkers_per_step": nspectra_per_step, "nlayers": a.nlayers, "nwave": a.nwave, "integ": integ,
+                "cut": conv["cut"], "cia_interp": conv["cia_interp"],
                 "kappa_model": a.kappa,
                 "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
                 "spinup_ms": a.spinup_ms,     # untimed, before the W warm-up steps: the device at its working clocks
-                "prefetch": "off (--no-prefetch): every step launches its own prep_profiles" if a.no_prefetch else
-                            "on: the batches are resident and independent, each call names the next batch "
-                            "(bartrt_prefetch_profiles_dev) and the RT launch prepares its layer records in extra "
-                            "workgroups -- no work is skipped, the next step's prep_profiles launch is; see "
-                            "`no_prefetch` for the plain sequence",
+                "prefetch": "on (--prefetch): the batches are resident and independent, each call names the next "
+                            "batch (bartrt_prefetch_profiles_dev) and the RT launch prepares its layer records in "
+                            "extra workgroups -- a grid / population of models, not an MCMC step" if a.prefetch else
+                            "off: every step launches its own prep_profiles kernel, as an MCMC step (whose proposal "
+                            "depends on the previous spectra) has to",
                 **({"DIAGNOSTIC": "--same-walkers: identical profiles in a batch, not the benchmark"}
                    if a.same_walkers else {}),
                 "parallelism": ("wavenumber-block shard x%d + all-gather" % world if sharded else
@@ -736,11 +808,33 @@ def main():
                             "the other %d windows ran right after it, same length" % (len(wms) - 1),
                 "ms_per_step": _stats(wms), "spectra_per_s_median": nspectra_per_step / (np.median(wms) / 1e3),
             } if len(wms) > 1 else None,
+            "parity": parity,
             "roofline": {
                 "bound": "hbm", "achieved": uniq / per_launch_s / 1e9, "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": uniq / per_launch_s / 1e9 / PEAK_HBM_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_GBps": traffic / per_launch_s / 1e9 if traffic else None,
+                # the three fractions side by side; each is one division of figures in this object
+                "fractions": {
+                    "frac_survey8d_letter": alg / per_launch_s / 1e9 / PEAK_HBM_GBS,
+                    "frac_survey8d_letter_note": "SURVEY 8d's bytes per spectrum (80.09 MB, no credit for table planes "
+                                                 "shared between the walkers of a launch) x walkers / avg launch time / "
+                                                 "peak.  NOT bounded by HBM: walkers whose temperatures fall in the "
+                                                 "same bracket read the same planes, which L2 serves -- above 1 it "
+                                                 "says so, not that work is skipped (see `parity`)",
+                    "frac_unique_bytes": uniq / per_launch_s / 1e9 / PEAK_HBM_GBS,
+                    "frac_unique_bytes_note": "= `frac`: the launch's compulsory bytes (every table row counted once per "
+                                              "launch, down to where its wave stopped) / avg launch time / peak",
+                    "frac_counter": traffic / per_launch_s / 1e9 / PEAK_HBM_GBS if traffic else None,
+                    "frac_counter_note": "`traffic` (FETCH_SIZE x calibration + WRITE_SIZE of the committed rocprofv3 "
+                                         "--pmc passes of this build and workload) / avg launch time / peak.  FETCH_SIZE "
+                                         "counts requests that leave L2, INCLUDING those the 256 MiB Infinity Cache (MALL) "
+                                         "serves: in the timed loop consecutive batches share most planes through it, so "
+                                         "this is an upper bound on DRAM utilisation; `frac_cold` is the lower one",
+                    "frac_cold": (cold or {}).get("frac"),
+                    "frac_cold_note": "unique bytes / median launch time after a 1 GiB scratch sweep / peak: nothing "
+                                      "in L2 or the Infinity Cache, every compulsory byte from DRAM",
+                },
                 "bound_measured": bound_measured,
                 "cold": cold,
                 "bytes_model": "achieved = unique_bytes_per_launch / avg launch time: every (layer, T plane, "
@@ -764,16 +858,17 @@ def main():
             },
             "source_id": sid,
         }
-        if extras and world == 1 and not a.no_prefetch:
-            def plain():
-                r = timed(nwalk, a.steps, a.warmup, True, repeats=4, prefetch=False)
+        if extras and world == 1 and not a.prefetch:
+            def prefetched():
+                r = timed(nwalk, a.steps, a.warmup, True, repeats=4, prefetch=True)
                 return {
-                    "note": "the same windows with every step launching its own prep_profiles kernel (what an MCMC "
-                            "step whose proposal depends on the previous spectra has to do)",
+                    "note": "the same windows with each call naming the next batch (bartrt_prefetch_profiles_dev): the "
+                            "RT launch prepares the next batch's layer records in extra workgroups; for grids / "
+                            "populations of independent models, not for an MCMC step",
                     "ms_per_step": _stats(r["windows_ms"]),
                     "spectra_per_s_median": nspectra_per_step / (np.median(r["windows_ms"]) / 1e3),
                     "rt_kernel_ms": r["kern_ms"] / max(r["nlaunch"], 1)}
-            res["no_prefetch"] = guarded("no_prefetch", plain)
+            res["with_prefetch"] = guarded("with_prefetch", prefetched)
         if main_run["diag"]:
             res["scaling_diag"] = main_run["diag"]
         if replicas:
@@ -801,13 +896,34 @@ def main():
                     isw["rule1_over_rule0_rt_kernel_" + b] = isw["1"][b]["rt_kernel_us"] / isw["0"][b]["rt_kernel_us"]
                 return isw
             res["integ_sweep"] = guarded("integ_sweep", rules)
+            # the two readings of `toomuch` under the default rule, 10 and 256 walkers
+            def cuts():
+                csw = {}
+                try:
+                    for cut in ("vertical", "slant"):
+                        trm.set_cut(cut)
+                        csw[cut] = {}
+                        for b in (10, 256):
+                            k = 150 if b == 10 else 25
+                            r = timed(b, k, 10, True)
+                            csw[cut][str(b)] = {"spectra_per_s": b * k / r["dt"], "ms_per_step": r["dt"] / k * 1e3,
+                                                "rt_kernel_us": r["kern_ms"] / max(r["nlaunch"], 1) * 1e3}
+                finally:
+                    trm.set_cut(conv["cut"])
+                for b in ("10", "256"):
+                    csw["slant_over_vertical_rt_kernel_" + b] = csw["slant"][b]["rt_kernel_us"] / csw["vertical"][b]["rt_kernel_us"]
+                return csw
+            res["cut_sweep"] = guarded("cut_sweep", cuts)
             trm.free_memory()
-            if a.kappa == "forest":
-                res["survey8d_workload"] = guarded("survey8d", lambda: bench_configs.survey8d_leg(
-                    a, wd, integ, make_profiles, launch_byte_model, PEAK_HBM_GBS))
+            # the two readings of `toomuch` and the prefetched form on an opacity model whose photosphere lies
+            # inside the column (on 8d's transparent opacities no ray ever reaches the cut)
+            other = "forest" if a.kappa == "survey8d" else "survey8d"
+            res[other + "_workload"] = guarded(other, lambda: bench_configs.kappa_leg(
+                a, wd, conv, other, make_profiles, launch_byte_model, PEAK_HBM_GBS))
             res["configs"] = guarded("configs", lambda: bench_configs.run_all(integ))
         if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(case, integ))
+            res["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(
+                case, conv, profs_all.reshape(-1, profs_all.shape[-1])))
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

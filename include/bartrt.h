@@ -100,6 +100,11 @@ int bartrt_get_integ(int *rule);
 int bartrt_set_cut(int slant);
 int bartrt_get_cut(int *slant);
 
+/* How the engine interpolates the cross-section (CIA) files, fixed at bartrt_init by the cfg key
+ * `cia_interp linear|spline` / BARTRT_CIA_INTERP: *spline = 0 linear in wavenumber
+ * and temperature, 1 natural cubic splines in both.  Read-only: the tables are resampled at init. */
+int bartrt_get_cia_interp(int *spline);
+
 /* Prefetched preparation.  Names the profile batch of the bartrt_run_transit_batch_dev call
  * AFTER the next one: the next call's RT launch prepares that batch's layer records
  * (hydrostatic radii, densities, interpolation weights) in extra workgroups of its own grid,

@@ -20,6 +20,7 @@ warnings.simplefilter("ignore")
 np.float = float  # noqa
 np.int = int      # noqa
 REF = "/root/reference"
+sys.dont_write_bytecode = True   # nothing is written into the (read-only) reference tree
 sys.path.insert(0, os.path.join(REF, "code"))
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))

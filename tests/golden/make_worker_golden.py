@@ -34,6 +34,7 @@ warnings.simplefilter("ignore")
 np.float = float  # noqa  (np.zeros(2, np.int) at BARTfunc.py:130)
 np.int = int      # noqa
 REF = "/root/reference"
+sys.dont_write_bytecode = True   # nothing is written into the (read-only) reference tree
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(REF, "code"))

@@ -141,6 +141,8 @@ def test_reference_readers_on_product_files():
             sys.modules["matplotlib." + sub] = m
         sys.modules["matplotlib"] = mpl
     sys.path.insert(0, REF_CODE)
+    nobytecode = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True                       # the reference tree is read-only: no __pycache__ there
     try:
         import cf
         import readtransit
@@ -148,6 +150,7 @@ def test_reference_readers_on_product_files():
         tau, wns = cf.readTauDat(os.path.join(G, "tau.dat"), int(exp["nlayers"]))
         _, inten = readtransit.readspectrum(os.path.join(G, "intens.dat"), wn=True)
     finally:
+        sys.dont_write_bytecode = nobytecode
         sys.path.remove(REF_CODE)
         for n in added:
             delattr(np, n)

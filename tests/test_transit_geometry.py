@@ -130,6 +130,26 @@ def test_matrix_tiles_and_cloud_deck(tmp_path, nlayers, nwave):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nlayers", [292, 300])
+def test_deep_column_with_eight_molecules_and_two_cia_pairs(tmp_path, nlayers):
+    """Eight table molecules + two CIA pairs: from 293 layers on the layer records of the matrix-tile
+    kernel pass the 64 kB of dynamic LDS a kernel gets without opting in -- such columns take the scalar
+    kernel (which opts in) instead of failing at launch."""
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    from test_gpu_parity import walkers
+    sp = ("He", "H2", "CO", "CO2", "CH4", "H2O", "NH3", "HCN", "C2H2", "N2")
+    ab = (0.15, 0.85) + (1e-4,) * 8
+    c = _case(tmp_path, nlayers=nlayers, nwave=40, species=sp, abund=ab, opmol=sp[2:], cia=2)
+    engine.init(c.tcfg)
+    try:
+        profs = walkers(c, 2, seed=5)
+        np.testing.assert_allclose(engine.run_batch(profs), orc.OracleEngine(c.tcfg).run_batch(profs), rtol=RTOL)
+    finally:
+        trm.free_memory()
+
+
+@pytest.mark.gpu
 def test_worker_transit_solution(tmp_path):
     """solution = transit: Rp is a fitted parameter fed through set_radius, the
     bands are plain filter averages of the modulation (BARTfunc.py:391-393)."""

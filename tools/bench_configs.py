@@ -28,57 +28,86 @@ PEAK_FP64_TFLOPS = 78.6        # vector fp64; the fp64 matrix pipe has the same 
 PEAK_FP64_TOPS = PEAK_FP64_TFLOPS / 2.0   # fp64 VALU lane-operations per second (an FMA is ONE operation)
 
 
-def _time_launches(engine, torch, d_prof, out, steps, warm=5):
-    """Steps over the cycled batches, each call naming the next batch (bartrt_prefetch_profiles_dev:
-    the batches are resident and independent, as in bench.py's own loop)."""
+def _time_launches(engine, torch, d_prof, out, steps, warm=5, prefetch=False):
+    """Steps over the cycled batches.  prefetch: each call names the next batch
+    (bartrt_prefetch_profiles_dev: resident, independent batches); off = the MCMC-step form,
+    every step its own prep_profiles launch (bench.py's default)."""
     nsets = d_prof.shape[0]
+    nxt = (lambda i: d_prof[(i + 1) % nsets]) if prefetch else (lambda i: None)
     for i in range(warm):
-        engine.run_batch_dev(d_prof[i % nsets], out, next_prof=d_prof[(i + 1) % nsets])
+        engine.run_batch_dev(d_prof[i % nsets], out, next_prof=nxt(i))
     torch.cuda.synchronize()
     engine.timing_begin(1)
     t0 = time.perf_counter()
     for i in range(warm, warm + steps):
-        engine.run_batch_dev(d_prof[i % nsets], out, next_prof=d_prof[(i + 1) % nsets])
+        engine.run_batch_dev(d_prof[i % nsets], out, next_prof=nxt(i))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kms, nl = engine.timing_end()
     return dt / steps, kms / max(nl, 1) / 1e3
 
 
-def survey8d_leg(a, wd, integ, make_profiles, launch_byte_model, peak_hbm):
-    """SURVEY 8d's workload to the letter: kappa = exp(N(-25, 3)) cm2/g, CIA 1e-45 exp(N(0,1)):
-    a transparent column, every layer walked by every wave (no credit from the toomuch cut)."""
+KAPPA_TEXT = {
+    "survey8d": "SURVEY 8d's opacity model to the letter (exp(N(-25,3)) cm2/g, CIA 1e-45 exp(N(0,1))): transparent "
+                "column, every layer walked",
+    "forest": "log-normal line forest of median ~1 cm2/g (bart_amd/synth.py kappa_layer): the photosphere lies inside "
+              "the column, the `toomuch` cut ends the walk of most wavenumbers above the bottom",
+}
+
+
+def kappa_leg(a, wd, conv, kappa, make_profiles, launch_byte_model, peak_hbm):
+    """The headline shape on the OTHER opacity model (bench.py --kappa): plain steps, prefetched steps, and the two
+    `toomuch` cuts at 10 and 256 walkers, with the launch's byte model."""
     import torch
     from bart_amd import engine, synth, transit_module as trm
-    case = synth.make_case(wd + "_survey8d", nlayers=a.nlayers, nwave=a.nwave, kappa_model="survey8d", reuse=True)
+    base = wd[:-len("_survey8d")] if wd.endswith("_survey8d") else wd
+    case = synth.make_case(base + ("" if kappa == "forest" else "_" + kappa), nlayers=a.nlayers, nwave=a.nwave,
+                           kappa_model=kappa, reuse=True)
     engine.init(case.tcfg)
     try:
-        trm.set_integ(integ)
+        trm.set_integ(conv["integ"])
+        trm.set_cut(conv["cut"])
         n, nsets = a.walkers, 16
         profs = make_profiles(case, n * nsets, seed=20260103).reshape(nsets, n, -1)
         d_prof = torch.from_numpy(profs).cuda()
         out = torch.empty((n, a.nwave), dtype=torch.float64, device="cuda")
-        step_s, kern_s = _time_launches(engine, torch, d_prof, out, 60)
+        _time_launches(engine, torch, d_prof, out, 400)           # clocks up
+        step_s, kern_s = _time_launches(engine, torch, d_prof, out, 200)
+        pstep_s, pkern_s = _time_launches(engine, torch, d_prof, out, 200, prefetch=True)
         engine.walked_begin()
         engine.run_batch_dev(d_prof[0], out)
         torch.cuda.synchronize()
         walked, wpc, kname = engine.walked_end()
         m = launch_byte_model(case, profs[0], walked, wpc, a.nwave)
         alg = engine.algorithmic_bytes(n)
+        cuts = {}
+        for cut in ("vertical", "slant"):
+            trm.set_cut(cut)
+            cuts[cut] = {}
+            for b in (10, 256):
+                pb = make_profiles(case, b * 4, seed=20260110 + b).reshape(4, b, -1)
+                dpb = torch.from_numpy(pb).cuda()
+                ob = torch.empty((b, a.nwave), dtype=torch.float64, device="cuda")
+                st, ks = _time_launches(engine, torch, dpb, ob, 120 if b == 10 else 24)
+                cuts[cut][str(b)] = {"spectra_per_s": b / st, "ms_per_step": st * 1e3, "rt_kernel_us": ks * 1e6}
+        trm.set_cut(conv["cut"])
+        for b in ("10", "256"):
+            cuts["slant_over_vertical_rt_kernel_" + b] = cuts["slant"][b]["rt_kernel_us"] / cuts["vertical"][b]["rt_kernel_us"]
         return {
-            "workload": "SURVEY 8d's opacity model to the letter (exp(N(-25,3)) cm2/g, CIA 1e-45 exp(N(0,1))): "
-                        "transparent column, %d walkers per step, integ %d" % (n, integ),
+            "workload": "%s; %d walkers per step, integ %d, cut %s" % (KAPPA_TEXT[kappa], n, conv["integ"], conv["cut"]),
             "value": n / step_s, "unit": "spectra/s", "ms_per_step": step_s * 1e3, "rt_kernel_ms": kern_s * 1e3,
+            "with_prefetch": {"value": n / pstep_s, "ms_per_step": pstep_s * 1e3, "rt_kernel_ms": pkern_s * 1e3},
             "kernel": kname, "layers_walked_frac": m["layers_walked_frac"],
             "spectrum_max": float(out.max()),
+            "cut_sweep": cuts,
             "roofline": {"bound": "hbm", "achieved": m["unique_bytes"] / kern_s / 1e9, "peak": peak_hbm, "unit": "GB/s",
                          "frac": m["unique_bytes"] / kern_s / 1e9 / peak_hbm,
                          "unique_bytes_per_launch": m["unique_bytes"],
                          "survey8d_algorithmic_bytes_per_launch": alg,
-                         "survey8d_algorithmic_GBps": alg / kern_s / 1e9,
-                         "note": "all layers walked: unique bytes = every plane pair the batch's temperatures bracket, "
-                                 "down to the bottom; the 8d figure (no credit for planes shared between walkers) "
-                                 "stays a labelled L2 + HBM throughput, not a fraction of the HBM peak"}}
+                         "frac_survey8d_letter": alg / kern_s / 1e9 / peak_hbm,
+                         "note": "unique bytes = every table row the launch's walkers read, once per launch, down to "
+                                 "where each wave stopped; the 8d-letter figure gives no credit for planes shared "
+                                 "between walkers (L2 serves them) and is not bounded by the HBM peak"}}
     finally:
         trm.free_memory()
 

@@ -448,6 +448,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     r.wgt[a] = kPI * (sh * sh - sl * sl);
     r.invmu[a] = 1.0 / std::cos(angles[a] * kPI / 180.0);
     r.wq[a] = r.wgt[a] * r.invmu[a];
+    r.mu[a] = std::cos(angles[a] * kPI / 180.0);
   }
   if (!have_table && cfg_has(cfg, "linedb")) {
     lbl_init(*this, cfg["linedb"]);
@@ -628,6 +629,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.integ = integ;
   r.cut_slant = cut_slant ? 1 : 0;
   r.toomuch = toomuch;
+  if (cut_slant) slant_thresholds(r);
   r.spec = d_spec_out;
   r.tau_out = (want_tau && n == 1) ? d_tau : nullptr;
   r.last_out = (want_tau && n == 1) ? d_last : nullptr;

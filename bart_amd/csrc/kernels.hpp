@@ -189,6 +189,10 @@ struct RtArgs {
   double invmu[kMaxAngles];
   double wgt[kMaxAngles];  // pi (sin^2 hi - sin^2 lo)
   double wq[kMaxAngles];   // wgt[a] * invmu[a]: the angle quadrature of rules 1 / 2 taken before the layer sum
+  // `cut slant` (specialised kernels): mu[a] = cos(theta_a) and thr[a] = the largest vertical optical depth a
+  // ray of that angle survives, i.e. the largest double t with t * invmu[a] <= toomuch (slant_thresholds)
+  double mu[kMaxAngles];
+  double thr[kMaxAngles];
   double *spec;            // [nw][W]
   double *tau_out;         // optional [W][L] (single walker), may be null
   int *last_out;           // optional [W]
@@ -209,6 +213,23 @@ struct RtArgs {
   PrepArgs prep_next;
 };
 __host__ __device__ inline int prep_slots(int nprep) { return (nprep + 7) / 8 * 8; }
+
+// thr[a] of RtArgs for a value of `toomuch`: tau > thr[a]  <=>  tau * invmu[a] > toomuch, to the bit (the
+// product is monotone in tau, so the set of surviving depths is an interval that ends on one double)
+inline void slant_thresholds(RtArgs &r) {
+  for (int a = 0; a < r.A; a++) {
+    const double im = r.invmu[a];
+    double t = r.toomuch / im;
+    if (!(t == t) || t > 1.7e308 || t < 0.0) { r.thr[a] = t < 0.0 ? -1.0 : 1.7976931348623157e308; continue; }
+    for (int it = 0; it < 64 && t * im > r.toomuch; it++) t = __builtin_nextafter(t, 0.0);
+    for (int it = 0; it < 64; it++) {
+      const double up = __builtin_nextafter(t, 1.7976931348623157e308);
+      if (up == t || up * im > r.toomuch) break;
+      t = up;
+    }
+    r.thr[a] = t;
+  }
+}
 
 // What launch_rt launched (diagnostics; the byte model of bench.py)
 struct RtLaunchInfo {

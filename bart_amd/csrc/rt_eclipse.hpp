@@ -622,6 +622,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 
 }  // namespace bartrt
 #include "rt_eclipse_s1.hpp"   // rule 1's single-wave kernel
+#include "rt_eclipse_s1s.hpp"  // ... with the `toomuch` cut on each ray's slant depth
 namespace bartrt {
 
 // If one ray angle has exactly half the cosine of another (0 and 60 degrees of
@@ -635,6 +636,8 @@ inline bool order_angles_for_square(RtArgs &r) {
         std::swap(r.invmu[x], r.invmu[y]);
         std::swap(r.wgt[x], r.wgt[y]);
         std::swap(r.wq[x], r.wq[y]);
+        std::swap(r.mu[x], r.mu[y]);
+        std::swap(r.thr[x], r.thr[y]);
       };
       swap_angles(0, i);
       if (j == 0) j = i;  // the doubled angle sat in slot 0 and moved to i

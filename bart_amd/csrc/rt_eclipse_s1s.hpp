@@ -1,0 +1,331 @@
+// Single-wave eclipse kernel of integration rule 1 with the `toomuch` cut on each ray's SLANT
+// depth (cfg `cut slant`, DESIGN.md C19: SURVEY.md App. A-4 read literally -- "slant path ds = dr /
+// cos(theta); tau accumulated from the top; the loop stops where tau > toomuch").  Same walk as
+// rt_eclipse_simpson (rt_eclipse_s1.hpp): one lane per (walker, wavenumber), buffer loads two
+// layers ahead, layer records from LDS, the optical depth by the Simpson radius table.  What the
+// per-angle cut changes:
+//
+//  * every ray angle a ends on its own layer k_a (the first with tau_k / mu_a > toomuch, at most the
+//    vertical cut's) and so on its own PARITY: the hybrid rule starts with the trapezoid of (0, 1)
+//    when the angle's point count is even, with a Simpson panel when it is odd.  The angle
+//    quadrature can therefore not be taken before the layer sum: each angle keeps the two running
+//    sums of the panels that end on even / odd points (P0_a, P1_a), and which of them an angle ends
+//    on is known only when it dies.
+//  * the panels in WEIGHT form: the Simpson weights (w0, w1, w2) of the tau panel (k-2, k-1, k)
+//    depend on the column's tau grid alone, so they are formed once per layer (one reciprocal, as
+//    in rt_eclipse_simpson) and an angle's panel is three multiply-adds on its last three
+//    integrands y_a = B exp(-tau / mu_a).
+//  * an angle is alive at layer k iff the running maximum of tau over the layers above stays at or
+//    below its threshold thr_a (RtArgs::thr: the largest tau with tau / mu_a <= toomuch), so the
+//    five alive flags are functions of ONE running value -- no per-angle state, sticky by
+//    construction.  A dead angle's sums are frozen by multiplying its panel with the flag.
+//  * the padded point (integrand 0, one unit of SLANT depth = mu_a of vertical depth past the
+//    angle's last point) closes a panel (k_a - 1, k_a, pad) whose weights depend on the angle.
+//    Evaluating it in line would cost every layer what it costs the one layer where it counts;
+//    instead each angle records, again by multiplication with its flag, the optical depth of its
+//    last two points (T_a = sum of the counted intervals, T1_a = the same sum one layer behind) and
+//    the number of its points, and the pad panels of the five angles are evaluated once per
+//    column after the walk (four exponentials per angle: the Planck terms and transmittances of
+//    the two points, from the layer records still in LDS).
+//  * zero-width tau panels (two adjacent layers of exactly zero extinction) make a reciprocal
+//    infinite and the lane's sums non-finite, which is sticky; a wave that ends with a non-finite
+//    flux recomputes its columns ray by ray with SlantRay (integ.hpp), case analysis and all.
+#pragma once
+#include "integ.hpp"
+#include "kernels.hpp"
+#include "rt_eclipse_s1.hpp"
+
+#include <type_traits>
+
+namespace bartrt {
+
+template <int AT, int MT, int CT, bool SQ, int SCHED = 1, bool EXT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+void rt_eclipse_simpson_slant(RtArgs p) {
+  extern __shared__ double smem[];
+  constexpr int A = AT, M = MT, C = CT;
+  constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
+  constexpr int NR = NLD + (EXT ? 1 : 0) > 0 ? NLD + (EXT ? 1 : 0) : 1;
+  constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
+  const int L = p.L, W = p.W;
+  int bid = blockIdx.x;
+  if (p.nprep > 0) {   // the head of the grid prepares the NEXT batch's layer records (RtArgs::nprep)
+    if (bid < p.nprep) { prep_block(p.prep_next, bid, smem); return; }
+    bid -= prep_slots(p.nprep);
+    if (bid < 0) return;
+  }
+  int tile, w;
+  block_to_work(bid, p.nwalkers, tile, w);
+  if (tile >= p.ntiles) return;
+
+  double *sC = smem;
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
+  double *sWw = smem + (size_t)L * NC + (size_t)L * NI;
+  const double *sW = sWw;
+  stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI, threadIdx.x,
+                blockDim.x);
+  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const bool deck_on = kstop_deck(kraw);
+  __syncthreads();
+  simpson_radius_table(sWw, sC, NC, L, kend, threadIdx.x, blockDim.x);
+  __syncthreads();
+
+  const int i = tile * blockDim.x + threadIdx.x;
+  const bool valid = i < W;
+  const unsigned ii = valid ? (unsigned)i : (unsigned)(W - 1);
+  const double nu = p.wn[ii];
+  const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
+  const double nu4 = (nu * nu) * (nu * nu);
+  const TableLoader<M, C> tab(p, ii, sI);
+  const double *extw = EXT ? p.ext + (size_t)w * L * W + ii : nullptr;
+  auto load_layer = [&](int k, double (&r)[NR]) {
+    tab.load(k, r);
+    if constexpr (EXT) r[NLD] = extw[(size_t)(L - 1 - k) * W];
+  };
+  const double tcap = tau_cap(p, A);
+  // `toomuch` ends a ray only where a deeper layer exists (nothing follows the bottom layer)
+  const int kcut = kend < L - 2 ? kend : L - 2;
+  double thr_max = p.thr[0];
+#pragma unroll
+  for (int a = 1; a < A; a++) thr_max = p.thr[a] > thr_max ? p.thr[a] : thr_max;
+
+  // optical depth: tau of the last even layer, the last two extinctions
+  double s_even = 0.0, eprev = 0.0, e2 = 0.0;
+  // the tau grid of the intensity integrals: abscissa of the previous point, the previous
+  // interval and its reciprocal; tm = the largest tau so far (layers <= kcut)
+  double x1 = 0.0, h0 = 0.0, r0 = 1.0, tm = 0.0;
+  // per ray angle: the last two integrands, six..one times the sums of the panels that end on even
+  // / odd points, tau of the last point and of the one before it, the number of points
+  double y1[A], y2[A], P0[A], P1[A], Ta[A], T1a[A], Ka[A];
+#pragma unroll
+  for (int a = 0; a < A; a++) { y1[a] = y2[a] = P0[a] = P1[a] = Ta[a] = T1a[a] = Ka[a] = 0.0; }
+
+  // one layer.  J = position in the four-layer block (the parity of k), FIRST = the block of
+  // k0 = 0, MASKED = the column's last block: layers past kend are walked with clamped inputs
+  // and masked; the blocks above it lie inside the column (k0 + 3 <= kcut) and carry no range
+  // logic at all.
+  auto layer = [&](auto Jc, auto Fc, auto Mc, int k0, const double (&r)[NR], const double (&cf)[NC],
+                   double (&cfn)[NC]) {
+    constexpr int J = decltype(Jc)::value;
+    constexpr bool FIRST = decltype(Fc)::value, MASKED = decltype(Mc)::value;
+    const int k = k0 + J;
+    auto read_rec = [&](int kk, double (&c_)[NC]) {
+      const double *c = sC + ((MASKED || J == 3) ? (kk < kend ? kk : kend) : kk) * NC;
+#pragma unroll
+      for (int j = 0; j < NC; j++) c_[j] = c[j];
+    };
+    if constexpr (SCHED != 0) read_rec(k + 1, cfn);
+    else read_rec(k, const_cast<double (&)[NC]>(cf));
+    double e = fma(cf[2 + 2 * M + 2 * C], nu4, cf[3 + 2 * M + 2 * C]);   // Rayleigh + grey cloud
+#pragma unroll
+    for (int j = 0; j < NLD; j++) e = fma(cf[2 + j], r[j], e);
+    if constexpr (EXT) e += r[NLD];
+    const double *wk = sW + 4 * k;
+    double tau;
+    if constexpr ((J & 1) != 0) {
+      tau = fma(eprev + e, wk[3], s_even);
+    } else if constexpr (FIRST && J == 0) {
+      tau = 0.0;
+    } else {
+      s_even = fma(wk[0], e2, fma(wk[1], eprev, fma(wk[2], e, s_even)));
+      tau = s_even;
+    }
+    e2 = eprev;
+    eprev = e;
+    // alive flags from the running maximum of tau over the layers above (1.0 / 0.0)
+    bool inr = true;                      // wave-uniform: the layer lies inside the column
+    if constexpr (MASKED) inr = k <= kend;
+    double m[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) m[a] = (inr && tm <= p.thr[a]) ? 1.0 : 0.0;
+    // Planck exponent and the slant-path exponents in one interleaved batch
+    const double tcl = fmin(tau, tcap);
+    double xs[AE + 1], ex[AE + 1], y[A];
+    xs[AE] = fmin(cf[1] * nu, 700.0);
+#pragma unroll
+    for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
+    exp_rt_n<AE + 1>(xs, ex);
+    const double B = bnum * rcp_n1(ex[AE] - 1.0);
+#pragma unroll
+    for (int a = 0; a < AE; a++) y[a] = B * ex[a];
+    if (SQ) y[A - 1] = (B * ex[0]) * ex[0];
+    if constexpr (FIRST && J == 0) {
+#pragma unroll
+      for (int a = 0; a < A; a++) { y1[a] = y[a]; Ka[a] = m[a]; }
+    } else {
+      // the interval this layer closes (a unit one on masked overrun layers: tau stands still there)
+      double h1 = tau - x1;
+      if constexpr (MASKED) h1 = inr ? h1 : 1.0;
+      double w0, w1, w2, r1 = 1.0;
+      if constexpr (FIRST && J == 1) {
+        w0 = 0.0; w1 = w2 = 0.5 * h1;      // the first interval: a trapezoid
+      } else {
+        r1 = rcp_n1(h1);
+        const double hs = h0 + h1, s6 = hs * (1.0 / 6.0);
+        w0 = s6 * fma(-h1, r0, 2.0);
+        w2 = s6 * fma(-h0, r1, 2.0);
+        w1 = (hs - w0) - w2;              // the three weights add up to the panel's width
+      }
+#pragma unroll
+      for (int a = 0; a < A; a++) {
+        const double c = fma(w0, y2[a], fma(w1, y1[a], w2 * y[a]));
+        if constexpr ((J & 1) != 0) P1[a] = fma(c, m[a], P1[a]);
+        else P0[a] = fma(c, m[a], P0[a]);
+        Ta[a] = fma(m[a], h1, Ta[a]);
+        T1a[a] = fma(m[a], h0, T1a[a]);
+        Ka[a] += m[a];
+        y2[a] = y1[a];
+        y1[a] = y[a];
+      }
+      if constexpr (FIRST && J == 1) r1 = rcp_n1(h1);
+      h0 = h1; r0 = r1;
+    }
+    x1 = tau;
+    if constexpr (MASKED) tm = (k <= kcut) ? fmax(tm, tau) : tm;
+    else tm = fmax(tm, tau);
+  };
+  auto clampk = [&](int k) { return k < kend ? k : kend; };
+  using std::integral_constant;
+  using std::true_type;
+  using std::false_type;
+
+  double a0[NR], a1[NR], b0[NR], b1[NR];
+  double cfE[NC], cfO[NC];
+  auto block4 = [&](auto Fc, auto Mc, int k0) {
+    constexpr bool MASKED = decltype(Mc)::value;
+    load_layer(MASKED ? clampk(k0 + 2) : k0 + 2, b0);
+    load_layer(MASKED ? clampk(k0 + 3) : k0 + 3, b1);
+    layer(integral_constant<int, 0>{}, Fc, Mc, k0, a0, cfE, cfO);
+    layer(integral_constant<int, 1>{}, Fc, Mc, k0, a1, cfO, cfE);
+    load_layer(clampk(k0 + 4), a0);
+    load_layer(clampk(k0 + 5), a1);
+    layer(integral_constant<int, 2>{}, Fc, Mc, k0, b0, cfE, cfO);
+    layer(integral_constant<int, 3>{}, Fc, Mc, k0, b1, cfO, cfE);
+  };
+  load_layer(clampk(0), a0);
+  load_layer(clampk(1), a1);
+  if constexpr (SCHED != 0) {
+#pragma unroll
+    for (int j = 0; j < NC; j++) cfE[j] = sC[j];
+  }
+  // some ray of this lane is still alive (the one with the largest threshold goes last)
+  auto any_active = [&]() {
+    unsigned long long mk = __ballot(tm <= thr_max);
+    asm volatile("" : "+s"(mk));
+    return mk != 0ull;
+  };
+  int kw = 4;   // layers walked (whole blocks)
+  if (kcut >= 3) {
+    block4(true_type{}, false_type{}, 0);
+    int k0 = 4;
+    bool alive = any_active();
+    if (alive & (k0 + 3 <= kcut)) {
+      do {
+        block4(false_type{}, false_type{}, k0);
+        k0 += 4;
+        alive = any_active();
+      } while (alive & (k0 + 3 <= kcut));
+    }
+    kw = k0;
+    if (alive & (k0 <= kend)) {   // the column's last, partial block
+      block4(false_type{}, true_type{}, k0);
+      kw = k0 + 4;
+    }
+  } else {
+    block4(true_type{}, true_type{}, 0);
+  }
+
+  // ---- after the walk: per ray angle the sum of its parity, its padded panel, the deck's surface term
+  double F = 0.0;
+  {
+    const double tauend = x1;   // tau(kend) when the wave reached the column's end (the table's overrun entries)
+    double Bend = 0.0;
+    if (deck_on) Bend = bnum * rcp_n1(exp_rt(fmin(sC[kend * NC + 1] * nu, 700.0)) - 1.0);
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+      const bool died = !(tm <= p.thr[a]);
+      const int np = (int)Ka[a];                    // points counted: 0 .. np - 1 (died on point np - 1)
+      // the last point's index: the padded one (np) for a ray that died, else np - 1 = kend
+      const bool odd_end = died ? (np & 1) != 0 : ((np - 1) & 1) != 0;
+      double S = odd_end ? P1[a] : P0[a];
+      if (__any(died)) {
+        // panel (np - 2, np - 1, pad): h0 = tau(np-1) - tau(np-2), h1 = mu_a (one unit of slant depth), y(pad) = 0
+        const int kd = died ? np - 1 : 1, kp = kd > 0 ? kd - 1 : 0;
+        const double mu = p.mu[a];
+        const double hd = Ta[a] - T1a[a];
+        double xe[4], ee[4];
+        xe[0] = -fmin(Ta[a], tcap) * p.invmu[a];
+        xe[1] = -fmin(T1a[a], tcap) * p.invmu[a];
+        xe[2] = fmin(sC[kd * NC + 1] * nu, 700.0);
+        xe[3] = fmin(sC[kp * NC + 1] * nu, 700.0);
+        exp_rt_n<4>(xe, ee);
+        const double yd = bnum * rcp_n1(ee[2] - 1.0) * ee[0];
+        const double yp = bnum * rcp_n1(ee[3] - 1.0) * ee[1];
+        const double rd = rcp_n1(hd), hs = hd + mu, s6 = hs * (1.0 / 6.0);
+        const double wp = s6 * fma(-mu, rd, 2.0);
+        const double wd = s6 * (hs * hs) * (rd * p.invmu[a]);
+        const double pad = fma(wp, yp, wd * yd);
+        S += died ? pad : 0.0;
+      }
+      F = fma(p.wq[a], S, F);
+      if (deck_on) {
+        // an opaque deck this ray reached below its cut emits as a surface: B(kend) exp(-tau(kend) / mu_a)
+        const double xd = tauend * p.invmu[a];
+        const bool deck = !died && !(xd > p.toomuch);
+        const double Ed = exp_rt(fmax(-fmin(tauend, tcap) * p.invmu[a], kExpMin));
+        F += deck ? p.wgt[a] * Bend * Ed : 0.0;
+      }
+    }
+  }
+  if (__any(!(fabs(F) < __builtin_huge_val()))) {
+    // a zero-width panel somewhere in this wave (or an overflow): ray by ray, one layer at a time
+    double se = 0.0, ep = 0.0, ep2 = 0.0, tau = 0.0;
+    SlantRay<kIntegSimpson> ray[A];
+    bool alive_a[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) alive_a[a] = true;
+    bool act = true;
+    for (int k = 0; k <= kend; k++) {
+      double r[NR];
+      load_layer(k, r);
+      const double *c = sC + k * NC;
+      double e = fma(c[2 + 2 * M + 2 * C], nu4, c[3 + 2 * M + 2 * C]);
+#pragma unroll
+      for (int j = 0; j < NLD; j++) e = fma(c[2 + j], r[j], e);
+      if constexpr (EXT) e += r[NLD];
+      const double *wk = sW + 4 * k;
+      double t = tau;
+      if (k & 1) t = fma(ep + e, wk[3], se);
+      else if (k >= 2) t = fma(wk[0], ep2, fma(wk[1], ep, fma(wk[2], e, se)));
+      if (act) {   // frozen once no ray is alive, as TauColumn<kIntegSimpson> keeps it
+        tau = t;
+        if (!(k & 1) && k >= 2) se = t;
+      }
+      ep2 = ep;
+      ep = e;
+      const double B = bnum * rcp_n1(exp_rt(fmin(c[1] * nu, 700.0)) - 1.0);
+      bool any = false;
+#pragma unroll
+      for (int a = 0; a < A; a++) {
+        const double x = tau * p.invmu[a];
+        ray[a].point(alive_a[a], x, B, exp_rt(fmax(-fmin(tau, tcap) * p.invmu[a], kExpMin)));
+        alive_a[a] = alive_a[a] && !(x > p.toomuch);
+        any = any || alive_a[a];
+      }
+      act = any;
+      if (!__any(act)) break;
+    }
+    F = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; a++) F += p.wgt[a] * ray[a].result(deck_on && alive_a[a], L);
+  }
+  if (valid) p.spec[(size_t)w * W + i] = F;
+  if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
+    p.walked_out[(size_t)w * p.ntiles + tile] = (kw < kend + 1 ? kw : kend + 1);
+}
+
+// the builds (rt_eclipse_i1s_ilp.hip): ray grids of five angles and of the other sizes, the line-by-line hand-off
+bool launch_rt_simpson_slant(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+bool launch_rt_simpson_slant_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+
+}  // namespace bartrt

@@ -10,16 +10,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
-SOURCES = ["rt_eclipse_angles.hip", "rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
+SOURCES = ["rt_eclipse_angles.hip", "rt_eclipse_slant_ilp.hip", "rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
            "transit_geom.hip",
            "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "io.cpp"]   # longest first
-HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
+HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
 
 
 # per-file compiler options (see the comment on rt_eclipse_fast in csrc/rt_eclipse.hpp)
 ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ILP, "rt_eclipse_i1_ilp.hip": ILP}
+EXTRA_FLAGS = {"rt_eclipse_i0_ilp.hip": ILP, "rt_eclipse_i1_ilp.hip": ILP, "rt_eclipse_slant_ilp.hip": ILP}
 # rt_eclipse_angles.hip is compiled once per ray-grid size other than five: (object name, flags)
 ANGLE_SIZES = (1, 2, 3, 4, 6, 7, 8, 9)
 VARIANTS = {"rt_eclipse_angles.hip": [("rt_eclipse_a%d" % n, ["-DBARTRT_ANGLES=%d" % n, *ILP]) for n in ANGLE_SIZES]}

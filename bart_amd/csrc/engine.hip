@@ -27,7 +27,7 @@ Engine::~Engine() {
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_mass);
   fr(d_prep_consts); fr(d_diam); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
-  fr(d_walked); fr(d_coef2); fr(d_idx2); fr(d_kstop2); fr(d_ok2);
+  fr(d_walked); fr(d_coef2); fr(d_idx2); fr(d_kstop2); fr(d_ok2); fr(d_slog);
   if (h_pin) (void)hipHostFree(h_pin);
   for (auto e : ev) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
@@ -647,6 +647,20 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   }();
   r.ntiles = (r.W + block - 1) / block;
   r.rtop = d_rtop; r.ds = d_ds;
+  r.slog = nullptr;
+  if (cut_slant && solution == 0 && !lbl_fused) {
+    // the event log of the single-wave `cut slant` kernels (rt_eclipse_s1s.hpp): 100 bytes per lane
+    const size_t need = slant_log_bytes(n, r.ntiles, block, A);
+    if (need > slog_cap) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (d_slog) HIPCHK(hipFree(d_slog));
+      d_slog = nullptr;
+      slog_cap = 0;
+      HIPCHK(hipMalloc(&d_slog, need));
+      slog_cap = need;
+    }
+    r.slog = d_slog;
+  }
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
   r.transparent = transparent ? 1 : 0;
   // Timing: the RT kernel's own dispatch stamps the two events (BARTRT_RT_LAUNCH) -- no marker

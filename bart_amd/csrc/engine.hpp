@@ -112,6 +112,8 @@ struct Engine {
   int *d_kstop2 = nullptr;
   unsigned char *d_ok2 = nullptr;
   int cap2 = 0;                          // walkers the second set holds
+  void *d_slog = nullptr;                // `cut slant`: the single-wave kernels' event log (RtArgs::slog)
+  size_t slog_cap = 0;
   // per-step converters
   StepArgs *step = nullptr;
   Lbl *lbl = nullptr;

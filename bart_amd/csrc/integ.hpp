@@ -276,6 +276,11 @@ struct SlantRay {
   double I = 0.0, P1 = 0.0, y1 = 0.0, y2 = 0.0, x1 = 0.0, x2 = 0.0, Bprev = 0.0, Eprev = 1.0;
   int n = 0;
   __device__ __forceinline__ void simpson_point(bool live, double x, double y) {
+    // x arrives as the product tau / mu of the caller: fused into these differences it would be taken
+    // unrounded against the ROUNDED x1 of the layer above, and two layers of equal optical depth would
+    // be a rounding error apart instead of a zero-width panel (1e15-fold garbage through 1 / h; the
+    // zero-band case of tests/test_gpu_simpson.py caught it) -- no contraction here
+#pragma clang fp contract(off)
     const double h0 = x1 - x2, h1 = x - x1;
     double w0, w1, w2;
     simpson_tau_weights(h0, h1, w0, w1, w2);
@@ -294,6 +299,7 @@ struct SlantRay {
     if (INTEG == kIntegTransmittance) {
       I += live ? 0.5 * (Bprev + B) * (Eprev - E) : 0.0;
     } else if (INTEG == kIntegTrapzTau) {
+#pragma clang fp contract(off)
       I += live ? 0.5 * (y1 + B * E) * (x - x1) : 0.0;
       y1 = live ? B * E : y1; x1 = live ? x : x1;
     } else {
@@ -340,6 +346,76 @@ struct ColumnFlux<kIntegTrapzTau, AMAX> {
   }
   __device__ __forceinline__ double flux(const RtArgs &, int, bool deck, double, int) {
     return deck ? F + ydeck : F;
+  }
+};
+
+// `cut slant` in the single-wave kernel of rules 0 / 2 (rt_eclipse_fast<..., SLANT = true>): every ray ends on the
+// first layer whose slant depth passes toomuch, i.e. ray a counts on layer k iff the largest optical depth of the
+// layers above, tm, is at or below its threshold RtArgs::thr[a] (the largest tau with tau / mu_a <= toomuch).  The
+// rays' terms are masked one by one (their weights selected against tm), so the quadrature is a masked dot product
+// per layer instead of one value taken before the layer sum.  Neither rule pads a point, and a ray that passes the
+// cut on the bottom layer ends there like one that does not -- except for a cloud deck's surface term, which a ray
+// gets iff it is alive after the column's last layer.  (Rule 1: rt_eclipse_s1s.hpp.)
+template <int INTEG, int AMAX>
+struct ColumnFluxSlant;
+
+template <int AMAX>
+struct ColumnFluxSlant<kIntegTransmittance, AMAX> {
+  double F = 0.0, tm = 0.0, Eprev[AMAX];
+  __device__ __forceinline__ explicit ColumnFluxSlant(const RtArgs &) {
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) Eprev[a] = 1.0;      // transmittances are 1 above the top layer
+  }
+  __device__ __forceinline__ void layer(const RtArgs &p, int, bool live, double lv, double tau, double Bprev, double B,
+                                        const double (&E)[AMAX]) {
+    double g = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      const double wm = tm <= p.thr[a] ? p.wgt[a] : 0.0;
+      g = fma(wm, Eprev[a] - E[a], g);
+      Eprev[a] = E[a];
+    }
+    F = fma((Bprev + B) * lv, g, F);
+    tm = live ? fmax(tm, tau) : tm;
+  }
+  __device__ __forceinline__ double flux(const RtArgs &p, int, bool deck_on, double Bprev, int) {
+    if (!deck_on) return F;
+    double g = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) g += tm <= p.thr[a] ? p.wgt[a] * Eprev[a] : 0.0;
+    return fma(Bprev, g, F);
+  }
+};
+
+template <int AMAX>
+struct ColumnFluxSlant<kIntegTrapzTau, AMAX> {
+  double F = 0.0, tm = 0.0, x1 = 0.0, Bl = 0.0, y1[AMAX], El[AMAX];
+  __device__ __forceinline__ explicit ColumnFluxSlant(const RtArgs &) {
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { y1[a] = 0.0; El[a] = 1.0; }
+  }
+  __device__ __forceinline__ void layer(const RtArgs &p, int, bool live, double lv, double tau, double, double B,
+                                        const double (&E)[AMAX]) {
+    double g = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+      const double wm = tm <= p.thr[a] ? p.wq[a] : 0.0;
+      const double y = B * E[a];
+      g = fma(wm, y1[a] + y, g);
+      y1[a] = y;
+      El[a] = live ? E[a] : El[a];
+    }
+    F = fma((tau - x1) * lv, g, F);
+    x1 = live ? tau : x1;
+    Bl = live ? B : Bl;
+    tm = live ? fmax(tm, tau) : tm;
+  }
+  __device__ __forceinline__ double flux(const RtArgs &p, int, bool deck_on, double, int) {
+    if (!deck_on) return F;
+    double g = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) g += tm <= p.thr[a] ? p.wgt[a] * El[a] : 0.0;
+    return fma(Bl, g, F);
   }
 };
 

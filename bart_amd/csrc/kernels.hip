@@ -245,7 +245,7 @@ hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *i
     const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
     return !(e && e[0] == '0');
   }();
-  if (kmode != "generic" && !a.cut_slant) {   // (the per-angle cut lives in the generic kernel)
+  if (kmode != "generic") {
     hipError_t err = hipSuccess;
     bool done = false;
     switch (a.integ) {

@@ -193,6 +193,8 @@ struct RtArgs {
   // ray of that angle survives, i.e. the largest double t with t * invmu[a] <= toomuch (slant_thresholds)
   double mu[kMaxAngles];
   double thr[kMaxAngles];
+  int drank[kMaxAngles];   // rank of ray a in the order of dying (0 = the smallest thr goes first)
+  void *slog;              // `cut slant` event log of the single-wave kernels: slant_log_bytes(...) bytes
   double *spec;            // [nw][W]
   double *tau_out;         // optional [W][L] (single walker), may be null
   int *last_out;           // optional [W]
@@ -229,6 +231,15 @@ inline void slant_thresholds(RtArgs &r) {
     }
     r.thr[a] = t;
   }
+  for (int a = 0; a < r.A; a++) {
+    int rk = 0;
+    for (int b = 0; b < r.A; b++) rk += (r.thr[b] < r.thr[a] || (r.thr[b] == r.thr[a] && b < a)) ? 1 : 0;
+    r.drank[a] = rk;
+  }
+}
+// bytes of RtArgs::slog for a launch: per (walker, tile) workgroup, per lane, A slots of (tau, interval, index)
+inline size_t slant_log_bytes(int nwalkers, int ntiles, int block, int A) {
+  return (size_t)nwalkers * (size_t)ntiles * (size_t)block * (size_t)A * 20u;
 }
 
 // What launch_rt launched (diagnostics; the byte model of bench.py)

@@ -88,7 +88,9 @@ __host__ __device__ inline size_t integ_lds_doubles(int L) {
 // EXT: the line-by-line path's hand-off -- the layer's line extinction ext[w][l][W]
 // (atm layer order) is one more coalesced 8-byte load per layer and one more addend
 // (line-by-line engines have no table: MT = 0).
-template <int AT, int MT, int CT, bool SQ, int INTEG, int SCHED = 0, bool EXT = false>
+// SLANT: the `toomuch` cut on each ray's slant depth (cfg `cut slant`): the rays' terms are masked
+// one by one (ColumnFluxSlant, integ.hpp) and the column is walked while its longest-lived ray is alive.
+template <int AT, int MT, int CT, bool SQ, int INTEG, int SCHED = 0, bool EXT = false, bool SLANT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_fast(RtArgs p) {
   extern __shared__ double smem[];
@@ -134,12 +136,19 @@ void rt_eclipse_fast(RtArgs p) {
   };
 
   TauColumn<INTEG> tc;
-  ColumnFlux<INTEG, A> ci(p);
+  std::conditional_t<SLANT, ColumnFluxSlant<INTEG, A>, ColumnFlux<INTEG, A>> ci(p);
   double Bprev = 0.0;
   bool active = true;
   const int kraw = p.kstop[w], kend = kstop_layer(kraw);
   const bool deck_on = kstop_deck(kraw);
   const double tcap = tau_cap(p, A);
+  // the optical depth that ends the lane's walk: toomuch itself, or (SLANT) the threshold of the ray that goes last
+  double tstop = p.toomuch;
+  if constexpr (SLANT) {
+    tstop = p.thr[0];
+#pragma unroll
+    for (int a = 1; a < A; a++) tstop = p.thr[a] > tstop ? p.thr[a] : tstop;
+  }
 
   // One layer's arithmetic.  Straight-line: layer indices past the end are
   // clamped and masked instead of branched around, so that inside an unrolled
@@ -176,8 +185,8 @@ void rt_eclipse_fast(RtArgs p) {
     if (SQ) es[A - 1] = ex[0] * ex[0];
     const double B = bnum * rcp_n1(ex[AE] - 1.0);
     ci.layer(p, A, live, lv, tc.tau, Bprev, B, es);
-    Bprev = B;
-    active = active && !(live && tc.tau > p.toomuch);
+    Bprev = SLANT ? (live ? B : Bprev) : B;
+    active = active && !(live && tc.tau > tstop);
   };
   auto clampk = [&](int k) { return k < kend ? k : kend; };
 
@@ -200,7 +209,7 @@ void rt_eclipse_fast(RtArgs p) {
     layer(k0 + 3, b1, cfO, cfE);
     if (!__any(active)) break;
   }
-  const double F = ci.flux(p, A, deck_on && active, Bprev, L);
+  const double F = ci.flux(p, A, SLANT ? deck_on : (deck_on && active), Bprev, L);
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
     p.walked_out[(size_t)w * p.ntiles + tile] = (k0 + 4 < kend + 1 ? k0 + 4 : kend + 1);
@@ -638,6 +647,7 @@ inline bool order_angles_for_square(RtArgs &r) {
         std::swap(r.wq[x], r.wq[y]);
         std::swap(r.mu[x], r.mu[y]);
         std::swap(r.thr[x], r.thr[y]);
+        std::swap(r.drank[x], r.drank[y]);
       };
       swap_angles(0, i);
       if (j == 0) j = i;  // the doubled angle sat in slot 0 and moved to i
@@ -656,6 +666,10 @@ inline bool order_angles_for_square(RtArgs &r) {
 bool launch_rt_fast_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 // ... and with the line-by-line extinction array as input (no table, 0-2 CIA pairs)
 bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+
+// the `cut slant` kernels of rules 0 / 1 for five angles (rt_eclipse_slant_ilp.hip), table and line-by-line input
+bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
 // ... and for ray grids of 1 .. 9 angles other than five (rt_eclipse_angles.hip, one object per size)
 #define BARTRT_ANGLE_SIZES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(9)
@@ -685,12 +699,17 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     b.ntiles = a.ntiles;
     if (info) { info->kernel = "rt_eclipse_fast (line-by-line extinction)"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
     err = hipSuccess;
+    if (a.cut_slant) {
+      if (info) info->kernel = "single-wave `cut slant` kernel (line-by-line extinction)";
+      return launch_rt_slant_ext(b, INTEG, sq, block, nblocks, sh, st, err);
+    }
     if (INTEG == kIntegSimpson ? launch_rt_simpson_ext(b, sq, block, nblocks, sh, st, err)
                                : launch_rt_fast_ext(b, sq, block, nblocks, sh, st, err))
       return true;
     return false;
   }
   if (!(!a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
+  if (a.cut_slant && (INTEG == kIntegTrapzTau || !a.slog)) return false;   // (rule 2 with the slant cut: generic kernel)
   if (a.A != 5) {
     // other ray-grid sizes: the single-wave kernel of rule 0 / rule 1 at every batch size
     if (INTEG == kIntegTrapzTau || a.A < 1 || a.A > 9 || kmode == "quad" || kmode == "octo" || kmode == "split") return false;
@@ -701,7 +720,9 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       nba += prep_slots(a.nprep);
     }
     if (info) {
-      info->kernel = INTEG == kIntegSimpson ? "rt_eclipse_simpson (ray grid of another size)" : "rt_eclipse_fast (ray grid of another size)";
+      info->kernel = a.cut_slant ? (INTEG == kIntegSimpson ? "rt_eclipse_simpson_slant (ray grid of another size)"
+                                                          : "rt_eclipse_fast<SLANT> (ray grid of another size)")
+                     : INTEG == kIntegSimpson ? "rt_eclipse_simpson (ray grid of another size)" : "rt_eclipse_fast (ray grid of another size)";
       info->wn_per_column = block; info->ncolumns = a.ntiles; info->prep_fused = a.nprep > 0;
     }
     err = hipSuccess;
@@ -741,6 +762,17 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   err = hipSuccess;
   constexpr bool SQOK = true;   // exp(-2 tau / mu) = exp(-tau / mu)^2 under every rule
   constexpr long quad_max = INTEG == kIntegSimpson ? kQuadMaxColumnsSimpson : kQuadMaxColumns;
+  if (a.cut_slant) {
+    // the per-ray cut lives in the single-wave kernels (each ray its own sums): every batch size
+    b.ntiles = a.ntiles;
+    if (info) {
+      info->kernel = INTEG == kIntegSimpson ? "rt_eclipse_simpson_slant (ILP-scheduled build)" : "rt_eclipse_fast<SLANT> (ILP-scheduled build)";
+      info->wn_per_column = block; info->ncolumns = b.ntiles;
+    }
+    if (launch_rt_slant(b, INTEG, sq, block, nblocks + pslots, sh + shp, st, err)) return true;
+    if (info) info->prep_fused = false;
+    return false;
+  }
   if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= quad_max)) && fits32) {
     // the smallest launches take eight layers per step (8 wavenumbers per wave)
     b.ntiles = octo ? (a.W + 31) / 32 : ntiles64;

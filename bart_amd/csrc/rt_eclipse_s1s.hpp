@@ -21,12 +21,17 @@
 //    construction.  A dead angle's sums are frozen by multiplying its panel with the flag.
 //  * the padded point (integrand 0, one unit of SLANT depth = mu_a of vertical depth past the
 //    angle's last point) closes a panel (k_a - 1, k_a, pad) whose weights depend on the angle.
-//    Evaluating it in line would cost every layer what it costs the one layer where it counts;
-//    instead each angle records, again by multiplication with its flag, the optical depth of its
-//    last two points (T_a = sum of the counted intervals, T1_a = the same sum one layer behind) and
-//    the number of its points, and the pad panels of the five angles are evaluated once per
-//    column after the walk (four exponentials per angle: the Planck terms and transmittances of
-//    the two points, from the layer records still in LDS).
+//    Evaluating it in line would cost every layer what it costs the one layer where it counts, and
+//    carrying each angle's last two depths along costs fifteen multiply-adds per layer and the
+//    registers that decide between two waves per SIMD and spilling.  Instead a lane LOGS its death
+//    events: a layer on which its count of living rays dropped writes (tau, the interval it closed,
+//    its index) to the lane's slot "rays dead before" of a small per-wave log in global memory
+//    (RtArgs::slog; 100 bytes per lane) -- a buffer store whose offset is pushed out of the
+//    descriptor's range on lanes without an event, so that the hardware drops it: no branch, no
+//    dummy traffic, at most five stores per lane and column.  After the walk each ray that died
+//    finds its event (the last one logged at or below its rank in the order of dying), and its pad
+//    panel is evaluated once per column (four exponentials: the Planck terms and transmittances of
+//    its last two points, from the layer records still in LDS).
 //  * zero-width tau panels (two adjacent layers of exactly zero extinction) make a reciprocal
 //    infinite and the lane's sums non-finite, which is sticky; a wave that ends with a non-finite
 //    flux recomputes its columns ray by ray with SlantRay (integ.hpp), case analysis and all.
@@ -94,11 +99,34 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   // the tau grid of the intensity integrals: abscissa of the previous point, the previous
   // interval and its reciprocal; tm = the largest tau so far (layers <= kcut)
   double x1 = 0.0, h0 = 0.0, r0 = 1.0, tm = 0.0;
-  // per ray angle: the last two integrands, six..one times the sums of the panels that end on even
-  // / odd points, tau of the last point and of the one before it, the number of points
-  double y1[A], y2[A], P0[A], P1[A], Ta[A], T1a[A], Ka[A];
+  // per ray angle: the last two integrands, the sums of the panels that end on even / odd points
+  double y1[A], y2[A], P0[A], P1[A];
 #pragma unroll
-  for (int a = 0; a < A; a++) { y1[a] = y2[a] = P0[a] = P1[a] = Ta[a] = T1a[a] = Ka[a] = 0.0; }
+  for (int a = 0; a < A; a++) { y1[a] = y2[a] = P0[a] = P1[a] = 0.0; }
+  // the wave's event log: [slot 0 .. A-1][lane] (tau, interval) pairs, then [slot][lane] layer indices
+  // (-1: no event in that slot), addressed through a descriptor of exactly its size
+  const unsigned nth = blockDim.x;
+  const unsigned log_bytes = nth * (unsigned)A * 20u;
+  const auto rs_log = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char *>(p.slog) + ((size_t)w * p.ntiles + tile) * log_bytes, 0, (int)log_bytes, 0x00020000);
+  const unsigned log_k0 = nth * (unsigned)A * 16u + threadIdx.x * 4u;   // this lane's index of slot 0
+#pragma unroll
+  for (int sl = 0; sl < A; sl++) __builtin_amdgcn_raw_buffer_store_b32(-1, rs_log, (int)(log_k0 + sl * nth * 4u), 0, 0);
+  int nprev = A;             // rays alive when the previous layer began
+  // logs the event "the rays alive dropped from nprev to nnow on layer kev" (tau and interval of that layer
+  // are x1 and h0 by now); lanes without one store out of range, which the hardware drops
+  auto log_event = [&](int nnow, int kev) {
+    const bool ev = nnow < nprev;
+    const unsigned slot = (unsigned)(A - nprev);
+    const unsigned off = ev ? slot * nth * 16u + threadIdx.x * 16u : 0x7ffffff0u;
+    const unsigned offk = ev ? log_k0 + slot * nth * 4u : 0x7ffffff0u;
+    v4u_t v;
+    v.x = (unsigned)__double2loint(x1); v.y = (unsigned)__double2hiint(x1);
+    v.z = (unsigned)__double2loint(h0); v.w = (unsigned)__double2hiint(h0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs_log, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(kev, rs_log, (int)offk, 0, 0);
+    nprev = nnow;
+  };
 
   // one layer.  J = position in the four-layer block (the parity of k), FIRST = the block of
   // k0 = 0, MASKED = the column's last block: layers past kend are walked with clamped inputs
@@ -136,8 +164,14 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     bool inr = true;                      // wave-uniform: the layer lies inside the column
     if constexpr (MASKED) inr = k <= kend;
     double m[A];
+    int nnow = 0;
 #pragma unroll
-    for (int a = 0; a < A; a++) m[a] = (inr && tm <= p.thr[a]) ? 1.0 : 0.0;
+    for (int a = 0; a < A; a++) {
+      const bool al = tm <= p.thr[a];
+      nnow += al ? 1 : 0;
+      m[a] = (inr && al) ? 1.0 : 0.0;
+    }
+    if constexpr (!(FIRST && J == 0)) log_event(nnow, k - 1);
     // Planck exponent and the slant-path exponents in one interleaved batch
     const double tcl = fmin(tau, tcap);
     double xs[AE + 1], ex[AE + 1], y[A];
@@ -151,7 +185,7 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     if (SQ) y[A - 1] = (B * ex[0]) * ex[0];
     if constexpr (FIRST && J == 0) {
 #pragma unroll
-      for (int a = 0; a < A; a++) { y1[a] = y[a]; Ka[a] = m[a]; }
+      for (int a = 0; a < A; a++) y1[a] = y[a];
     } else {
       // the interval this layer closes (a unit one on masked overrun layers: tau stands still there)
       double h1 = tau - x1;
@@ -171,9 +205,6 @@ void rt_eclipse_simpson_slant(RtArgs p) {
         const double c = fma(w0, y2[a], fma(w1, y1[a], w2 * y[a]));
         if constexpr ((J & 1) != 0) P1[a] = fma(c, m[a], P1[a]);
         else P0[a] = fma(c, m[a], P0[a]);
-        Ta[a] = fma(m[a], h1, Ta[a]);
-        T1a[a] = fma(m[a], h0, T1a[a]);
-        Ka[a] += m[a];
         y2[a] = y1[a];
         y1[a] = y[a];
       }
@@ -238,25 +269,50 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   // ---- after the walk: per ray angle the sum of its parity, its padded panel, the deck's surface term
   double F = 0.0;
   {
+    // an event on the last layer walked
+    int nnow = 0;
+#pragma unroll
+    for (int a = 0; a < A; a++) nnow += (tm <= p.thr[a]) ? 1 : 0;
+    log_event(nnow, kw - 1);
     const double tauend = x1;   // tau(kend) when the wave reached the column's end (the table's overrun entries)
     double Bend = 0.0;
     if (deck_on) Bend = bnum * rcp_n1(exp_rt(fmin(sC[kend * NC + 1] * nu, 700.0)) - 1.0);
+    const bool anydied = __any(nnow < A);
+    int kev[A];
+#pragma unroll
+    for (int sl = 0; sl < A; sl++) kev[sl] = -1;
+    if (anydied) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the log's stores have reached L2
+#pragma unroll
+      for (int sl = 0; sl < A; sl++)
+        kev[sl] = __builtin_amdgcn_raw_buffer_load_b32(rs_log, (int)(log_k0 + sl * nth * 4u), 0, 1 /* glc */);
+    }
 #pragma unroll
     for (int a = 0; a < A; a++) {
       const bool died = !(tm <= p.thr[a]);
-      const int np = (int)Ka[a];                    // points counted: 0 .. np - 1 (died on point np - 1)
-      // the last point's index: the padded one (np) for a ray that died, else np - 1 = kend
-      const bool odd_end = died ? (np & 1) != 0 : ((np - 1) & 1) != 0;
+      // the ray's event: the last one logged in a slot at or below its rank in the order of dying
+      int kd = kend, slot = 0;
+      const int rank = p.drank[a];
+#pragma unroll
+      for (int sl = 0; sl < A; sl++) {
+        const bool take = sl <= rank && kev[sl] >= 0;
+        kd = take ? kev[sl] : kd;
+        slot = take ? sl : slot;
+      }
+      // the last point's index: the padded one (kd + 1) for a ray that died on layer kd, else kend
+      const bool odd_end = died ? ((kd + 1) & 1) != 0 : (kend & 1) != 0;
       double S = odd_end ? P1[a] : P0[a];
       if (__any(died)) {
-        // panel (np - 2, np - 1, pad): h0 = tau(np-1) - tau(np-2), h1 = mu_a (one unit of slant depth), y(pad) = 0
-        const int kd = died ? np - 1 : 1, kp = kd > 0 ? kd - 1 : 0;
+        // panel (kd - 1, kd, pad): h0 = tau(kd) - tau(kd - 1), h1 = mu_a (one unit of slant depth), y(pad) = 0
+        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_log, (int)((unsigned)slot * nth * 16u + threadIdx.x * 16u), 0, 1);
+        const double taud = __builtin_bit_cast(double, (v2u_t){v.x, v.y});
+        const double hd = __builtin_bit_cast(double, (v2u_t){v.z, v.w});
+        const int kdc = died ? kd : 1, kp = kdc > 0 ? kdc - 1 : 0;
         const double mu = p.mu[a];
-        const double hd = Ta[a] - T1a[a];
         double xe[4], ee[4];
-        xe[0] = -fmin(Ta[a], tcap) * p.invmu[a];
-        xe[1] = -fmin(T1a[a], tcap) * p.invmu[a];
-        xe[2] = fmin(sC[kd * NC + 1] * nu, 700.0);
+        xe[0] = -fmin(taud, tcap) * p.invmu[a];
+        xe[1] = -fmin(taud - hd, tcap) * p.invmu[a];
+        xe[2] = fmin(sC[kdc * NC + 1] * nu, 700.0);
         xe[3] = fmin(sC[kp * NC + 1] * nu, 700.0);
         exp_rt_n<4>(xe, ee);
         const double yd = bnum * rcp_n1(ee[2] - 1.0) * ee[0];

@@ -1,0 +1,49 @@
+// The single-wave eclipse kernels with the `toomuch` cut on each ray's slant depth (cfg `cut slant`,
+// DESIGN.md C19) for the usual five-angle ray grid, compiled under the compiler's maximum-ILP
+// scheduling strategy (bart_amd/build.py): rule 1's own kernel (rt_eclipse_simpson_slant,
+// rt_eclipse_s1s.hpp), rule 0's (rt_eclipse_fast<..., SLANT = true> with ColumnFluxSlant, integ.hpp),
+// and both with the line-by-line extinction array as input.  Rule 2 with the slant cut runs the
+// generic kernel.
+#include "rt_eclipse.hpp"
+
+namespace bartrt {
+
+bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+  if (integ != kIntegSimpson && integ != kIntegTransmittance) return false;
+#define BARTRT_SLANT(MM, CC)                                                                                              \
+  if (b.M == MM && b.C == CC) {                                                                                           \
+    if (integ == kIntegSimpson) {                                                                                         \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, true, 1>), dim3(nblocks), dim3(block), sh, st, b);    \
+      else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, 1>), dim3(nblocks), dim3(block), sh, st, b);      \
+    } else {                                                                                                              \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, true, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);  \
+      else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+    }                                                                                                                     \
+    err = hipGetLastError();                                                                                              \
+    return true;                                                                                                          \
+  }
+  BARTRT_MC_LIST(BARTRT_SLANT)
+#undef BARTRT_SLANT
+  return false;
+}
+
+bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+  if (integ != kIntegSimpson && integ != kIntegTransmittance) return false;
+#define BARTRT_SLANT_EXT(CC)                                                                                                   \
+  if (b.M == 0 && b.C == CC) {                                                                                                 \
+    if (integ == kIntegSimpson) {                                                                                              \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, 0, CC, true, 1, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+      else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, 0, CC, false, 1, true>), dim3(nblocks), dim3(block), sh, st, b);      \
+    } else {                                                                                                                   \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, 0, CC, true, 0, 1, true, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+      else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, 0, CC, false, 0, 1, true, true>), dim3(nblocks), dim3(block), sh, st, b);      \
+    }                                                                                                                          \
+    err = hipGetLastError();                                                                                                   \
+    return true;                                                                                                               \
+  }
+  BARTRT_SLANT_EXT(0) BARTRT_SLANT_EXT(1) BARTRT_SLANT_EXT(2)
+#undef BARTRT_SLANT_EXT
+  return false;
+}
+
+}  // namespace bartrt

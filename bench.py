@@ -172,9 +172,9 @@ def parity_record(case, conv, profs, spec_gpu, plain_equal, what, max_walkers=16
     return rec
 
 
-RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "prep.hpp", "engine.hpp",
-              "rt_eclipse_i0.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1.hip", "rt_eclipse_i1_ilp.hip",
-              "kernels.hip", "engine.hip")
+RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "prep.hpp",
+              "engine.hpp", "rt_eclipse_i0.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1.hip", "rt_eclipse_i1_ilp.hip",
+              "rt_eclipse_slant_ilp.hip", "kernels.hip", "engine.hip")
 
 
 def source_id():

@@ -28,11 +28,19 @@ from bart_amd import engine, synth, transit_module as trm
 from oracle import rt_oracle as orc
 from test_gpu_parity import walkers
 
+mode = sys.argv[1]
+tmp = sys.argv[2]
+CUT = sys.argv[3]                 # vertical | slant (DESIGN.md C19)
+INTEG = int(sys.argv[4])
+
 def check(cfg, profs, what, clouds=(None,)):
     engine.init(cfg)
     try:
-        trm.set_integ(1)
-        o = orc.OracleEngine(cfg, integ=1)
+        trm.set_integ(INTEG); trm.set_cut(CUT)
+        o = orc.OracleEngine(cfg, integ=INTEG, cut=CUT)
+        if CUT == "slant":          # the per-ray cut runs its own single-wave kernels, not the generic one
+            engine.walked_begin(); engine.run_batch(profs); kname = engine.walked_end()[2]
+            assert "slant" in kname.lower() or "SLANT" in kname, kname
         for ct in clouds:
             if ct is not None:
                 trm.set_cloudtop(float(ct)); o.set_cloudtop(float(ct))
@@ -45,8 +53,6 @@ def check(cfg, profs, what, clouds=(None,)):
     finally:
         trm.free_memory()
 
-mode = sys.argv[1]
-tmp = sys.argv[2]
 if mode == "lengths":
     for L in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 29, 30, 31, 32, 100):
         c = synth.make_case(os.path.join(tmp, "L%%d" %% L), nlayers=L, nwave=130)
@@ -75,8 +81,8 @@ elif mode == "zero":
         ids, tg, pr, wnn = op["ids"].copy(), op["temps"].copy(), op["press"].copy(), op["wn"].copy(); del op
         synth.write_opacity(c.opacity, ids, tg, pr, wnn, kappa=k)
         profs = walkers(c, 6, seed=11)
-        engine.init(c.tcfg); trm.set_integ(1)
-        o = orc.OracleEngine(c.tcfg, integ=1)
+        engine.init(c.tcfg); trm.set_integ(INTEG); trm.set_cut(CUT)
+        o = orc.OracleEngine(c.tcfg, integ=INTEG, cut=CUT)
         ref, got = o.run_batch(profs), engine.run_batch(profs)
         trm.free_memory()
         assert np.all(np.isfinite(got)), tag
@@ -87,10 +93,13 @@ print("ok")
 """
 
 
+@pytest.mark.parametrize("cut,integ", [("vertical", 1), ("slant", 1), ("slant", 0)])
 @pytest.mark.parametrize("mode", ["lengths", "cuts", "zero"])
-def test_simpson_single_wave_kernel(tmp_path, mode):
+def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ):
+    """(cut slant: the same sweeps through rt_eclipse_simpson_slant / rt_eclipse_fast<SLANT>, where every ray
+    angle ends on its own layer -- the deaths, pads and decks of five rays land on every block position.)"""
     env = dict(os.environ, BARTRT_KERNEL="mono_ilp")
-    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, mode, str(tmp_path)],
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, mode, str(tmp_path), cut, str(integ)],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
 

@@ -6,6 +6,7 @@
 #include "../../include/bartrt.h"
 #include "engine.hpp"
 #include "lbl.hpp"
+#include "share.hpp"
 #include "step.hpp"
 
 using namespace bartrt;
@@ -123,6 +124,13 @@ int bartrt_get_cia_interp(int *spline) {
   NEED_ENGINE();
   if (!spline) return fail(BARTRT_EINVAL, "get_cia_interp: null output pointer");
   *spline = g_eng->cia_spline ? 1 : 0;
+  return BARTRT_OK;
+}
+
+int bartrt_get_share(int *shared, int *owner) {
+  NEED_ENGINE();
+  if (shared) *shared = g_eng->kappa_share ? 1 : 0;
+  if (owner) *owner = (g_eng->kappa_share && g_eng->kappa_share->owner) ? 1 : 0;
   return BARTRT_OK;
 }
 

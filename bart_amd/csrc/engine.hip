@@ -2,12 +2,17 @@
 // drives the kernels.  One engine per process (one process per GPU).
 #include "engine.hpp"
 #include "lbl.hpp"
+#include "share.hpp"
 #include "step.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace bartrt {
 
@@ -24,6 +29,7 @@ Engine::~Engine() {
   delete step;
   delete lbl;
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  if (kappa_share) { kappa_share->release(); kappa_share = nullptr; d_kappa = nullptr; }
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_mass);
   fr(d_prep_consts); fr(d_diam); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
@@ -138,7 +144,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     throw IoError{"voigt: '" + cfg["voigt"] + "' is neither exact nor grid"};
   // `cut vertical | slant`: which optical depth `toomuch` is compared with
   {
-    std::string v = cfg_has(cfg, "cut") ? cfg["cut"] : "vertical";
+    std::string v = cfg_has(cfg, "cut") ? cfg["cut"] : "slant";
     if (const char *ev = std::getenv("BARTRT_CUT")) if (*ev) v = ev;
     if (v != "vertical" && v != "slant") throw IoError{"cut: '" + v + "' is neither vertical nor slant"};
     cut_slant = v == "slant";
@@ -251,37 +257,66 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     size_t slab_bytes = (size_t)256 << 20;
     if (const char *e = std::getenv("BARTRT_INIT_SLAB_BYTES")) slab_bytes = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
     const long per = std::max<long>(1, std::min<long>(planes, (long)(slab_bytes / (plane_doubles * sizeof(double)))));
-    double *h = nullptr, *d_stage = nullptr;
-    HIPCHK(hipMalloc(&d_kappa, n * sizeof(double)));
-    hipError_t er = hipHostMalloc(&h, (size_t)per * plane_doubles * sizeof(double), hipHostMallocDefault);
-    if (er == hipSuccess) er = hipMalloc(&d_stage, (size_t)per * plane_doubles * sizeof(double));
-    try {
-      for (long p0 = 0; p0 < planes && er == hipSuccess; p0 += per) {
-        const long np = std::min(per, planes - p0);
-        read_opacity_rows(cfg["opacityfile"], oh, lo, hi, p0 * M, np * M, h);
-        er = hipMemcpyAsync(d_stage, h, (size_t)np * plane_doubles * sizeof(double), hipMemcpyHostToDevice, stream);
-        if (er == hipSuccess) er = launch_grid_transpose(d_stage, d_kappa + (size_t)p0 * plane_doubles, np, M, Wl, stream);
-        if (er == hipSuccess) er = hipStreamSynchronize(stream);   // the slab buffers are reused
+    auto upload = [&](double *dst) {
+      double *h = nullptr, *d_stage = nullptr;
+      hipError_t er = hipHostMalloc(&h, (size_t)per * plane_doubles * sizeof(double), hipHostMallocDefault);
+      if (er == hipSuccess) er = hipMalloc(&d_stage, (size_t)per * plane_doubles * sizeof(double));
+      try {
+        for (long p0 = 0; p0 < planes && er == hipSuccess; p0 += per) {
+          const long np = std::min(per, planes - p0);
+          read_opacity_rows(cfg["opacityfile"], oh, lo, hi, p0 * M, np * M, h);
+          er = hipMemcpyAsync(d_stage, h, (size_t)np * plane_doubles * sizeof(double), hipMemcpyHostToDevice, stream);
+          if (er == hipSuccess) er = launch_grid_transpose(d_stage, dst + (size_t)p0 * plane_doubles, np, M, Wl, stream);
+          if (er == hipSuccess) er = hipStreamSynchronize(stream);   // the slab buffers are reused
+        }
+      } catch (...) {
+        if (h) (void)hipHostFree(h);
+        if (d_stage) (void)hipFree(d_stage);
+        throw;
       }
-    } catch (...) {
       if (h) (void)hipHostFree(h);
       if (d_stage) (void)hipFree(d_stage);
-      throw;
+      HIPCHK(er);
+    };
+    // `shareOpacity` (code/makecfg.py:106-107: BART's worker processes share ONE opacity grid; a bare key in
+    // the cfg makeTransit writes) or BARTRT_SHARE_OPACITY=1: the first process of this (file, device, block)
+    // uploads the grid, the others map its HBM allocation through an IPC handle (share.hpp)
+    bool share = cfg_has(cfg, "shareOpacity") && cfg["shareOpacity"] != "0" && cfg["shareOpacity"] != "no" &&
+                 cfg["shareOpacity"] != "false";
+    if (const char *e = std::getenv("BARTRT_SHARE_OPACITY")) if (*e) share = std::string(e) != "0";
+    if (share) {
+      struct stat fst;
+      if (stat(cfg["opacityfile"].c_str(), &fst) != 0) throw IoError{"opacity file: cannot stat " + cfg["opacityfile"]};
+      char rp[PATH_MAX];
+      const std::string real = realpath(cfg["opacityfile"].c_str(), rp) ? std::string(rp) : cfg["opacityfile"];
+      int bus = 0;
+      hipDeviceProp_t prop;
+      std::string devid = std::to_string(device);
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        bus = prop.pciBusID;
+        devid = std::to_string(prop.pciDomainID) + ":" + std::to_string(bus) + ":" + std::to_string(prop.pciDeviceID);
+      }
+      const std::string key = real + "|" + std::to_string((long long)fst.st_size) + "|" + std::to_string((long long)fst.st_mtime) +
+                              "|" + std::to_string((long long)getuid()) + "|dev " + devid + "|wn " + std::to_string(lo) + ":" +
+                              std::to_string(hi) + "|layout LTWM v1";
+      kappa_share = TableShare::attach(key, n * sizeof(double), upload);
+      d_kappa = kappa_share->ptr;
+    } else {
+      HIPCHK(hipMalloc(&d_kappa, n * sizeof(double)));
+      upload(d_kappa);
     }
-    if (h) (void)hipHostFree(h);
-    if (d_stage) (void)hipFree(d_stage);
-    HIPCHK(er);
   }
   // CIA: resample on the local grid (zero outside the file) and lay out, per table, nt-1
   // pair planes [W][2] = (alpha_j, alpha_j+1) per wavenumber: one 16-byte load per table and
   // layer (kernels.hpp, "Table layout").  `cia_interp` (BARTRT_CIA_INTERP):
-  // linear (default) in wavenumber and temperature, or spline -- natural cubic splines in both;
+  // spline (default: the reading of the reference believed in) -- natural cubic splines in wavenumber
+  // and temperature -- or linear in both;
   // the temperature spline's second derivatives then ride as one more table per file, whose
   // weights prep_body fills with the spline's curvature terms, so every RT kernel serves it.
   std::vector<double> cia_planes, cia_temp;
   PrepArgs &pa = prep;
   {
-    std::string v = cfg_has(cfg, "cia_interp") ? cfg["cia_interp"] : "linear";
+    std::string v = cfg_has(cfg, "cia_interp") ? cfg["cia_interp"] : "spline";
     if (const char *ev = std::getenv("BARTRT_CIA_INTERP")) if (*ev) v = ev;
     if (v != "linear" && v != "spline") throw IoError{"cia_interp: '" + v + "' is neither linear nor spline"};
     cia_spline = v == "spline";

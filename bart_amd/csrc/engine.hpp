@@ -18,6 +18,7 @@ hipError_t launch_grid_transpose(const double *src, double *dst, long planes, in
 
 int parse_integ(const std::string &v);  // "0" / "transmittance", "1" / "simpson", "2" / "trapz_tau"
 
+struct TableShare;  // the opacity grid shared between processes (share.hpp)
 struct StepArgs;  // converters around the engine (step.hip)
 struct Lbl;       // line-by-line extinction (lbl.hip)
 
@@ -45,6 +46,7 @@ struct Engine {
   // device-resident inputs
   double *d_kappa = nullptr, *d_cia = nullptr, *d_wn = nullptr, *d_wn_full = nullptr;
   double *d_press = nullptr, *d_mass = nullptr, *d_diam = nullptr;
+  TableShare *kappa_share = nullptr;  // cfg `shareOpacity`: d_kappa is (or is mapped from) another process's allocation
   double *d_prep_consts = nullptr;  // PrepArgs::consts
   PrepArgs prep{};  // static part filled at init
   RtArgs rt{};

@@ -4,9 +4,13 @@
 #include <hip/hip_ext.h>
 
 // (molecules, CIA pairs) the specialised kernels are instantiated for
+// (four CIA slots = two cross-section files under the default `cia_interp spline`: BART's usual H2-H2 + H2-He)
 #define BARTRT_MC_LIST(X) \
   X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) \
-  X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2) X(7, 1) X(7, 2) X(8, 1) X(8, 2)
+  X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2) X(7, 1) X(7, 2) X(8, 1) X(8, 2)                 \
+  X(1, 4) X(2, 4) X(3, 4) X(4, 4) X(5, 4) X(6, 4)
+// CIA slot counts of the line-by-line hand-off kernels (no table molecules)
+#define BARTRT_EXT_C_LIST(X) X(0) X(1) X(2) X(4)
 
 // Every launch of an RT kernel goes through this: the kernel's own dispatch carries the timing
 // events of RtArgs (null: a plain launch).
@@ -27,7 +31,7 @@ constexpr double kRaySigma0 = 2.52e-28, kRayLambda0 = 7.5e-5;
 constexpr double kPolH2 = 0.8059e-24, kPolHe = 0.2051e-24;
 
 constexpr int kMaxAngles = 16;
-constexpr int kMaxCia = 4;
+constexpr int kMaxCia = 8;
 constexpr int kMaxMol = 16;
 
 // Per-layer coefficient record produced by prep_profiles, consumed by the RT

@@ -691,7 +691,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   if (a.ext) {
     // line-by-line hand-off: the single-wave kernel with the extinction array as one
     // more load per layer (rules 0 and 1, no table; anything else takes the generic kernel)
-    if (!(INTEG != kIntegTrapzTau && a.A == 5 && a.M == 0 && a.C <= 2 && !a.intens_out && !a.tau_out &&
+    if (!(INTEG != kIntegTrapzTau && a.A == 5 && a.M == 0 && (a.C <= 2 || a.C == 4) && !a.intens_out && !a.tau_out &&
           sh <= 55 * 1024 && kmode != "generic"))
       return false;
     RtArgs b = a;

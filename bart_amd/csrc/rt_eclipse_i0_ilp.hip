@@ -27,7 +27,7 @@ bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t
     err = hipGetLastError();                                                                                          \
     return true;                                                                                                      \
   }
-  BARTRT_FAST_EXT(0) BARTRT_FAST_EXT(1) BARTRT_FAST_EXT(2)
+  BARTRT_EXT_C_LIST(BARTRT_FAST_EXT)
 #undef BARTRT_FAST_EXT
   return false;
 }

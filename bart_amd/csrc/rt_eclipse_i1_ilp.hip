@@ -28,7 +28,7 @@ bool launch_rt_simpson_ext(const RtArgs &b, bool sq, int block, int nblocks, siz
     err = hipGetLastError();                                                                                          \
     return true;                                                                                                      \
   }
-  BARTRT_S1_EXT(0) BARTRT_S1_EXT(1) BARTRT_S1_EXT(2)
+  BARTRT_EXT_C_LIST(BARTRT_S1_EXT)
 #undef BARTRT_S1_EXT
   return false;
 }

@@ -41,7 +41,7 @@ bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nbl
     err = hipGetLastError();                                                                                                   \
     return true;                                                                                                               \
   }
-  BARTRT_SLANT_EXT(0) BARTRT_SLANT_EXT(1) BARTRT_SLANT_EXT(2)
+  BARTRT_EXT_C_LIST(BARTRT_SLANT_EXT)
 #undef BARTRT_SLANT_EXT
   return false;
 }

@@ -318,7 +318,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   static const bool force_window = std::getenv("BARTRT_WINDOW") != nullptr;  // (tests)
   const bool window = a.kappa_bytes >= (1ull << 32) - 4096 || force_window;
   const bool fits32 = a.cia_bytes < (1ull << 32) - 4096 && (!window || window_fits(a, 4));
-  if (!generic_only && a.ext && a.M == 0 && a.C <= 2 && !a.tau_out && a.cia_bytes < (1ull << 32) - 4096 &&
+  if (!generic_only && a.ext && a.M == 0 && (a.C <= 2 || a.C == 4) && !a.tau_out && a.cia_bytes < (1ull << 32) - 4096 &&
       a.L <= 16 * kMfmaTilesMax) {
     // line-by-line engines (no table): the matrix-tile kernel with the extinction array as input
     RtArgs b = a;
@@ -336,7 +336,7 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
       BARTRT_RT_LAUNCH((rt_transit_mfma<0, CC, kMfmaTilesMax, true>), dim3(nb), dim3(256), shm, st, b); \
     return hipGetLastError();                                                                        \
   }
-    BARTRT_TRANSIT_EXT(0) BARTRT_TRANSIT_EXT(1) BARTRT_TRANSIT_EXT(2)
+    BARTRT_EXT_C_LIST(BARTRT_TRANSIT_EXT)
 #undef BARTRT_TRANSIT_EXT
   }
   // (the matrix-tile kernels run on the default 64 kB of dynamic LDS: a column whose records need more --

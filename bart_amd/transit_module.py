@@ -90,6 +90,7 @@ def lib():
         L.bartrt_set_cut.argtypes = [i]
         L.bartrt_get_cut.argtypes = [C.POINTER(i)]
         L.bartrt_get_cia_interp.argtypes = [C.POINTER(i)]
+        L.bartrt_get_share.argtypes = [C.POINTER(i), C.POINTER(i)]
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
@@ -163,7 +164,7 @@ def set_integ(rule):
 
 
 def set_cut(cut):
-    """'vertical' (default) or 'slant': which optical depth `toomuch` is compared with
+    """'slant' (default) or 'vertical': which optical depth `toomuch` is compared with
     (include/bartrt.h, bartrt_set_cut)."""
     check(lib().bartrt_set_cut({"vertical": 0, "slant": 1, 0: 0, 1: 1}[cut]))
 
@@ -175,11 +176,19 @@ def get_cut() -> str:
 
 
 def get_cia_interp() -> str:
-    """'linear' or 'spline': how the engine resampled the cross-section files at init
+    """'spline' (default) or 'linear': how the engine resampled the cross-section files at init
     (cfg key `cia_interp`)."""
     v = C.c_int(-1)
     check(lib().bartrt_get_cia_interp(C.byref(v)))
     return "spline" if v.value else "linear"
+
+
+def get_share():
+    """-> (shared, owner): the opacity grid is one allocation shared between processes (cfg `shareOpacity`,
+    code/makecfg.py:106-107) / this process made it."""
+    a, b = C.c_int(0), C.c_int(0)
+    check(lib().bartrt_get_share(C.byref(a), C.byref(b)))
+    return bool(a.value), bool(b.value)
 
 
 def get_integ() -> int:

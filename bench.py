@@ -920,7 +920,7 @@ def main():
             other = "forest" if a.kappa == "survey8d" else "survey8d"
             res[other + "_workload"] = guarded(other, lambda: bench_configs.kappa_leg(
                 a, wd, conv, other, make_profiles, launch_byte_model, PEAK_HBM_GBS))
-            res["configs"] = guarded("configs", lambda: bench_configs.run_all(integ))
+            res["configs"] = guarded("configs", lambda: bench_configs.run_all(integ, headline_dir=wd, kappa=a.kappa))
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(
                 case, conv, profs_all.reshape(-1, profs_all.shape[-1])))

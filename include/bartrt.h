@@ -91,19 +91,31 @@ int bartrt_set_integ(int rule);
 int bartrt_get_integ(int *rule);
 
 /* Which optical depth `toomuch` is compared with (no counterpart in the reference's
- * module).  0 (default) = the vertical depth: the column ends on one layer for every ray angle --
- * the form every specialised kernel is built on.  1 = each ray's SLANT depth tau / mu: SURVEY.md
- * App. A-4 read literally ("slant path ds = dr / cos(theta) ... stops where tau > toomuch"); every
- * angle ends on its own layer and rule 1 pads one unit of slant depth; runs the generic kernel
- * (3-10x slower).  The two differ by about exp(-toomuch) of the flux.  Also the cfg key
- * `cut vertical|slant` and BARTRT_CUT. */
+ * module).  1 (default since round 4) = each ray's SLANT depth tau / mu: SURVEY.md App. A-4 read
+ * literally ("slant path ds = dr / cos(theta) ... stops where tau > toomuch") and the reading the
+ * engine's call structure is recalled to have -- the optical depth is computed per ray angle, the
+ * cut inside that loop; every angle ends on its own layer and rule 1 pads one unit of slant depth.
+ * 0 = the vertical depth: the column ends on one layer for every ray angle.  Both run specialised
+ * single-wave kernels (rules 0 and 1; the slant cut costs 1.15-1.35x per launch); the two differ
+ * by about exp(-toomuch) of the flux.  Also the cfg key `cut vertical|slant` and BARTRT_CUT. */
 int bartrt_set_cut(int slant);
 int bartrt_get_cut(int *slant);
 
 /* How the engine interpolates the cross-section (CIA) files, fixed at bartrt_init by the cfg key
- * `cia_interp linear|spline` / BARTRT_CIA_INTERP: *spline = 0 linear in wavenumber
- * and temperature, 1 natural cubic splines in both.  Read-only: the tables are resampled at init. */
+ * `cia_interp linear|spline` / BARTRT_CIA_INTERP: *spline = 1 (default since round 4)
+ * natural cubic splines in wavenumber and temperature, 0 linear in both.  Read-only: the tables are
+ * resampled at init. */
 int bartrt_get_cia_interp(int *spline);
+
+/* `shareOpacity` (a key of the reference's transit cfg: code/makecfg.py:106-107, BART.py:259-262 --
+ * BART's worker processes, one per chain, keep ONE copy of the opacity grid): with the key in the
+ * cfg (or BARTRT_SHARE_OPACITY=1) the first process to initialise on a (file, GPU, wavenumber block)
+ * uploads the grid and the others map its HBM allocation through a HIP IPC handle published in a
+ * POSIX shared-memory segment.  *shared = 1 if this engine's grid is such an allocation, *owner = 1
+ * if this process made it (it frees it in bartrt_free_memory once the other processes have let go,
+ * or after BARTRT_SHARE_WAIT_S seconds, default 60).  HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the
+ * environment where the host driver supports dmabuf IPC only. */
+int bartrt_get_share(int *shared, int *owner);
 
 /* Prefetched preparation.  Names the profile batch of the bartrt_run_transit_batch_dev call
  * AFTER the next one: the next call's RT launch prepares that batch's layer records

@@ -184,8 +184,8 @@ class OracleEngine:
         self.kappa = np.ascontiguousarray(kap[:, :, :, sl]) if kap.shape[2] else np.zeros(1)
         W = len(self.wn)
         s1, s2, cnt, ct, ca, cy = [], [], [], [], [], []
-        spline = (cia_interp or k.get("cia_interp", "linear")) == "spline"     # the product's cfg key
-        assert (cia_interp or k.get("cia_interp", "linear")) in ("linear", "spline")
+        spline = (cia_interp or k.get("cia_interp", "spline")) == "spline"     # the product's cfg key
+        assert (cia_interp or k.get("cia_interp", "spline")) in ("linear", "spline")
         for f in [x for x in k.get("csfile", "").split(",") if x]:
             c = read_cia(f)
             s1.append(self.species.index(c["species"][0]))
@@ -220,7 +220,7 @@ class OracleEngine:
             integ = {"transmittance": 0, "simpson": 1, "trapz_tau": 2, "trapz": 2}.get(v)
             integ = int(v) if integ is None else integ
         c.integ = int(integ)
-        cut = cut or k.get("cut", "vertical")       # the product's cfg key
+        cut = cut or k.get("cut", "slant")       # the product's cfg key
         assert cut in ("vertical", "slant")
         c.cut_slant = int(cut == "slant")
         c.solution = 0 if k.get("solution", "eclipse") == "eclipse" else 1

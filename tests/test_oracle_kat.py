@@ -10,10 +10,11 @@ from bart_amd import synth
 from oracle import rt_oracle as orc
 
 
-def _engine(tmp_path, integ=None, **kw):
-    """integ: the integration rule the known answer belongs to (None: the default, rule 1)."""
+def _engine(tmp_path, integ=None, cut=None, **kw):
+    """integ: the integration rule the known answer belongs to (None: the default, rule 1);
+    cut: which depth `toomuch` cuts (None: the default, each ray's slant depth)."""
     case = synth.make_case(str(tmp_path), **kw)
-    return case, orc.OracleEngine(case.tcfg, integ=integ)
+    return case, orc.OracleEngine(case.tcfg, integ=integ, cut=cut)
 
 
 def _wgt(angles):
@@ -58,19 +59,28 @@ def test_table_interpolation_at_nodes_and_midpoints(tmp_path):
     np.testing.assert_allclose(ext[l], want, rtol=1e-15)
 
 
-def test_isothermal_closed_form(tmp_path):
+@pytest.mark.parametrize("cut", ["vertical", "slant"])
+def test_isothermal_closed_form(tmp_path, cut):
     """Isothermal column, any opacity: under rule 0 (trapezoid in the
     transmittance) I(mu) = B (1 - exp(-tau_last/mu)) exactly, so the flux tends to pi*B from
-    below once tau >> 1.  (Rules 1 and 2 reach it in the limit of fine layers:
-    test_all_rules_converge_on_a_finely_layered_isothermal_column.)"""
-    case, e = _engine(tmp_path, integ=0, nwave=40)
+    below once tau >> 1 -- tau_last the depth of the column's cut (`cut vertical`) or of the
+    ray's own (`cut slant`: the first layer whose slant depth passes toomuch).  (Rules 1 and 2
+    reach it in the limit of fine layers: test_all_rules_converge_on_a_finely_layered_isothermal_column.)"""
+    case, e = _engine(tmp_path, integ=0, cut=cut, nwave=40)
     T = 1500.0
     spec, tau, last = e.run(case.profiles(temp=np.full(100, T)), want_tau=True)
     wg = _wgt(e.angles)
+    toomuch = float(e.keys["toomuch"])
     for i in range(0, 40, 7):
         B = orc.planck(e.wn[i], T)
-        F = sum(w * B * (1.0 - np.exp(-tau[i, last[i]] / np.cos(np.radians(a))))
-                for a, w in zip(e.angles, wg))
+        F = 0.0
+        for a, w in zip(e.angles, wg):
+            mu = np.cos(np.radians(a))
+            la = last[i]
+            if cut == "slant":
+                over = np.nonzero(tau[i, :last[i] + 1] / mu > toomuch)[0]
+                la = over[0] if len(over) else last[i]
+            F += w * B * (1.0 - np.exp(-tau[i, la] / mu))
         assert abs(spec[i] / F - 1) < 1e-13
         assert tau[i, last[i]] > 10.0
         assert 1 - 1e-4 < spec[i] / (np.pi * B) <= 1.0
@@ -186,14 +196,17 @@ def _parabola_hybrid(x, y):
     return res
 
 
+@pytest.mark.parametrize("cut", ["vertical", "slant"])
 @pytest.mark.parametrize("toomuch", [0.7, 10.0, 1e30])
-def test_rule1_is_the_simpson_hybrid_of_appendix_a4(tmp_path, toomuch):
+def test_rule1_is_the_simpson_hybrid_of_appendix_a4(tmp_path, toomuch, cut):
     """Rule 1 (SURVEY.md App. A-4 as recalled) pinned against an independent numpy
     statement: tau[k] = hybrid over the layers k .. top taken from layer k upwards;
     I(mu) = (1/mu) hybrid over (tau, B exp(-tau/mu)) from the top down to `last`,
-    plus one zero point one unit of tau further when a layer exists there."""
+    plus one zero point one unit of tau further when a layer exists there.  `cut slant`
+    (the default): `last` is the ray's own -- the first layer whose SLANT depth tau / mu
+    passes toomuch -- and the padded point lies one unit of slant depth further (mu in tau)."""
     case = synth.make_case(str(tmp_path), nwave=12, nlayers=31, toomuch=toomuch)
-    e = orc.OracleEngine(case.tcfg, integ=1)
+    e = orc.OracleEngine(case.tcfg, integ=1, cut=cut)
     prof = case.profiles(temp=np.linspace(1900.0, 700.0, 31))
     spec, tau, last = e.run(prof, want_tau=True)
     inten = e.intensity(prof)
@@ -208,16 +221,20 @@ def test_rule1_is_the_simpson_hybrid_of_appendix_a4(tmp_path, toomuch):
         assert k1 == L - 1 or tau[i, k1] > toomuch
         for a, ang in enumerate(e.angles):
             mu = np.cos(np.radians(ang))
-            x = list(tau[i, :k1 + 1])
-            y = [orc.planck(e.wn[i], prof[0][L - 1 - k]) * np.exp(-tau[i, k] / mu) for k in range(k1 + 1)]
-            if k1 + 1 < L:
-                x.append(x[-1] + 1.0); y.append(0.0)
+            ka, pad = k1, 1.0
+            if cut == "slant":
+                over = np.nonzero(tau[i, :k1 + 1] / mu > toomuch)[0]
+                ka, pad = (over[0] if len(over) else k1), mu
+            x = list(tau[i, :ka + 1])
+            y = [orc.planck(e.wn[i], prof[0][L - 1 - k]) * np.exp(-tau[i, k] / mu) for k in range(ka + 1)]
+            if ka + 1 < L:
+                x.append(x[-1] + pad); y.append(0.0)
             assert abs(inten[a, i] / (_parabola_hybrid(x, y) / mu) - 1) < 1e-11
     # rule 2 is the plain trapezoid of the same integrand on rule 0's optical depth
-    e2 = orc.OracleEngine(case.tcfg, integ=2)
+    e2 = orc.OracleEngine(case.tcfg, integ=2, cut="vertical")
     _, tau2, last2 = e2.run(prof, want_tau=True)
     in2 = e2.intensity(prof)
-    _, tau0, last0 = orc.OracleEngine(case.tcfg, integ=0).run(prof, want_tau=True)
+    _, tau0, last0 = orc.OracleEngine(case.tcfg, integ=0, cut="vertical").run(prof, want_tau=True)
     assert np.array_equal(tau2, tau0) and np.array_equal(last2, last0)
     i, k1 = 5, last2[5]
     y = np.array([orc.planck(e.wn[i], prof[0][L - 1 - k]) * np.exp(-tau2[i, k]) for k in range(k1 + 1)])

@@ -275,8 +275,73 @@ def lbl(integ, wnosamps=(1, 2160)):
     return out
 
 
-def run_all(integ):
+def mc3_processes(headline_dir, kappa, nprocs=(3, 10), steps=1500):
+    """INTEGRATION.md section 1 taken literally: MC3 starts one worker process per chain (examples/WASP-12b/BART.cfg:113:
+    ten; the demo three) and each holds its own transit instance -- transit_init, then run_transit once per step.  N
+    such processes (tools/mc3_child.py) on ONE GPU and the headline grid, in lockstep: with every process uploading its
+    own 864 MB grid, and with `shareOpacity` (code/makecfg.py:106-107): one process uploads, the others map that
+    allocation (csrc/share.hip).  Reported: aggregate spectra/s, time per call, init time, device memory in use."""
+    import subprocess
+    import torch
+    from bart_amd import synth
+    case = synth.make_case(headline_dir, nlayers=100, nwave=10000, kappa_model=kappa, reuse=True)
+    shared_cfg = case.tcfg + ".share"
+    open(shared_cfg, "w").write(open(case.tcfg).read().rstrip("\n") + "\nshareOpacity\n")
+    child = os.path.join(ROOT, "tools", "mc3_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def used():
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    def expect(p, word):
+        for line in p.stdout:
+            if line.startswith(word + " "):
+                return json.loads(line[len(word) + 1:])
+        raise RuntimeError("worker ended without '%s': %s" % (word, p.stderr.read()[-2000:]))
+
+    out = {"note": "N processes x one walker per call through trm.run_transit (host buffers in and out), all on one GPU; "
+                   "the grouped worker (BARTfunc.main(comm, group): the chains of all workers batched into one call) and "
+                   "the in-process sampler are the forms that reach the bench line's rate -- this is the unmodified path"}
+    for share in (False, True):
+        for n in nprocs:
+            base = used()
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, child, shared_cfg if share else case.tcfg, str(r), str(steps)],
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+                     for r in range(n)]
+            try:
+                ready = [expect(p, "ready") for p in procs]
+                t_up = time.perf_counter() - t0
+                mem = used() - base
+                for p in procs:
+                    p.stdin.write("go\n"); p.stdin.flush()
+                done = [expect(p, "done") for p in procs]
+                for p in procs:
+                    p.stdin.write("bye\n"); p.stdin.flush()
+                for p in procs:
+                    p.wait(timeout=180)
+            finally:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            loop = max(d["loop_s"] for d in done)
+            out["%s_%d" % ("shared" if share else "own_copies", n)] = {
+                "processes": n, "steps_per_process": steps, "aggregate_spectra_per_s": n * steps / loop,
+                "us_per_call_median": float(np.median([d["us_per_step"] for d in done])),
+                "init_s_median": float(np.median([r["init_s"] for r in ready])), "all_ready_after_s": t_up,
+                "device_memory_in_use_GB": mem / 1e9, "owners": int(sum(r["owner"] for r in ready)),
+                "shared": bool(all(r["shared"] for r in ready))}
+    return out
+
+
+def run_all(integ, headline_dir=None, kappa="survey8d"):
     res = {}
+    if headline_dir:
+        try:
+            res["mc3_processes"] = mc3_processes(headline_dir, kappa)
+        except Exception as e:
+            res["mc3_processes"] = {"error": repr(e)}
     for name, fn in (("demo_1walker", demo_1walker), ("wasp12b_step", wasp12b_step)):
         try:
             res[name] = fn(integ)

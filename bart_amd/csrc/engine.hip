@@ -281,8 +281,9 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     // `shareOpacity` (code/makecfg.py:106-107: BART's worker processes share ONE opacity grid; a bare key in
     // the cfg makeTransit writes) or BARTRT_SHARE_OPACITY=1: the first process of this (file, device, block)
     // uploads the grid, the others map its HBM allocation through an IPC handle (share.hpp)
-    bool share = cfg_has(cfg, "shareOpacity") && cfg["shareOpacity"] != "0" && cfg["shareOpacity"] != "no" &&
-                 cfg["shareOpacity"] != "false";
+    bool share = false;     // (makeTransit writes the key bare: present without a value means yes)
+    if (auto it = cfg.find("shareOpacity"); it != cfg.end())
+      share = it->second != "0" && it->second != "no" && it->second != "false" && it->second != "False";
     if (const char *e = std::getenv("BARTRT_SHARE_OPACITY")) if (*e) share = std::string(e) != "0";
     if (share) {
       struct stat fst;

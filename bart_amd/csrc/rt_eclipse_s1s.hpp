@@ -52,6 +52,8 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C;
   constexpr int NR = NLD + (EXT ? 1 : 0) > 0 ? NLD + (EXT ? 1 : 0) : 1;
   constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
+  constexpr int kBlk = 6;             // layers per straight-line block (even: a layer's parity is its position)
+  static_assert(kBlk - 2 <= kSimpsonPad, "the radius table's overrun entries");
   const int L = p.L, W = p.W;
   int bid = blockIdx.x;
   if (p.nprep > 0) {   // the head of the grid prepares the NEXT batch's layer records (RtArgs::nprep)
@@ -128,9 +130,9 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     nprev = nnow;
   };
 
-  // one layer.  J = position in the four-layer block (the parity of k), FIRST = the block of
+  // one layer.  J = position in the six-layer block (the parity of k), FIRST = the block of
   // k0 = 0, MASKED = the column's last block: layers past kend are walked with clamped inputs
-  // and masked; the blocks above it lie inside the column (k0 + 3 <= kcut) and carry no range
+  // and masked; the blocks above it lie inside the column (k0 + 5 <= kcut) and carry no range
   // logic at all.
   auto layer = [&](auto Jc, auto Fc, auto Mc, int k0, const double (&r)[NR], const double (&cf)[NC],
                    double (&cfn)[NC]) {
@@ -138,7 +140,7 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     constexpr bool FIRST = decltype(Fc)::value, MASKED = decltype(Mc)::value;
     const int k = k0 + J;
     auto read_rec = [&](int kk, double (&c_)[NC]) {
-      const double *c = sC + ((MASKED || J == 3) ? (kk < kend ? kk : kend) : kk) * NC;
+      const double *c = sC + ((MASKED || J == kBlk - 1) ? (kk < kend ? kk : kend) : kk) * NC;
 #pragma unroll
       for (int j = 0; j < NC; j++) c_[j] = c[j];
     };
@@ -220,21 +222,32 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   using std::true_type;
   using std::false_type;
 
-  double a0[NR], a1[NR], b0[NR], b1[NR];
+  // THREE load slots in rotation over straight-line blocks of SIX layers: a slot is reloaded for the layer
+  // three below right after the layer that used it, so every load is issued two layers of arithmetic before
+  // its use -- the shortest distance of rt_eclipse_simpson's two-pairs-of-slots scheme -- with a quarter fewer
+  // registers in flight (with two CIA slots the four-slot form spilled, and a spill's reload queues behind the
+  // table loads in flight: 119 against 88 us per ten-walker launch)
+  double s0[NR], s1[NR], s2[NR];
   double cfE[NC], cfO[NC];
-  auto block4 = [&](auto Fc, auto Mc, int k0) {
+  auto block6 = [&](auto Fc, auto Mc, int k0) {
     constexpr bool MASKED = decltype(Mc)::value;
-    load_layer(MASKED ? clampk(k0 + 2) : k0 + 2, b0);
-    load_layer(MASKED ? clampk(k0 + 3) : k0 + 3, b1);
-    layer(integral_constant<int, 0>{}, Fc, Mc, k0, a0, cfE, cfO);
-    layer(integral_constant<int, 1>{}, Fc, Mc, k0, a1, cfO, cfE);
-    load_layer(clampk(k0 + 4), a0);
-    load_layer(clampk(k0 + 5), a1);
-    layer(integral_constant<int, 2>{}, Fc, Mc, k0, b0, cfE, cfO);
-    layer(integral_constant<int, 3>{}, Fc, Mc, k0, b1, cfO, cfE);
+    auto inblk = [&](int k) { return MASKED ? clampk(k) : k; };
+    layer(integral_constant<int, 0>{}, Fc, Mc, k0, s0, cfE, cfO);
+    load_layer(inblk(k0 + 3), s0);
+    layer(integral_constant<int, 1>{}, Fc, Mc, k0, s1, cfO, cfE);
+    load_layer(inblk(k0 + 4), s1);
+    layer(integral_constant<int, 2>{}, Fc, Mc, k0, s2, cfE, cfO);
+    load_layer(inblk(k0 + 5), s2);
+    layer(integral_constant<int, 3>{}, Fc, Mc, k0, s0, cfO, cfE);
+    load_layer(clampk(k0 + 6), s0);
+    layer(integral_constant<int, 4>{}, Fc, Mc, k0, s1, cfE, cfO);
+    load_layer(clampk(k0 + 7), s1);
+    layer(integral_constant<int, 5>{}, Fc, Mc, k0, s2, cfO, cfE);
+    load_layer(clampk(k0 + 8), s2);
   };
-  load_layer(clampk(0), a0);
-  load_layer(clampk(1), a1);
+  load_layer(clampk(0), s0);
+  load_layer(clampk(1), s1);
+  load_layer(clampk(2), s2);
   if constexpr (SCHED != 0) {
 #pragma unroll
     for (int j = 0; j < NC; j++) cfE[j] = sC[j];
@@ -245,25 +258,25 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     asm volatile("" : "+s"(mk));
     return mk != 0ull;
   };
-  int kw = 4;   // layers walked (whole blocks)
-  if (kcut >= 3) {
-    block4(true_type{}, false_type{}, 0);
-    int k0 = 4;
+  int kw = kBlk;   // layers walked (whole blocks)
+  if (kcut >= kBlk - 1) {
+    block6(true_type{}, false_type{}, 0);
+    int k0 = kBlk;
     bool alive = any_active();
-    if (alive & (k0 + 3 <= kcut)) {
+    if (alive & (k0 + kBlk - 1 <= kcut)) {
       do {
-        block4(false_type{}, false_type{}, k0);
-        k0 += 4;
+        block6(false_type{}, false_type{}, k0);
+        k0 += kBlk;
         alive = any_active();
-      } while (alive & (k0 + 3 <= kcut));
+      } while (alive & (k0 + kBlk - 1 <= kcut));
     }
     kw = k0;
-    if (alive & (k0 <= kend)) {   // the column's last, partial block
-      block4(false_type{}, true_type{}, k0);
-      kw = k0 + 4;
+    if (alive & (k0 <= kend)) {   // the column's last, partial block (at most kBlk layers are left: kend <= kcut + 1)
+      block6(false_type{}, true_type{}, k0);
+      kw = k0 + kBlk;
     }
   } else {
-    block4(true_type{}, true_type{}, 0);
+    block6(true_type{}, true_type{}, 0);
   }
 
   // ---- after the walk: per ray angle the sum of its parity, its padded panel, the deck's surface term

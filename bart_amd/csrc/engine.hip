@@ -717,8 +717,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   }
   r.walked_out = nullptr;
   if (want_walked && solution == 0 && !lbl_fused) {
-    // the finest column any eclipse kernel records is 8 wavenumbers wide
-    const size_t need = (size_t)n * ((size_t)(r.W + 7) / 8 + 64);
+    // the finest column any eclipse kernel records is 3 wavenumbers wide (rt_eclipse_quad with one ray per lane)
+    const size_t need = (size_t)n * ((size_t)(r.W + 2) / 3 + 64);
     if (need > walked_cap) {
       if (d_walked) HIPCHK(hipFree(d_walked));
       d_walked = nullptr;

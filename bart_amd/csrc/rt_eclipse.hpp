@@ -45,6 +45,11 @@ namespace bartrt {
 //   5: 60 / 54 / 47   6: 64 / 58 / 50   7: 78 / 74 / 64   8: 81 / 78 / 68   9: 91 / 79 / 69   10: 103 / 102 / 71
 // -- the single-wave kernel from four walkers on, the producer / consumer pair never.
 constexpr long kQuadMaxColumns = 640, kQuadMaxColumnsSimpson = 480;
+// `cut slant`: one ray per lane (rt_eclipse_quad<..., RAYS>) while the launch is a few thousand (walker, wavenumber)
+// pairs -- the demo shape's 2 501 samples with one walker 15 us against the single-wave kernel's 51; it redoes the
+// extinction five times over, so on the 1e4-sample grid ONE walker already takes what the single-wave kernel takes
+// (63 against 58 us, +35 us per further walker)
+constexpr long kQuadRaysMaxColumns = 80;
 constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this
 constexpr long kSplitMinColumns = 1025, kSplitMaxColumns = 1300;
 constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
@@ -405,13 +410,26 @@ void rt_eclipse_split(RtArgs p) {
 // was the last row), and at the end the rows whose parity is that of the last
 // point's index are added up.  The optical depth is the prefix sum of the even
 // rows' radius panels plus, on odd rows, the trapezoid of the last interval.
-template <int AT, int MT, int CT, bool SQ, int R, int INTEG>
+//
+// RAYS: one ray angle per lane -- a wave's 64 / R columns are (wavenumber, ray) pairs instead of wavenumbers (R = 4,
+// five angles: three wavenumbers x five rays, one column idle).  Every lane then runs the single-ray form of the
+// walk with its own ray's constants: one transmittance, ITS cut (`cut slant`: the ray's threshold RtArgs::thr, so the
+// ballots that find a column's cut and the row that carries the padded point work per ray as they stand) and ITS pad
+// width (mu of vertical depth = one unit of slant depth); the five rays of a wavenumber meet in a five-lane sum at
+// the very end.  Extinction, optical depth and Planck term are computed five times over -- on launches that leave
+// most of the chip idle anyway (one to three walkers) -- in exchange for a layer-parallel walk whose per-step work
+// is a fifth of the five-ray lane's: this is how `cut slant`, whose rays cannot share a layer sum, keeps a
+// few-walker kernel (the single-wave slant kernel walks a column's 100 layers serially: 50 us at any small batch).
+template <int AT, int MT, int CT, bool SQ, int R, int INTEG, bool RAYS = false>
 __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;
-  constexpr int AE = SQ ? A - 1 : A;  // transmittances that need an exponential
-  constexpr int WN = 64 / R;           // wavenumbers per wave
+  constexpr int AL = RAYS ? 1 : A;                    // ray angles a lane evaluates
+  constexpr int AE = RAYS ? 1 : (SQ ? A - 1 : A);     // transmittances that need an exponential
+  constexpr int WN = 64 / R;                          // columns per wave
+  constexpr int WNR = RAYS ? WN / A : WN;             // wavenumbers per wave
+  static_assert(!RAYS || (WNR >= 1 && !SQ), "RAYS: the ray grid fits a lane row; no squared-transmittance shortcut");
   constexpr bool SIMPSON = INTEG == kIntegSimpson;
   const int L = p.L, W = p.W;
   int bid = blockIdx.x;
@@ -437,9 +455,22 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 
   const int lane = threadIdx.x & 63;
   const int q = lane / WN, m = lane % WN;
-  const int i0 = (tile * 4 + (threadIdx.x >> 6)) * WN;  // this wave's first wavenumber
+  const int ray = RAYS ? m % A : 0, mw = RAYS ? m / A : m;   // column m = wavenumber mw (and ray)
+  const bool col_on = !RAYS || m < WNR * A;                  // (RAYS: the columns past the last whole wavenumber idle)
+  const int i0 = (tile * 4 + (threadIdx.x >> 6)) * WNR;  // this wave's first wavenumber
   if (i0 >= W) return;
-  const unsigned ii = i0 + m < W ? (unsigned)(i0 + m) : (unsigned)(W - 1);
+  const unsigned ii = (col_on && i0 + mw < W) ? (unsigned)(i0 + mw) : (unsigned)(W - 1);
+  // this lane's ray (RAYS) -- or, without, the column's cut and pad as they always were
+  double invmu_l = p.invmu[0], wgt_l = p.wgt[0], wq_l = p.wq[0], thr_l = p.toomuch, padw_l = 1.0;
+  if constexpr (RAYS) {
+    if (p.cut_slant) { thr_l = p.thr[0]; padw_l = p.mu[0]; }
+#pragma unroll
+    for (int a = 1; a < A; a++)
+      if (ray == a) {
+        invmu_l = p.invmu[a]; wgt_l = p.wgt[a]; wq_l = p.wq[a];
+        if (p.cut_slant) { thr_l = p.thr[a]; padw_l = p.mu[a]; }
+      }
+  }
   const double nu = p.wn[ii];
   const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
   const double nu4 = (nu * nu) * (nu * nu);
@@ -478,9 +509,11 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   // carries of row 0: extinction, Planck term, transmittances of the layer just
   // above this step (row R - 1 of the previous step), and the optical depth there
   double c_e = 0.0, c_B = 0.0, c_tau = 0.0;
-  double c_G = p.wgt[0];   // rule 0: sum_a w_a E_a of the layer above (all transmittances 1 at the top)
+  double c_G = RAYS ? wgt_l : p.wgt[0];   // rule 0: sum_a w_a E_a of the layer above (all transmittances 1 at the top)
+  if constexpr (!RAYS) {
 #pragma unroll
-  for (int a = 1; a < A; a++) c_G += p.wgt[a];
+    for (int a = 1; a < A; a++) c_G += p.wgt[a];
+  }
   // rule 1: second carries (row R - 2 / R - 1 of the previous step for rows 0 / 1),
   // the running even-index Simpson sum of the optical depth, the index of the last
   // point of the intensity integral and the "next step's row 0 is the padded point" flag
@@ -534,20 +567,23 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
     }
     c_tau = __shfl(tau, (R - 1) * WN + m);
     // which layers of this step are still above the cut
-    const unsigned long long over = __ballot(inrange && active && tau > p.toomuch);
+    const unsigned long long over = __ballot(inrange && active && tau > thr_l);
     const bool live = inrange && active && (over & below_bits) == 0ull;
     // Planck term and transmittances of this lane's layer
     const double tcl = fmin(tau, tcap);
     double xs[AE + 1], ex[AE + 1];
     xs[AE] = fmin(cf[1] * nu, 700.0);
 #pragma unroll
-    for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
+    for (int a = 0; a < AE; a++) xs[a] = -tcl * (RAYS ? invmu_l : p.invmu[a]);
     exp_rt_n<AE + 1>(xs, ex);
     const double B = bnum * rcp_n1(ex[AE] - 1.0);
-    double E[A];
+    double E[AL];
 #pragma unroll
     for (int a = 0; a < AE; a++) E[a] = ex[a];
-    if (SQ) E[A - 1] = E[0] * E[0];
+    if (SQ) E[AL - 1] = E[0] * E[0];
+    // the angle quadratures of this lane: all rays, or (RAYS) its one ray with the ray's weight
+    auto gsum = [&]() { if constexpr (RAYS) return wgt_l * E[0]; else return angle_sum<AL>(p, E); };
+    auto qsum = [&]() { if constexpr (RAYS) return wq_l * E[0]; else return angle_sum_q<AL>(p, E); };
     if constexpr (INTEG == kIntegTransmittance) {
       // the layer above: row q - 1, or the carry for row 0
       const double B_below = __shfl(B, from_below);
@@ -556,18 +592,18 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       const double hb = (Bprev + B) * (live ? 0.5 : 0.0);
       // rule 0 is linear in the transmittances: the angle quadrature first (ColumnFlux,
       // integ.hpp), so ONE value crosses the lane rows instead of one per ray angle
-      const double G = angle_sum<A>(p, E);
+      const double G = gsum();
       const double G_below = __shfl(G, from_below);
       const double Gprev = q == 0 ? c_G : G_below;
       c_G = G_below;
       I = fma(hb, Gprev - G, I);
-      if (deck_on && j == kend && live && !(tau > p.toomuch)) Fs = fma(B, G, Fs);  // deck reached below toomuch
+      if (deck_on && j == kend && live && !(tau > thr_l)) Fs = fma(B, G, Fs);  // deck reached below toomuch
     } else {
       // rules 1 / 2 are linear in Y = B sum_a (w_a / mu_a) E_a with angle-independent
       // weights (integ.hpp): ONE integrand per layer crosses the lane rows
       const double tau_b1 = __shfl(tau, from_below);
       const double tau1 = q == 0 ? tau_above_step : tau_b1;
-      const double y = B * angle_sum_q<A>(p, E);
+      const double y = B * qsum();
       const double yb = __shfl(y, from_below);
       const double y1 = q == 0 ? c_y : yb;
       c_y = yb;
@@ -589,7 +625,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
         const bool pad = j < L && ((cut_here && q == f + 1) || (pad_next && q == 0));
         if (cut_here) nend = R * s + f + ((R * s + f + 1 < L) ? 1 : 0);
         pad_next = cut_here && f == R - 1;
-        const double x = pad ? tau1 + 1.0 : tau;
+        const double x = pad ? tau1 + padw_l : tau;
         double w0, w1, w2;
         simpson_tau_weights(tau1 - tau2, x - tau1, w0, w1, w2);
         if (j == 1) { w0 = 0.0; w1 = 0.5 * (x - tau1); w2 = w1; }  // the first interval: a trapezoid
@@ -597,8 +633,8 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
         const double cterm = fma(w0, y2, fma(w1, y1, w2 * (pad ? 0.0 : y)));
         I += counts ? cterm : 0.0;
       }
-      if (deck_on && j == kend && live && !(tau > p.toomuch))   // deck reached below toomuch
-        Fs = fma(B, angle_sum<A>(p, E), Fs);
+      if (deck_on && j == kend && live && !(tau > thr_l))   // deck reached below toomuch
+        Fs = fma(B, gsum(), Fs);
     }
     active = active && (over & col_bits) == 0ull;
   };
@@ -622,7 +658,13 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   const bool mine_counts = !SIMPSON || ((q & 1) == (nend & 1));
   double F = Fs + (mine_counts ? I : 0.0);   // the lane's layers, angle quadrature already taken
   for (int o = WN; o < 64; o <<= 1) F += __shfl_xor(F, o);
-  if (q == 0 && i0 + m < W) p.spec[(size_t)w * W + i0 + m] = F;
+  if constexpr (RAYS) {   // the rays of a wavenumber: columns mw A .. mw A + A - 1 of row 0, in ray order
+    double Ft = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; a++) Ft += __shfl(F, (mw * A + a) & 63);
+    F = Ft;
+  }
+  if (q == 0 && ray == 0 && col_on && i0 + mw < W) p.spec[(size_t)w * W + i0 + mw] = F;
   if (p.walked_out && lane == 0) {
     const int layers = R * (s + 1) < kend + 1 ? R * (s + 1) : kend + 1;
     p.walked_out[(size_t)w * (4 * p.ntiles) + tile * 4 + (threadIdx.x >> 6)] = layers;
@@ -709,7 +751,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     return false;
   }
   if (!(!a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
-  if (a.cut_slant && (INTEG == kIntegTrapzTau || !a.slog)) return false;   // (rule 2 with the slant cut: generic kernel)
+  if (a.cut_slant && (!a.slog || (INTEG == kIntegTrapzTau && a.A != 5))) return false;   // (rule 2 on other ray grids: generic kernel)
   if (a.A != 5) {
     // other ray-grid sizes: the single-wave kernel of rule 0 / rule 1 at every batch size
     if (INTEG == kIntegTrapzTau || a.A < 1 || a.A > 9 || kmode == "quad" || kmode == "octo" || kmode == "split") return false;
@@ -763,7 +805,23 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   constexpr bool SQOK = true;   // exp(-2 tau / mu) = exp(-tau / mu)^2 under every rule
   constexpr long quad_max = INTEG == kIntegSimpson ? kQuadMaxColumnsSimpson : kQuadMaxColumns;
   if (a.cut_slant) {
-    // the per-ray cut lives in the single-wave kernels (each ray its own sums): every batch size
+    // the per-ray cut: launches that leave the chip mostly idle take the layer-parallel walk with ONE RAY PER LANE
+    // (rt_eclipse_quad<..., RAYS>: three wavenumbers x five rays x four layers per wave and step) ...
+    if ((kmode == "quad" || (kmode.empty() && columns <= kQuadRaysMaxColumns)) && fits32) {
+      b.ntiles = (a.W + 11) / 12;          // a workgroup: four waves of three wavenumbers
+      const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
+      const size_t shq = sh + shp;
+      if (info) { info->kernel = "rt_eclipse_quad<R=4, one ray per lane>"; info->wn_per_column = 3; info->ncolumns = 4 * b.ntiles; }
+#define BARTRT_QUADRAYS(MM, CC)                                                                                   \
+  if (a.M == MM && a.C == CC) {                                                                                   \
+    BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG, true>), dim3(nbq), dim3(256), shq, st, b);      \
+    err = hipGetLastError();                                                                                      \
+    return true;                                                                                                  \
+  }
+      BARTRT_MC_LIST(BARTRT_QUADRAYS)
+#undef BARTRT_QUADRAYS
+    }
+    // ... everything else the single-wave kernels (each ray its own sums in one lane)
     b.ntiles = a.ntiles;
     if (info) {
       info->kernel = INTEG == kIntegSimpson ? "rt_eclipse_simpson_slant (ILP-scheduled build)" : "rt_eclipse_fast<SLANT> (ILP-scheduled build)";

@@ -2,22 +2,24 @@
 // DESIGN.md C19) for the usual five-angle ray grid, compiled under the compiler's maximum-ILP
 // scheduling strategy (bart_amd/build.py): rule 1's own kernel (rt_eclipse_simpson_slant,
 // rt_eclipse_s1s.hpp), rule 0's (rt_eclipse_fast<..., SLANT = true> with ColumnFluxSlant, integ.hpp),
-// and both with the line-by-line extinction array as input.  Rule 2 with the slant cut runs the
-// generic kernel.
+// rule 2's (the same kernel with rule 2's masked accumulator), and rules 0 / 1 with the line-by-line extinction
+// array as input.
 #include "rt_eclipse.hpp"
 
 namespace bartrt {
 
 bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
-  if (integ != kIntegSimpson && integ != kIntegTransmittance) return false;
 #define BARTRT_SLANT(MM, CC)                                                                                              \
   if (b.M == MM && b.C == CC) {                                                                                           \
     if (integ == kIntegSimpson) {                                                                                         \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, true, 1>), dim3(nblocks), dim3(block), sh, st, b);    \
       else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, 1>), dim3(nblocks), dim3(block), sh, st, b);      \
-    } else {                                                                                                              \
+    } else if (integ == kIntegTransmittance) {                                                                            \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, true, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);  \
       else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);    \
+    } else {                                                                                                              \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, true, 2, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);  \
+      else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, 2, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);    \
     }                                                                                                                     \
     err = hipGetLastError();                                                                                              \
     return true;                                                                                                          \

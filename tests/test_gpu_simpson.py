@@ -40,7 +40,8 @@ def check(cfg, profs, what, clouds=(None,)):
         o = orc.OracleEngine(cfg, integ=INTEG, cut=CUT)
         if CUT == "slant":          # the per-ray cut runs its own single-wave kernels, not the generic one
             engine.walked_begin(); engine.run_batch(profs); kname = engine.walked_end()[2]
-            assert "slant" in kname.lower() or "SLANT" in kname, kname
+            assert "slant" in kname.lower() or "one ray per lane" in kname, kname
+            assert ("one ray per lane" in kname) == (os.environ.get("BARTRT_KERNEL") == "quad"), kname
         for ct in clouds:
             if ct is not None:
                 trm.set_cloudtop(float(ct)); o.set_cloudtop(float(ct))
@@ -93,12 +94,15 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("cut,integ", [("vertical", 1), ("slant", 1), ("slant", 0)])
+@pytest.mark.parametrize("cut,integ,kernel", [("vertical", 1, "mono_ilp"), ("slant", 1, "mono_ilp"), ("slant", 0, "mono_ilp"),
+                                              ("slant", 2, "mono_ilp"), ("slant", 1, "quad"), ("slant", 0, "quad"),
+                                              ("slant", 2, "quad")])
 @pytest.mark.parametrize("mode", ["lengths", "cuts", "zero"])
-def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ):
+def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ, kernel):
     """(cut slant: the same sweeps through rt_eclipse_simpson_slant / rt_eclipse_fast<SLANT>, where every ray
-    angle ends on its own layer -- the deaths, pads and decks of five rays land on every block position.)"""
-    env = dict(os.environ, BARTRT_KERNEL="mono_ilp")
+    angle ends on its own layer -- the deaths, pads and decks of five rays land on every block position -- and,
+    kernel = quad, through the layer-parallel walk with one ray per lane, rt_eclipse_quad<..., RAYS>.)"""
+    env = dict(os.environ, BARTRT_KERNEL=kernel)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, mode, str(tmp_path), cut, str(integ)],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]

@@ -50,6 +50,12 @@ constexpr long kQuadMaxColumns = 640, kQuadMaxColumnsSimpson = 480;
 // extinction five times over, so on the 1e4-sample grid ONE walker already takes what the single-wave kernel takes
 // (63 against 58 us, +35 us per further walker)
 constexpr long kQuadRaysMaxColumns = 80;
+// `cut slant`, rule 1: a team of three waves per column (rt_eclipse_s1t.hpp) for ONE walker's worth of columns at
+// W = 1e4 -- 44 against the single-wave kernel's 58 us; from two walkers on the team loses (59 / 59, four walkers 76 /
+// 61, ten 135 / 98, 64: 639 / 429 us): its producer wave keeps its table loads one layer ahead only (the 128
+// registers that five teams per CU allow), the Planck term and the panel weights are computed twice, and three
+// waves meet at a barrier every six layers
+constexpr long kTeamMaxColumns = 160;
 constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this
 constexpr long kSplitMinColumns = 1025, kSplitMaxColumns = 1300;
 constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
@@ -674,6 +680,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 }  // namespace bartrt
 #include "rt_eclipse_s1.hpp"   // rule 1's single-wave kernel
 #include "rt_eclipse_s1s.hpp"  // ... with the `toomuch` cut on each ray's slant depth
+#include "rt_eclipse_s1t.hpp"  // ... as a team of three waves per column
 namespace bartrt {
 
 // If one ray angle has exactly half the cosine of another (0 and 60 degrees of
@@ -820,6 +827,13 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
       BARTRT_MC_LIST(BARTRT_QUADRAYS)
 #undef BARTRT_QUADRAYS
+    }
+    // ... a team of three waves per column (rule 1) while single-wave columns would load the SIMDs unevenly ...
+    if (INTEG == kIntegSimpson && (kmode == "team" || (kmode.empty() && columns <= kTeamMaxColumns))) {
+      b.ntiles = ntiles64;
+      const size_t sht = sh + sizeof(double) * team_lds_doubles() + shp;
+      if (info) { info->kernel = "rt_eclipse_slant_team (three waves per column)"; info->wn_per_column = 64; info->ncolumns = b.ntiles; }
+      if (launch_rt_slant_team(b, sq, nb64 + pslots, sht, st, err)) return true;
     }
     // ... everything else the single-wave kernels (each ray its own sums in one lane)
     b.ntiles = a.ntiles;

@@ -194,7 +194,7 @@ def _cia_temps(path):
     return np.array([float(x) for x in lines[lines.index("@TEMPERATURES") + 1].split()])
 
 
-def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
+def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1, spline=False):
     """HBM bytes one RT launch has to move, from the launch's own walkers:
 
     * effective: the SURVEY 8d figure (two T planes x M molecules + two CIA planes per
@@ -205,7 +205,8 @@ def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
       walkers of a launch share table planes, and whichever implementation is used
       has to fetch a row from HBM only once per launch: this is the compulsory
       traffic the HBM roofline fraction is quoted on (+ records in, spectra out).
-    walked[nwalkers][ncols]: layers walked per column of wn_per_col wavenumbers."""
+    walked[nwalkers][ncols]: layers walked per column of wn_per_col wavenumbers.
+    spline: `cia_interp spline` -- every CIA file is two table slots (values and second derivatives in T)."""
     nw, ncols = walked.shape
     L = len(case.press_bar)
     M = len(case.opmol)
@@ -218,6 +219,7 @@ def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
           for t in cia_t]
     width = np.minimum(wn_per_col, nwave - wn_per_col * np.arange(ncols)).clip(min=0)
     k = np.arange(L)
+    nsl = 2 if spline else 1
     eff = uniq = 0.0
     walked_lw = 0.0
     for c in range(ncols):
@@ -225,7 +227,7 @@ def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
             continue
         act = walked[:, c][:, None] > k[None, :]            # [walker][layer]
         walked_lw += act.sum() * width[c]
-        eff += act.sum() * width[c] * (2 * M + 2 * len(cia_t)) * 8.0
+        eff += act.sum() * width[c] * (2 * M + 2 * nsl * len(cia_t)) * 8.0
         used = np.zeros((L, len(tg) + 1), bool)
         for w in range(nw):
             used[k[act[w]], j[w][act[w]]] = True
@@ -237,8 +239,8 @@ def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1):
                 usedc[k[act[w]], jj[w][act[w]]] = True
                 usedc[k[act[w]], jj[w][act[w]] + 1] = True
             # (the same CIA plane serves every layer that brackets it: count planes, not (layer, plane))
-            uniq += usedc.any(axis=0).sum() * width[c] * 8.0
-    NC, NI = 4 + 2 * M + 2 * len(cia_t), 1 + len(cia_t)      # words of a layer record (csrc/kernels.hpp)
+            uniq += nsl * usedc.any(axis=0).sum() * width[c] * 8.0
+    NC, NI = 4 + 2 * M + 2 * nsl * len(cia_t), 1 + nsl * len(cia_t)      # words of a layer record (csrc/kernels.hpp)
     fixed = nw * L * (NC + NI) * 8.0 + nw * nwave * 8.0 + nwave * 8.0   # records, spectra out, wavenumbers
     return {"effective_bytes": eff + fixed, "unique_bytes": uniq + fixed,
             "layers_walked_frac": walked_lw / (nw * L * float(nwave)),
@@ -353,6 +355,10 @@ def main():
                          "baseline).  The default sharded run also times a replicas pass for comparison")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-gather path even on one rank (smoke check of the N>1 code)")
+    ap.add_argument("--force-replicas-leg", action="store_true",
+                    help="run the N > 1 line's replicas comparison -- free the engine, initialise it unsharded, time, free, "
+                         "initialise the shard again, all under the live process group -- whatever the rank count "
+                         "(first-run-proofing of the 8-GPU record on one GPU)")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--config", default="table", choices=["table", "lbl"],
                     help="table: the headline opacity-table workload (BASELINE config 3, the contract's line); "
@@ -619,7 +625,7 @@ def main():
             engine.run_batch_dev(d_prof[sset], d_out)
             torch.cuda.synchronize()
             walked, wpc, kname_box[0] = engine.walked_end()
-            models.append(launch_byte_model(case, profs_h[sset], walked, wpc, h0 - l0))
+            models.append(launch_byte_model(case, profs_h[sset], walked, wpc, h0 - l0, spline=conv["cia_interp"] == "spline"))
 
     main_run = timed(nwalk, a.steps, a.warmup, True, repeats=a.repeats if extras else 0,
                      before=byte_model_passes if (rank == 0 and not dry) else None)
@@ -646,7 +652,7 @@ def main():
 
     # ---- N > 1, sharded: the same per-GPU work as independent replicas (SURVEY 8e's baseline)
     replicas = None
-    if extras and world > 1 and sharded:
+    if (extras and world > 1 and sharded) or (a.force_replicas_leg and not dry):
         trm.free_memory()
         engine.init(case.tcfg, shard=None, device=local_rank)
         apply_conventions()
@@ -656,7 +662,7 @@ def main():
                     "note": "every rank holds the whole grid and runs its own walkers: no collective; same "
                             "spectra per step as the sharded line", "diag": rr["diag"]}
         trm.free_memory()
-        engine.init(case.tcfg, shard=(rank, world), device=local_rank)
+        engine.init(case.tcfg, shard=(rank, world) if (sharded or a.force_replicas_leg) else None, device=local_rank)
         apply_conventions()
 
     def guarded(name, fn):
@@ -696,7 +702,11 @@ def main():
     elif rank == 0:
         assert ok
         value = nspectra_per_step * a.steps / dt
-        alg = engine.algorithmic_bytes(nwalk)          # SURVEY 8d bytes per RT launch on this GPU
+        # SURVEY 8d's bytes per RT launch on this GPU, to the letter: two T planes x M molecules + two planes of ONE
+        # CIA table per file + profile in + spectrum out (the engine's own count, bartrt_algorithmic_bytes, follows
+        # its table slots: two per file under `cia_interp spline`)
+        alg = nwalk * (2.0 * a.nlayers * (hi - lo) * len(case.opmol) * 8 + 2.0 * a.nlayers * (hi - lo) * len(case.cia) * 8
+                       + (len(case.species) + 1) * a.nlayers * 8 + (hi - lo) * 8)
         per_launch_s = kern_ms / 1e3 / max(nlaunch, 1)
         nsets = profs_all.shape[0]
         kname = kname_box[0]

@@ -40,6 +40,27 @@ def test_gpus2_self_launch_one_json_line():
     assert d["allgather_recv_bytes_per_rank_per_bucket"] == 2 * 4 * 6 * wmax * 8
 
 
+def test_gpus8_uneven_grid_dry_run():
+    """A node's worth of ranks on a grid that does not divide (2 501 samples over 8): the blocks' padding in the
+    bucketed all-gather, the reassembly checked sample for sample inside bench.py, and the keys the first real
+    8-GPU record will be read by (what an N = 8 line should look like)."""
+    r = _bench("--gpus", "8", "--dry-gloo", "--steps", "9", "--warmup", "2", "--walkers", "2",
+               "--nwave", "2501", "--gather-steps", "4", "--sweep", "")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["walkers_per_step"] == 16 and j["scaling"] == "weak"
+    d = j["scaling_diag"]
+    for key in ("mode", "per_rank_window_s", "rank_skew_ms", "per_rank_rt_kernel_ms", "per_rank_final_drain_ms",
+                "steps_per_bucket", "allgather_send_bytes_per_rank_per_bucket",
+                "allgather_recv_bytes_per_rank_per_bucket", "ms_per_step_minus_rt_kernel"):
+        assert key in d, key
+    assert len(d["per_rank_window_s"]) == 8 and len(d["per_rank_final_drain_ms"]) == 8
+    wmax = max(2501 * (k + 1) // 8 - 2501 * k // 8 for k in range(8))
+    assert wmax == 313 and d["allgather_send_bytes_per_rank_per_bucket"] == 4 * 16 * wmax * 8
+
+
 def test_gpus2_replicas_mode_has_no_collective():
     """--mode replicas: SURVEY 8e's baseline -- every rank the whole grid and its own walkers."""
     r = _bench("--gpus", "2", "--dry-gloo", "--mode", "replicas", "--steps", "5", "--warmup", "1", "--walkers", "3",

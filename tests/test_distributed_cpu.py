@@ -8,6 +8,8 @@ reassembles [nwalkers, W] on every rank, and max-over-ranks timing."""
 import os
 import socket
 import subprocess
+
+import pytest
 import sys
 import textwrap
 
@@ -106,41 +108,56 @@ SHARDED_WORKER = textwrap.dedent('''
     from multiprocessing.connection import Listener, Client
     from bart_amd import BARTfunc, engine
 
-    rank, world, W, NF = int(sys.argv[1]), 2, 1001, 3
+    rank, world, W, NF = int(sys.argv[1]), int(sys.argv[2]), 1001, 3
     addr = ("127.0.0.1", %(gport)d)
 
     class SockGroup:
-        """The workers' own communicator (their MPI.COMM_WORLD) for two processes:
-        the mpi4py calls BARTfunc.main makes, over one socket."""
+        """The workers' own communicator (their MPI.COMM_WORLD): the mpi4py calls BARTfunc.main
+        makes, over sockets -- rank 0 in the middle, every collective rooted there."""
         def __init__(self):
             if rank == 0:
-                self.l = Listener(addr); self.c = self.l.accept()
+                self.l = Listener(addr); self.c = {}
+                for _ in range(world - 1):
+                    c = self.l.accept(); self.c[c.recv()] = c
             else:
                 import time
-                for _ in range(200):
+                for _ in range(400):
                     try:
-                        self.c = Client(addr); break
+                        self.c0 = Client(addr); break
                     except OSError:
                         time.sleep(0.05)
+                self.c0.send(rank)
             self.log = []
         def Get_size(self): return world
         def Get_rank(self): return rank
         def Bcast(self, a, root=0):
+            assert root == 0
             self.log.append("bcast")
-            if rank == root: self.c.send(np.array(a))
-            else: a[...] = self.c.recv()
+            if rank == 0:
+                for c in self.c.values(): c.send(np.array(a))
+            else: a[...] = self.c0.recv()
         def Allgather(self, send, recv):
             self.log.append("allgather")
-            self.c.send(np.array(send)); other = self.c.recv()
-            recv[rank] = send; recv[1 - rank] = other
+            if rank == 0:
+                recv[0] = send
+                for r, c in self.c.items(): recv[r] = c.recv()
+                for c in self.c.values(): c.send(np.array(recv))
+            else:
+                self.c0.send(np.array(send)); recv[...] = self.c0.recv()
         def Gather(self, send, recv, root=0):
+            assert root == 0
             self.log.append("gather")
-            if rank == root: recv[rank] = send; recv[1 - rank] = self.c.recv()
-            else: self.c.send(np.array(send))
+            if rank == 0:
+                recv[0] = send
+                for r, c in self.c.items(): recv[r] = c.recv()
+            else: self.c0.send(np.array(send))
         def Scatter(self, send, recv, root=0):
+            assert root == 0
             self.log.append("scatter")
-            if rank == root: recv[...] = send[rank]; self.c.send(np.array(send[1 - rank]))
-            else: recv[...] = self.c.recv()
+            if rank == 0:
+                recv[...] = send[0]
+                for r, c in self.c.items(): c.send(np.array(send[r]))
+            else: recv[...] = self.c0.recv()
 
     class FakeIntercomm:
         """MC3's side of the protocol for this worker (code/BARTfunc.py:129-132,
@@ -185,14 +202,14 @@ SHARDED_WORKER = textwrap.dedent('''
     mine = [rng.normal(size=4) for _ in range(5)]               # this worker's chain
     lone = FakeIntercomm(mine)
     BARTfunc.main(lone, ["-c", %(cfg)r], worker_factory=StubWorker)   # reference: a lone worker
-    os.environ["BARTRT_GPUS"] = "2"
+    os.environ["BARTRT_GPUS"] = str(world)
     os.environ["BARTRT_PORT"] = "%(tport)d"
     comm, group = FakeIntercomm(mine), SockGroup()
     made = []
     def factory(cfg, shard=None, device=None, group=None):
         made.append(StubWorker(cfg, shard, device, group)); return made[-1]
     BARTfunc.main(comm, ["-c", %(cfg)r], group=group, worker_factory=factory, shard_backend="gloo")
-    assert comm.done and len(comm.received) == 5 and made[0].shard == (rank, 2) and made[0].calls == 5
+    assert comm.done and len(comm.received) == 5 and made[0].shard == (rank, world) and made[0].calls == 5
     assert made[0].group is not None
     for got, want in zip(comm.received, lone.received):
         assert got.shape == (NF,) and np.allclose(got, want, rtol=1e-13, atol=0), (got, want)
@@ -204,10 +221,11 @@ SHARDED_WORKER = textwrap.dedent('''
 ''')
 
 
-def test_mc3_driven_sharded_worker(tmp_path):
-    """BARTfunc.main under BARTRT_GPUS=2, two worker processes as
-    MC3 spawns them, gloo in place of RCCL and a stand-in for the GPU worker that
-    returns its wavenumber block of a known spectrum: the port broadcast and
+@pytest.mark.parametrize("world", [2, 8])
+def test_mc3_driven_sharded_worker(tmp_path, world):
+    """BARTfunc.main under BARTRT_GPUS=G (G = 8 is a node's worth, the 1 001-sample grid then
+    splits unevenly), G worker processes as MC3 spawns them, gloo in place of RCCL and a stand-in for the GPU
+    worker that returns its wavenumber block of a known spectrum: the port broadcast and
     process-group bring-up, the per-step Allgather of the chains' parameters, the
     all-gather that reassembles the spectra on every shard owner, the Scatter of the
     band fluxes -- each master-side communicator receives what a lone worker sends
@@ -215,11 +233,11 @@ def test_mc3_driven_sharded_worker(tmp_path):
     cfg = tmp_path / "BART.cfg"
     cfg.write_text("[MCMC]\ntconfig = transit.cfg\nparams = 0 0 0 0\n")
     args = {"root": ROOT, "gport": _free_port(), "tport": _free_port(), "cfg": str(cfg)}
-    procs = [subprocess.Popen([sys.executable, "-c", SHARDED_WORKER % args, str(r)],
+    procs = [subprocess.Popen([sys.executable, "-c", SHARDED_WORKER % args, str(r), str(world)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               env={k: v for k, v in os.environ.items() if k not in ("BARTRT_GPUS", "RANK", "WORLD_SIZE")})
-             for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+             for r in range(world)]
+    outs = [p.communicate(timeout=400)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o

@@ -32,11 +32,11 @@ def _env():
 
 def test_bench_collective_path_under_torchrun_world1(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --force-collective`: the
-    driver's N > 1 launch shape with one rank.  One JSON line, finite spectra (bench.py asserts
-    it), the N > 1 diagnostics present."""
+    driver's N > 1 launch shape with one rank.  One JSON line, its spectra held to the oracle by the line's
+    own `parity` record, the N > 1 diagnostics present, the replicas comparison included."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--force-collective", "--steps", "8", "--warmup", "2",
+           os.path.join(ROOT, "bench.py"), "--force-collective", "--force-replicas-leg", "--steps", "8", "--warmup", "2",
            "--no-extras", "--no-cpu", "--nwave", "2501", "--workdir", str(tmp_path / "w")]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
@@ -47,6 +47,10 @@ def test_bench_collective_path_under_torchrun_world1(tmp_path):
     d = j["scaling_diag"]
     assert d["mode"] == "shard" and d["steps_per_bucket"] == 4 and len(d["per_rank_rt_kernel_ms"]) == 1
     assert d["allgather_send_bytes_per_rank_per_bucket"] == 4 * 10 * 2501 * 8
+    # the line certifies its own (gathered) spectra against the oracle, and the replicas comparison of the N > 1
+    # line ran: the engine freed and initialised twice more under the live process group
+    assert j["parity"]["ok"] and j["parity"]["max_rel_err"] < 1e-9 and j["parity"]["bit_equal_to_plain_launch"]
+    assert j["replicas"]["value"] > 0 and j["replicas"]["diag"]["mode"] == "replicas"
 
 
 CHILD = r"""

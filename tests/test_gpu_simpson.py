@@ -42,6 +42,7 @@ def check(cfg, profs, what, clouds=(None,)):
             engine.walked_begin(); engine.run_batch(profs); kname = engine.walked_end()[2]
             assert "slant" in kname.lower() or "one ray per lane" in kname, kname
             assert ("one ray per lane" in kname) == (os.environ.get("BARTRT_KERNEL") == "quad"), kname
+            assert ("team" in kname) == (os.environ.get("BARTRT_KERNEL") == "team"), kname
         for ct in clouds:
             if ct is not None:
                 trm.set_cloudtop(float(ct)); o.set_cloudtop(float(ct))
@@ -96,12 +97,13 @@ print("ok")
 
 @pytest.mark.parametrize("cut,integ,kernel", [("vertical", 1, "mono_ilp"), ("slant", 1, "mono_ilp"), ("slant", 0, "mono_ilp"),
                                               ("slant", 2, "mono_ilp"), ("slant", 1, "quad"), ("slant", 0, "quad"),
-                                              ("slant", 2, "quad")])
+                                              ("slant", 2, "quad"), ("slant", 1, "team")])
 @pytest.mark.parametrize("mode", ["lengths", "cuts", "zero"])
 def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ, kernel):
     """(cut slant: the same sweeps through rt_eclipse_simpson_slant / rt_eclipse_fast<SLANT>, where every ray
     angle ends on its own layer -- the deaths, pads and decks of five rays land on every block position -- and,
-    kernel = quad, through the layer-parallel walk with one ray per lane, rt_eclipse_quad<..., RAYS>.)"""
+    kernel = quad, through the layer-parallel walk with one ray per lane, rt_eclipse_quad<..., RAYS>; kernel = team,
+    through the three waves per column of rt_eclipse_slant_team.)"""
     env = dict(os.environ, BARTRT_KERNEL=kernel)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, mode, str(tmp_path), cut, str(integ)],
                          env=env, capture_output=True, text=True, timeout=900)

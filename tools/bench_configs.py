@@ -78,8 +78,8 @@ def kappa_leg(a, wd, conv, kappa, make_profiles, launch_byte_model, peak_hbm):
         engine.run_batch_dev(d_prof[0], out)
         torch.cuda.synchronize()
         walked, wpc, kname = engine.walked_end()
-        m = launch_byte_model(case, profs[0], walked, wpc, a.nwave)
-        alg = engine.algorithmic_bytes(n)
+        m = launch_byte_model(case, profs[0], walked, wpc, a.nwave, spline=conv["cia_interp"] == "spline")
+        alg = n * 80.0856e6 * (a.nlayers / 100.0) * (a.nwave / 1e4)     # SURVEY 8d to the letter (bench.py)
         cuts = {}
         for cut in ("vertical", "slant"):
             trm.set_cut(cut)

@@ -197,6 +197,7 @@ struct RtArgs {
   // ray of that angle survives, i.e. the largest double t with t * invmu[a] <= toomuch (slant_thresholds)
   double mu[kMaxAngles];
   double thr[kMaxAngles];
+  double thrb[kMaxAngles]; // 2^600 * the next double above thr[a] (alive_flags, rt_eclipse_s1s.hpp)
   int drank[kMaxAngles];   // rank of ray a in the order of dying (0 = the smallest thr goes first)
   void *slog;              // `cut slant` event log of the single-wave kernels: slant_log_bytes(...) bytes
   double *spec;            // [nw][W]
@@ -235,6 +236,8 @@ inline void slant_thresholds(RtArgs &r) {
     }
     r.thr[a] = t;
   }
+  for (int a = 0; a < r.A; a++)
+    r.thrb[a] = __builtin_nextafter(r.thr[a], __builtin_inf()) * 4.149515568880993e180;   // 2^600; +inf past 4e127
   for (int a = 0; a < r.A; a++) {
     int rk = 0;
     for (int b = 0; b < r.A; b++) rk += (r.thr[b] < r.thr[a] || (r.thr[b] == r.thr[a] && b < a)) ? 1 : 0;

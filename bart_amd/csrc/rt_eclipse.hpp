@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   double c2_e = 0.0, c2_tau = 0.0, c_y = 0.0, c2_y = 0.0, c_S = 0.0;
   int nend = kend;
   bool pad_next = false;
-  bool active = true;  // no layer above this step passed `toomuch` (per wavenumber, all rows agree)
+  // no layer above this step passed `toomuch` (per column, all rows agree); columns that hold no sample of the grid
+  // (past its end, or the idle columns of RAYS) are dead from the start: they must not keep the wave walking
+  bool active = col_on && i0 + mw < W;
 
   auto step = [&](int s, const double (&rv)[NR]) {
     const int j = R * s + q, jc = clampk(j);
@@ -697,6 +699,7 @@ inline bool order_angles_for_square(RtArgs &r) {
         std::swap(r.mu[x], r.mu[y]);
         std::swap(r.thr[x], r.thr[y]);
         std::swap(r.drank[x], r.drank[y]);
+        std::swap(r.thrb[x], r.thrb[y]);
       };
       swap_angles(0, i);
       if (j == 0) j = i;  // the doubled angle sat in slot 0 and moved to i

@@ -44,6 +44,34 @@
 
 namespace bartrt {
 
+// The rays' alive flags as doubles, m[a] = (tm <= thr[a]) ? 1 : 0, and their sum.  A compare and a select per ray
+// cost four instructions (the select is two dwords); here tm is scaled once by -2^600 and each flag is ONE
+// addition with the result clamped to [0, 1]: RtArgs::thrb[a] = 2^600 * nextafter(thr[a], +inf), so the sum
+// is >= 2^600 ulp(thr) >> 1 while tm <= thr[a] and <= 0 from the next double on -- exactly the comparison, for
+// every threshold above 2^-500 and every optical depth below 2^400.  (A threshold that overflows the scaling is +inf: alive.)
+#ifndef BARTRT_FLAG_CLAMP
+#define BARTRT_FLAG_CLAMP 1
+#endif
+template <int A>
+__device__ __forceinline__ double alive_flags(const RtArgs &p, double tm, double (&m)[A]) {
+  double n = 0.0;
+#if BARTRT_FLAG_CLAMP
+  const double tb = tm * -4.149515568880993e180;   // -2^600
+#pragma unroll
+  for (int a = 0; a < A; a++) {
+    asm("v_add_f64 %0, %1, %2 clamp" : "=v"(m[a]) : "v"(tb), "s"(p.thrb[a]));
+    n += m[a];
+  }
+#else
+#pragma unroll
+  for (int a = 0; a < A; a++) {
+    m[a] = tm <= p.thr[a] ? 1.0 : 0.0;
+    n += m[a];
+  }
+#endif
+  return n;
+}
+
 template <int AT, int MT, int CT, bool SQ, int SCHED = 1, bool EXT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
 void rt_eclipse_simpson_slant(RtArgs p) {
@@ -107,21 +135,23 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   for (int a = 0; a < A; a++) { y1[a] = y2[a] = P0[a] = P1[a] = 0.0; }
   // the wave's event log: [slot 0 .. A-1][lane] (tau, interval) pairs, then [slot][lane] layer indices
   // (-1: no event in that slot), addressed through a descriptor of exactly its size
-  const unsigned nth = blockDim.x;
+  const unsigned nth = blockDim.x;                      // 64, 128 or 256
+  const unsigned lsh = (unsigned)__builtin_ctz(nth) + 4u;    // log2 of a slot's bytes in the pair part of the log
   const unsigned log_bytes = nth * (unsigned)A * 20u;
   const auto rs_log = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char *>(p.slog) + ((size_t)w * p.ntiles + tile) * log_bytes, 0, (int)log_bytes, 0x00020000);
   const unsigned log_k0 = nth * (unsigned)A * 16u + threadIdx.x * 4u;   // this lane's index of slot 0
 #pragma unroll
   for (int sl = 0; sl < A; sl++) __builtin_amdgcn_raw_buffer_store_b32(-1, rs_log, (int)(log_k0 + sl * nth * 4u), 0, 0);
-  int nprev = A;             // rays alive when the previous layer began
+  double nprev = (double)A;  // rays alive when the previous layer began (a sum of the 0 / 1 flags)
+  const unsigned tid16 = threadIdx.x * 16u;
   // logs the event "the rays alive dropped from nprev to nnow on layer kev" (tau and interval of that layer
   // are x1 and h0 by now); lanes without one store out of range, which the hardware drops
-  auto log_event = [&](int nnow, int kev) {
+  auto log_event = [&](double nnow, int kev) {
     const bool ev = nnow < nprev;
-    const unsigned slot = (unsigned)(A - nprev);
-    const unsigned off = ev ? slot * nth * 16u + threadIdx.x * 16u : 0x7ffffff0u;
-    const unsigned offk = ev ? log_k0 + slot * nth * 4u : 0x7ffffff0u;
+    const unsigned slot = (unsigned)((double)A - nprev);
+    const unsigned off = ev ? (slot << lsh) + tid16 : 0x7ffffff0u;
+    const unsigned offk = ev ? log_k0 + (slot << (lsh - 2u)) : 0x7ffffff0u;
     v4u_t v;
     v.x = (unsigned)__double2loint(x1); v.y = (unsigned)__double2hiint(x1);
     v.z = (unsigned)__double2loint(h0); v.w = (unsigned)__double2hiint(h0);
@@ -165,13 +195,12 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     // alive flags from the running maximum of tau over the layers above (1.0 / 0.0)
     bool inr = true;                      // wave-uniform: the layer lies inside the column
     if constexpr (MASKED) inr = k <= kend;
+    // (one multiplication and, per ray, one clamped addition: alive_flags)
     double m[A];
-    int nnow = 0;
+    const double nnow = alive_flags<A>(p, tm, m);
+    if constexpr (MASKED) {
 #pragma unroll
-    for (int a = 0; a < A; a++) {
-      const bool al = tm <= p.thr[a];
-      nnow += al ? 1 : 0;
-      m[a] = (inr && al) ? 1.0 : 0.0;
+      for (int a = 0; a < A; a++) m[a] = inr ? m[a] : 0.0;
     }
     if constexpr (!(FIRST && J == 0)) log_event(nnow, k - 1);
     // Planck exponent and the slant-path exponents in one interleaved batch
@@ -283,14 +312,13 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   double F = 0.0;
   {
     // an event on the last layer walked
-    int nnow = 0;
-#pragma unroll
-    for (int a = 0; a < A; a++) nnow += (tm <= p.thr[a]) ? 1 : 0;
+    double mfin[A];
+    const double nnow = alive_flags<A>(p, tm, mfin);
     log_event(nnow, kw - 1);
     const double tauend = x1;   // tau(kend) when the wave reached the column's end (the table's overrun entries)
     double Bend = 0.0;
     if (deck_on) Bend = bnum * rcp_n1(exp_rt(fmin(sC[kend * NC + 1] * nu, 700.0)) - 1.0);
-    const bool anydied = __any(nnow < A);
+    const bool anydied = __any(nnow < (double)A);
     int kev[A];
 #pragma unroll
     for (int sl = 0; sl < A; sl++) kev[sl] = -1;

@@ -6,14 +6,19 @@
 // array as input.
 #include "rt_eclipse.hpp"
 
+// (A/B builds, tools/ab_build.py: the single-wave slant kernel with or without the record read-ahead)
+#ifndef BARTRT_SLANT_SCHED
+#define BARTRT_SLANT_SCHED 1
+#endif
+
 namespace bartrt {
 
 bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
 #define BARTRT_SLANT(MM, CC)                                                                                              \
   if (b.M == MM && b.C == CC) {                                                                                           \
     if (integ == kIntegSimpson) {                                                                                         \
-      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, true, 1>), dim3(nblocks), dim3(block), sh, st, b);    \
-      else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, 1>), dim3(nblocks), dim3(block), sh, st, b);      \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, true, BARTRT_SLANT_SCHED>), dim3(nblocks), dim3(block), sh, st, b);    \
+      else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, BARTRT_SLANT_SCHED>), dim3(nblocks), dim3(block), sh, st, b);      \
     } else if (integ == kIntegTransmittance) {                                                                            \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, true, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);  \
       else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);    \

@@ -22,7 +22,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libbartrt.so")
+# (BARTRT_LIBPATH: another build of the library, for same-box A/B runs of tools/ -- tools/ab_build.py)
+_LIBPATH = os.environ.get("BARTRT_LIBPATH") or os.path.join(_HERE, "libbartrt.so")
 _lib = None
 
 

@@ -67,6 +67,10 @@ if __name__ == "__main__":
             # the workload of tools/profile_round.sh's PMC passes (bench.py defaults)
             "walkers": int(os.environ.get("PMC_WALKERS", 10)), "nwave": 10000, "nlayers": 100,
             "integ": int(os.environ.get("PMC_INTEG", 1)),      # the engine's default rule (bench.py without --integ)
+            # bench.py's defaults since round 4: SURVEY 8d's literal opacities, every step its own prep_profiles,
+            # the engine's default cut and CIA interpolation
+            "kappa": os.environ.get("PMC_KAPPA", "survey8d"), "cut": os.environ.get("PMC_CUT", "slant"),
+            "prefetch": bool(int(os.environ.get("PMC_PREFETCH", 0))),
             "kernel": names[0] if len(names) == 1 else names,
             "calibration_kernel": cal_names[0] if len(cal_names) == 1 else cal_names,
             "launches_averaged": n,

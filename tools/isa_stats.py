@@ -23,6 +23,9 @@ def main():
     m = re.search(r"Lb[01]ELi(\d)E", want)
     integ = "1" if "simpson" in want else (m.group(1) if m else "0")   # rule 1's single-wave kernel has its own name
     src = "rt_eclipse_i%s_ilp.hip" % integ if ilp else "rt_eclipse_i%s.hip" % integ
+    nlay = 4            # layers per straight-line block of the kernel
+    if "simpson_slant" in want:   # the `cut slant` kernel of rule 1: its own translation unit, six-layer blocks
+        src, ilp, nlay = "rt_eclipse_slant_ilp.hip", True, 6
     extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ilp else []
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
@@ -68,10 +71,10 @@ def main():
         else:
             cls[m] += 1
     print("kernel:", name)
-    print("instructions in the kernel: %d; layer loop body (four layers): %d = %.1f per layer"
-          % (sum(len(b) for b in blocks), len(big), len(big) / 4))
+    print("instructions in the kernel: %d; layer loop body (%d layers): %d = %.1f per layer"
+          % (sum(len(b) for b in blocks), nlay, len(big), len(big) / nlay))
     for k, v in cls.most_common():
-        print("  %-12s %4d  %6.1f per layer" % (k, v, v / 4))
+        print("  %-12s %4d  %6.1f per layer" % (k, v, v / nlay))
     print("by mnemonic:")
     for k, v in collections.Counter(big).most_common():
         print("  %-26s %4d" % (k, v))
@@ -85,10 +88,11 @@ def main():
         out = sys.argv[sys.argv.index("--json") + 1]
         fma = sum(1 for m in big if m.startswith(("v_fma_f64", "v_fmac_f64")))
         oth = sum(1 for m in big if m.startswith(FP64)) - fma
-        json.dump({"kernel": name, "kernel_family": "rt_eclipse_simpson" if "simpson" in name else "rt_eclipse_fast",
+        fam = "rt_eclipse_simpson_slant" if "simpson_slant" in name else ("rt_eclipse_simpson" if "simpson" in name else "rt_eclipse_fast")
+        json.dump({"kernel": name, "kernel_family": fam,
                    "source_id": bench.source_id(),
-                   "fp64_fma_per_layer": fma / 4, "fp64_other_per_layer": oth / 4,
-                   "instructions_per_layer": len(big) / 4, "file": os.path.basename(out)},
+                   "fp64_fma_per_layer": fma / nlay, "fp64_other_per_layer": oth / nlay,
+                   "instructions_per_layer": len(big) / nlay, "file": os.path.basename(out)},
                   open(out, "w"), indent=1)
 
 

@@ -473,7 +473,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   pa.iH2 = iH2; pa.iHe = iHe;
 
   RtArgs &r = rt;
-  r.L = L; r.M = M; r.Nt = Nt; r.C = C; r.A = A; r.W = Wl;
+  r.L = L; r.M = M; r.Nt = Nt; r.C = C; r.A = A; r.W = Wl; r.Wfull = Wfull;
   r.kappa = d_kappa; r.cia = d_cia; r.wn = d_wn;
   r.kappa_bytes = (unsigned long long)L * Nt * M * Wl * 8ull;
   r.cia_bytes = (unsigned long long)cia_planes.size() * 8ull;
@@ -717,8 +717,8 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   }
   r.walked_out = nullptr;
   if (want_walked && solution == 0 && !lbl_fused) {
-    // the finest column any eclipse kernel records is 3 wavenumbers wide (rt_eclipse_quad with one ray per lane)
-    const size_t need = (size_t)n * ((size_t)(r.W + 2) / 3 + 64);
+    // the finest column any eclipse kernel records is ONE wavenumber wide (rt_eclipse_quad with one ray per lane, R = 8)
+    const size_t need = (size_t)n * ((size_t)r.W + 64);
     if (need > walked_cap) {
       if (d_walked) HIPCHK(hipFree(d_walked));
       d_walked = nullptr;

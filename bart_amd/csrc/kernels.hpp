@@ -177,6 +177,9 @@ struct PrepArgs {
 
 struct RtArgs {
   int L, M, Nt, C, A, W, nwalkers, ntiles;
+  int Wfull;               // samples of the whole grid (W: this process's block of it): the kernel variant is chosen by
+                           // the batch on the WHOLE grid, so that a sharded run adds the same numbers in the same order
+                           // as the unsharded one (blocks concatenate bit for bit)
   const double *kappa;     // [L][Nt][W][M]: a wavenumber's molecules contiguous (TableLoader)
   const double *cia;       // [pair planes][W][2]
   unsigned long long kappa_bytes, cia_bytes;  // extents of the two tables

@@ -50,6 +50,7 @@ constexpr long kQuadMaxColumns = 640, kQuadMaxColumnsSimpson = 480;
 // extinction five times over, so on the 1e4-sample grid ONE walker already takes what the single-wave kernel takes
 // (63 against 58 us, +35 us per further walker)
 constexpr long kQuadRaysMaxColumns = 80;
+constexpr long kOctoRaysMaxColumns = 40;    // ... with eight layers per step (one wavenumber x five rays per wave) below this
 // `cut slant`, rule 1: a team of three waves per column (rt_eclipse_s1t.hpp) for ONE walker's worth of columns at
 // W = 1e4 -- 44 against the single-wave kernel's 58 us; from two walkers on the team loses (59 / 59, four walkers 76 /
 // 61, ten 135 / 98, 64: 639 / 429 us): its producer wave keeps its table loads one layer ahead only (the 128
@@ -649,19 +650,27 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 
   // rule 1 may need the row after the column's last layer for the padded point
   const int klast = SIMPSON ? (kend + 1 < L ? kend + 1 : L - 1) : kend;
-  double ra[NR], rb[NR];
-  load_layer(clampk(q), ra);
+  // Loads in flight ahead of the step that uses them: two steps' worth.  (Four, for the eight-row form that serves
+  // the smallest launches, was measured in round 4 and changes nothing there -- one walker on the demo grid 25.4
+  // against 24.3 us: those launches are bound by the steps' own dependent arithmetic and cross-row traffic, not by
+  // memory round trips -- and costs the two-walker launch on the bench grid its occupancy, 42.7 against 34.7 us.)
+  constexpr int NBUF = 2;
+  double rbuf[NBUF][NR];
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; b++) load_layer(clampk(R * b + q), rbuf[b]);
   int s = 0;
-  for (; R * s <= klast; s += 2) {
-    load_layer(clampk(R * (s + 1) + q), rb);
-    step(s, ra);
-    if (!__any(active || pad_next)) break;
-    load_layer(clampk(R * (s + 2) + q), ra);
-    if (R * (s + 1) <= klast) {
-      step(s + 1, rb);
-      if (!__any(active || pad_next)) { s++; break; }
+  bool gone = false;
+  for (; R * s <= klast && !gone; s += NBUF) {
+#pragma unroll
+    for (int b = 0; b < NBUF; b++) {
+      if (!gone && R * (s + b) <= klast) {
+        load_layer(clampk(R * (s + b + NBUF - 1) + q), rbuf[(b + NBUF - 1) % NBUF]);
+        step(s + b, rbuf[b]);
+        if (!__any(active || pad_next)) { gone = true; s += b - NBUF; }   // (s: the last step walked, after the loop's increment)
+      }
     }
   }
+  if (!gone) s -= 1;   // the loop ran out: the last step walked is the one before s (clamped by the record below)
   // the rows of a wavenumber hold its layers' terms: sum them; row 0 writes
   const bool mine_counts = !SIMPSON || ((q & 1) == (nend & 1));
   double F = Fs + (mine_counts ? I : 0.0);   // the lane's layers, angle quadrature already taken
@@ -722,6 +731,7 @@ bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t
 // the `cut slant` kernels of rules 0 / 1 for five angles (rt_eclipse_slant_ilp.hip), table and line-by-line input
 bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+bool launch_rt_slant_out(const RtArgs &b, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
 // ... and for ray grids of 1 .. 9 angles other than five (rt_eclipse_angles.hip, one object per size)
 #define BARTRT_ANGLE_SIZES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(9)
@@ -759,6 +769,13 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
                                : launch_rt_fast_ext(b, sq, block, nblocks, sh, st, err))
       return true;
     return false;
+  }
+  if ((a.intens_out || a.tau_out) && a.cut_slant && INTEG == kIntegSimpson && a.A == 5 && a.slog && a.nwalkers == 1 &&
+      a.nprep == 0 && plane_ok && sh <= 55 * 1024 && kmode.empty()) {
+    // tau.dat / outintens of the default conventions: the single-wave slant kernel writes them on its way
+    if (info) { info->kernel = "rt_eclipse_simpson_slant (with optical-depth / intensity outputs)"; info->wn_per_column = block; info->ncolumns = a.ntiles; info->prep_fused = false; }
+    err = hipSuccess;
+    if (launch_rt_slant_out(a, block, nblocks, sh, st, err)) return true;
   }
   if (!(!a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
   if (a.cut_slant && (!a.slog || (INTEG == kIntegTrapzTau && a.A != 5))) return false;   // (rule 2 on other ray grids: generic kernel)
@@ -803,7 +820,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   // too few single-wave columns to load the 1 024 SIMDs evenly -> several
   // waves per 64 wavenumbers: four 16-wavenumber waves that take four layers at
   // a time (quad-layer), or a producer / consumer pair
-  const long columns = (long)a.nwalkers * ((a.W + 63) / 64);
+  const long columns = (long)a.nwalkers * (((a.Wfull > 0 ? a.Wfull : a.W) + 63) / 64);   // (of the whole grid: RtArgs::Wfull)
   const int ntiles64 = (a.W + 63) / 64;
   const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
   // the quad-layer kernel addresses the tables with per-lane 32-bit offsets
@@ -817,19 +834,28 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   if (a.cut_slant) {
     // the per-ray cut: launches that leave the chip mostly idle take the layer-parallel walk with ONE RAY PER LANE
     // (rt_eclipse_quad<..., RAYS>: three wavenumbers x five rays x four layers per wave and step) ...
-    if ((kmode == "quad" || (kmode.empty() && columns <= kQuadRaysMaxColumns)) && fits32) {
-      b.ntiles = (a.W + 11) / 12;          // a workgroup: four waves of three wavenumbers
-      const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
-      const size_t shq = sh + shp;
-      if (info) { info->kernel = "rt_eclipse_quad<R=4, one ray per lane>"; info->wn_per_column = 3; info->ncolumns = 4 * b.ntiles; }
-#define BARTRT_QUADRAYS(MM, CC)                                                                                   \
-  if (a.M == MM && a.C == CC) {                                                                                   \
-    BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG, true>), dim3(nbq), dim3(256), shq, st, b);      \
-    err = hipGetLastError();                                                                                      \
-    return true;                                                                                                  \
+    if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadRaysMaxColumns)) && fits32) {
+      // (the smallest launches -- one walker on the demo shape -- eight layers per step: one wavenumber x five rays per wave)
+      const bool octor = kmode == "octo" || (kmode.empty() && columns <= kOctoRaysMaxColumns);
+      const bool win_ok = !b.window || window_fits(a, octor ? 8 : 4);
+      if (win_ok) {
+        b.ntiles = octor ? (a.W + 3) / 4 : (a.W + 11) / 12;          // a workgroup: four waves of one / three wavenumbers
+        const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
+        const size_t shq = sh + shp;
+        if (info) {
+          info->kernel = octor ? "rt_eclipse_quad<R=8, one ray per lane>" : "rt_eclipse_quad<R=4, one ray per lane>";
+          info->wn_per_column = octor ? 1 : 3; info->ncolumns = 4 * b.ntiles;
+        }
+#define BARTRT_QUADRAYS(MM, CC)                                                                                          \
+  if (a.M == MM && a.C == CC) {                                                                                          \
+    if (octor) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 8, INTEG, true>), dim3(nbq), dim3(256), shq, st, b);  \
+    else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG, true>), dim3(nbq), dim3(256), shq, st, b);        \
+    err = hipGetLastError();                                                                                             \
+    return true;                                                                                                         \
   }
-      BARTRT_MC_LIST(BARTRT_QUADRAYS)
+        BARTRT_MC_LIST(BARTRT_QUADRAYS)
 #undef BARTRT_QUADRAYS
+      }
     }
     // ... a team of three waves per column (rule 1) while single-wave columns would load the SIMDs unevenly ...
     if (INTEG == kIntegSimpson && (kmode == "team" || (kmode.empty() && columns <= kTeamMaxColumns))) {

@@ -72,8 +72,14 @@ __device__ __forceinline__ double alive_flags(const RtArgs &p, double tm, double
   return n;
 }
 
-template <int AT, int MT, int CT, bool SQ, int SCHED = 1, bool EXT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, BARTRT_WPE)))
+// OUT: also writes the optical depths tau_out[W][L] / last_out[W] (the deepest layer a ray of the sample reaches;
+// deeper layers repeat its depth) and the per-ray intensities intens_out[A][W] of a single walker -- what `tau.dat`
+// and `outintens` hold (code/cf.py:46-94 reads them back) -- from the same walk, instead of a second launch of the
+// generic kernel.
+// (the OUT build is a once-per-run diagnostic launch of one walker: it takes the registers of a whole SIMD -- one
+// wave per SIMD -- instead of spilling the output bookkeeping)
+template <int AT, int MT, int CT, bool SQ, int SCHED = 1, bool EXT = false, bool OUT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OUT ? 1 : 2, BARTRT_WPE)))
 void rt_eclipse_simpson_slant(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
@@ -129,6 +135,8 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   // the tau grid of the intensity integrals: abscissa of the previous point, the previous
   // interval and its reciprocal; tm = the largest tau so far (layers <= kcut)
   double x1 = 0.0, h0 = 0.0, r0 = 1.0, tm = 0.0;
+  [[maybe_unused]] int out_last = 0;          // OUT: the deepest layer with a living ray, its optical depth
+  [[maybe_unused]] double out_tau = 0.0;
   // per ray angle: the last two integrands, the sums of the panels that end on even / odd points
   double y1[A], y2[A], P0[A], P1[A];
 #pragma unroll
@@ -198,6 +206,13 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     // (one multiplication and, per ray, one clamped addition: alive_flags)
     double m[A];
     const double nnow = alive_flags<A>(p, tm, m);
+    if constexpr (OUT) {
+      if (p.tau_out && valid && inr && tm <= thr_max) {   // some ray of the sample is alive on this layer
+        p.tau_out[(size_t)i * L + k] = tau;
+        out_last = k;
+        out_tau = tau;
+      }
+    }
     if constexpr (MASKED) {
 #pragma unroll
       for (int a = 0; a < A; a++) m[a] = inr ? m[a] : 0.0;
@@ -365,12 +380,17 @@ void rt_eclipse_simpson_slant(RtArgs p) {
         S += died ? pad : 0.0;
       }
       F = fma(p.wq[a], S, F);
+      double Idk = 0.0;
       if (deck_on) {
         // an opaque deck this ray reached below its cut emits as a surface: B(kend) exp(-tau(kend) / mu_a)
         const double xd = tauend * p.invmu[a];
         const bool deck = !died && !(xd > p.toomuch);
         const double Ed = exp_rt(fmax(-fmin(tauend, tcap) * p.invmu[a], kExpMin));
-        F += deck ? p.wgt[a] * Bend * Ed : 0.0;
+        Idk = deck ? Bend * Ed : 0.0;
+        F = fma(p.wgt[a], Idk, F);
+      }
+      if constexpr (OUT) {
+        if (p.intens_out && valid) p.intens_out[(size_t)a * W + i] = fma(p.invmu[a], S, Idk);
       }
     }
   }
@@ -414,7 +434,19 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     }
     F = 0.0;
 #pragma unroll
-    for (int a = 0; a < A; a++) F += p.wgt[a] * ray[a].result(deck_on && alive_a[a], L);
+    for (int a = 0; a < A; a++) {
+      const double Ia = ray[a].result(deck_on && alive_a[a], L);
+      F += p.wgt[a] * Ia;
+      if constexpr (OUT) {
+        if (p.intens_out && valid) p.intens_out[(size_t)a * W + i] = Ia;
+      }
+    }
+  }
+  if constexpr (OUT) {
+    if (p.tau_out && valid) {
+      for (int kk = out_last + 1; kk < L; kk++) p.tau_out[(size_t)i * L + kk] = out_tau;
+      p.last_out[i] = out_last;
+    }
   }
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
@@ -422,7 +454,6 @@ void rt_eclipse_simpson_slant(RtArgs p) {
 }
 
 // the builds (rt_eclipse_i1s_ilp.hip): ray grids of five angles and of the other sizes, the line-by-line hand-off
-bool launch_rt_simpson_slant(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
-bool launch_rt_simpson_slant_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+// (the launchers are declared with the other specialised kernels' in rt_eclipse.hpp)
 
 }  // namespace bartrt

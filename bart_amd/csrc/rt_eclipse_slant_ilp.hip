@@ -34,6 +34,20 @@ bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks
   return false;
 }
 
+// rule 1 with the optical-depth / per-ray-intensity outputs of a single walker (rt_eclipse_simpson_slant<..., OUT>;
+// the ray angles in the cfg's order: no squared-transmittance pairing)
+bool launch_rt_slant_out(const RtArgs &b, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
+#define BARTRT_SLANT_OUT(MM, CC)                                                                                          \
+  if (b.M == MM && b.C == CC) {                                                                                           \
+    BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, 0, false, true>), dim3(nblocks), dim3(block), sh, st, b); \
+    err = hipGetLastError();                                                                                              \
+    return true;                                                                                                          \
+  }
+  BARTRT_MC_LIST(BARTRT_SLANT_OUT)
+#undef BARTRT_SLANT_OUT
+  return false;
+}
+
 bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
   if (integ != kIntegSimpson && integ != kIntegTransmittance) return false;
 #define BARTRT_SLANT_EXT(CC)                                                                                                   \

@@ -41,7 +41,7 @@ def check(cfg, profs, what, clouds=(None,)):
         if CUT == "slant":          # the per-ray cut runs its own single-wave kernels, not the generic one
             engine.walked_begin(); engine.run_batch(profs); kname = engine.walked_end()[2]
             assert "slant" in kname.lower() or "one ray per lane" in kname, kname
-            assert ("one ray per lane" in kname) == (os.environ.get("BARTRT_KERNEL") == "quad"), kname
+            assert ("one ray per lane" in kname) == (os.environ.get("BARTRT_KERNEL") in ("quad", "octo")), kname
             assert ("team" in kname) == (os.environ.get("BARTRT_KERNEL") == "team"), kname
         for ct in clouds:
             if ct is not None:
@@ -97,7 +97,7 @@ print("ok")
 
 @pytest.mark.parametrize("cut,integ,kernel", [("vertical", 1, "mono_ilp"), ("slant", 1, "mono_ilp"), ("slant", 0, "mono_ilp"),
                                               ("slant", 2, "mono_ilp"), ("slant", 1, "quad"), ("slant", 0, "quad"),
-                                              ("slant", 2, "quad"), ("slant", 1, "team")])
+                                              ("slant", 2, "quad"), ("slant", 1, "team"), ("slant", 1, "octo")])
 @pytest.mark.parametrize("mode", ["lengths", "cuts", "zero"])
 def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ, kernel):
     """(cut slant: the same sweeps through rt_eclipse_simpson_slant / rt_eclipse_fast<SLANT>, where every ray

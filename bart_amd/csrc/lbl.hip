@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void lbl_smax(LblDev d, const double *state, d
 struct AccArgs {
   int W, nstate, per_group;   // per_group: out[state][g][W] else out[state][W] summed over groups
   int pair_reach;             // states whose widest cut spans at most this many points go to lbl_accumulate_pairs
+  int mid_reach;              // ... at most this many (and more than pair_reach): the line-major walk of lbl_accumulate_fine; 0: off
   const double *wn;
   const double *state, *smax;
   double *out;
@@ -436,6 +437,20 @@ __device__ __forceinline__ bool narrow_state(const LblDev &d, const AccArgs &a, 
   return cany <= a.pair_reach * dnu;
 }
 
+// Moderately broad states evaluated on the output points (no oversampling): the widest cut of any isotope, taken at
+// the top of the FULL grid, reaches at most mid_reach points either side.  With lane = point (lbl_accumulate) a line
+// of +-48 points keeps 38 % of a 256-point tile's lanes inside its cut; the line-major walk of lbl_accumulate_fine on
+// 64-point sub-tiles keeps nearly all of them (round 4).  A function of the state alone; where a tile of such a state
+// is narrow enough for the pair kernel (narrow_state, by 256-point tile), the pair kernel keeps it.
+__device__ __forceinline__ bool mid_state(const LblDev &d, const AccArgs &a, const double *sv) {
+  if (a.mid_reach <= 0 || sv[1] > 1.0) return false;
+  const double wn_last = d.wn_first + (double)(d.wfull - 1) * d.wndelt;
+  double cany = 0.0;
+  for (int k = 0; k < d.niso; k++)
+    cany = fmax(cany, d.nwidth * fmax(sv[3 + 3 * k], (wn_last + 1.0) * sv[2 + 3 * k] * 1.011));
+  return cany <= a.mid_reach * d.wndelt;
+}
+
 // One line's staged record, or cut < 0 for a line below the strength threshold.
 struct LineRec { double nu0, amp, xs, y, cut; };
 __device__ __forceinline__ LineRec stage_line(const LblDev &d, const double *sv, double invT, double thresh, long j) {
@@ -470,6 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
   if (sv[1] > 1.0) return;                    // an oversampled state: lbl_accumulate_fine owns it
   if (narrow_state(d, a, sv, tile0)) return;  // lbl_accumulate_pairs owns it
+  if (mid_state(d, a, sv)) return;            // moderately broad: lbl_accumulate_fine's line-major walk owns it
   load_imw_table(s_tab);
   __syncthreads();
   const double invT = 1.0 / sv[0];
@@ -704,6 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // smaller sub-tiles (more resident waves) measured faster than larger ones (512: 55 ms,
 // 1 024: 56, 2 048: 63, 4 096: 92).
 constexpr int kFineTarget = 512;
+constexpr int kMidReach = 0;   // (0: off until measured; BARTRT_MID_REACH) see mid_state
 // Doubles of LDS one wave of lbl_accumulate_fine needs: the fine sums, a staged batch of 64 lines (five
 // doubles, four range ints and the Voigt order each).
 __host__ __device__ inline size_t fine_wave_doubles(int nfmax) { return (size_t)nfmax + 5 * 64 + (4 * 64 + 64) / 2; }
@@ -714,12 +731,15 @@ __global__ __launch_bounds__(1024) void lbl_accumulate_fine(LblDev d, AccArgs a,
   double *s_tab = s_dyn;
   const int st = blockIdx.y;
   const double *sv = a.state + (size_t)st * (2 + 3 * d.niso);
-  if (!(sv[1] > 1.0)) return;             // evaluated on the output points: the other two kernels
+  // states evaluated on the output points belong to the other two kernels, except the moderately broad ones
+  const bool mid = mid_state(d, a, sv);
+  if (!(sv[1] > 1.0) && !mid) return;
   load_imw_table(s_tab);
   __syncthreads();                        // the only workgroup barrier
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * 64;
   if (tile0 >= a.W) return;
+  if (mid && narrow_state(d, a, sv, tile0 & ~255)) return;   // (this 256-point tile: the pair kernel's)
   double *s_fine = s_dyn + kImwDoubles + (size_t)wave * fine_wave_doubles(nfmax);   // [nfmax]
   double *s_nu0 = s_fine + nfmax, *s_amp = s_nu0 + 64, *s_xs = s_amp + 64, *s_y = s_xs + 64, *s_cut = s_y + 64;
   int *s_rng = reinterpret_cast<int *>(s_cut + 64);                 // [64][4]: first point, core first / last, last point
@@ -1352,6 +1372,8 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
   HIPCHK(hipGetLastError());
   aa.W = e.W(); aa.nstate = sa.nstate; aa.wn = e.d_wn; aa.state = b->d_state; aa.smax = b->d_smax;
   aa.pair_reach = kPairReach;
+  static const int mid_reach = [] { const char *v = std::getenv("BARTRT_MID_REACH"); return v && *v ? std::max(0, atoi(v)) : kMidReach; }();
+  aa.mid_reach = mid_reach;
   if (d.voigt_grid) {
     // width-grid mode: lay the states' profile tables out, size the buffer, tabulate, accumulate
     const long ns = sa.nstate;
@@ -1400,14 +1422,17 @@ static void run_states(Engine &e, StateArgs &sa, AccArgs &aa, hipStream_t st) {
   hipLaunchKernelGGL(lbl_accumulate_pairs, dim3(ntile, sa.nstate, aa.per_group ? d.ngroup : 1), dim3(256),
                      0, st, d, aa);
   HIPCHK(hipGetLastError());
-  if (d.osamp > 1) {   // the states evaluated on a finer grid (each state is owned by one of the three)
-    int dvmax = 0;     // decided on the device (lbl_states); the other two kernels run meanwhile
-    HIPCHK(hipMemcpyAsync(&dvmax, b->d_dvmax, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (dvmax > 1) {
+  if (d.osamp > 1 || aa.mid_reach > 0) {   // the states evaluated on a finer grid, and the moderately broad ones (each state is owned by one of the three)
+    int dvmax = 1;     // decided on the device (lbl_states); the other two kernels run meanwhile
+    if (d.osamp > 1) {
+      HIPCHK(hipMemcpyAsync(&dvmax, b->d_dvmax, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    if (dvmax > 1 || aa.mid_reach > 0) {
       static const int ftarget = [] { const char *v = std::getenv("BARTRT_FINE_TARGET"); return v && *v ? std::max(64, atoi(v)) : kFineTarget; }();
       static const int fwaves = [] { const char *v = std::getenv("BARTRT_FINE_WAVES"); return v && *v ? std::min(16, std::max(1, atoi(v))) : 4; }();
-      const int nfmax = std::max(ftarget, dvmax) + 1;
+      // (no oversampled state: a sub-tile is 64 output points -- a quarter of the LDS, more resident waves)
+      const int nfmax = dvmax > 1 ? std::max(ftarget, dvmax) + 1 : 65;
       // four waves share a workgroup's copy of the Im w table unless their fine sums would not fit
       const size_t per_wave = sizeof(double) * fine_wave_doubles(nfmax), tab = sizeof(double) * kImwDoubles;
       const int nw = tab + fwaves * per_wave <= 64 * 1024 ? fwaves : 1;

@@ -305,8 +305,6 @@ static hipError_t allow_lds(K kernel, size_t bytes, size_t &allowed) {
 
 hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0 || a.W <= 0) return hipSuccess;
-  const int ntiles8 = (a.ntiles + 7) / 8 * 8;
-  const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) +
                                       (size_t)a.L * idx_stride(a.C) + (size_t)a.L * 64);
   const size_t sh_pairs = sizeof(double) * (size_t)a.L * 64;
@@ -362,15 +360,20 @@ hipError_t launch_transit(const RtArgs &a, hipStream_t st) {
     BARTRT_MC_LIST(BARTRT_TRANSIT)
 #undef BARTRT_TRANSIT
   }
+  // the scalar kernel: one wave per 64 wavenumbers, whatever workgroup size the eclipse kernels run with
+  // (BARTRT_BLOCK: a.ntiles counts tiles of that size)
+  RtArgs b = a;
+  b.ntiles = (a.W + 63) / 64;
+  const int nb = (b.ntiles + 7) / 8 * 8 * a.nwalkers;
   static size_t allowed = 48 * 1024, allowed_pairs = 48 * 1024;
   if (sh <= 160 * 1024) {
     hipError_t e = allow_lds(rt_transit<true>, sh, allowed);
     if (e != hipSuccess) return e;
-    BARTRT_RT_LAUNCH(rt_transit<true>, dim3(nblocks), dim3(64), sh, st, a);
+    BARTRT_RT_LAUNCH(rt_transit<true>, dim3(nb), dim3(64), sh, st, b);
   } else {
     hipError_t e = allow_lds(rt_transit<false>, sh_pairs, allowed_pairs);
     if (e != hipSuccess) return e;
-    BARTRT_RT_LAUNCH(rt_transit<false>, dim3(nblocks), dim3(64), sh_pairs, st, a);
+    BARTRT_RT_LAUNCH(rt_transit<false>, dim3(nb), dim3(64), sh_pairs, st, b);
   }
   return hipGetLastError();
 }

@@ -38,7 +38,7 @@ def _draw(rng, wide=False):
     return kw, geometry, nwalk, cloud
 
 
-def _run(tmp_path, seed, integ=0, ramp=False):
+def _run(tmp_path, seed, integ=0, ramp=False, cut=None):
     from bart_amd import engine, synth, transit_module as trm
     from oracle import rt_oracle as orc
     from test_gpu_parity import walkers
@@ -54,7 +54,9 @@ def _run(tmp_path, seed, integ=0, ramp=False):
     engine.init(c.tcfg)
     try:
         trm.set_integ(integ)
-        o = orc.OracleEngine(c.tcfg, integ=integ)
+        o = orc.OracleEngine(c.tcfg, integ=integ, cut=cut)
+        if cut is not None:       # (None: the engine's and the oracle's default, `cut slant`)
+            trm.set_cut(cut)
         if cloud is not None:
             trm.set_cloudtop(cloud); o.set_cloudtop(cloud)
         profs = walkers(c, nwalk, seed=seed)
@@ -65,7 +67,7 @@ def _run(tmp_path, seed, integ=0, ramp=False):
         # times the result: there the kernel's difference form and the restatement's agree to 1e-12 of the
         # largest sample, not of each (tools/fuzz_sweep.py 200-560: five such columns, <= 8e-13 of the maximum)
         np.testing.assert_allclose(spec, ref, rtol=RTOL, atol=1e-12 * np.abs(ref).max() if integ == 1 else 1e-300,
-                                   err_msg="%s %s walkers=%d cloud=%s integ=%d" % (geometry, kw, nwalk, cloud, integ))
+                                   err_msg="%s %s walkers=%d cloud=%s integ=%d cut=%s" % (geometry, kw, nwalk, cloud, integ, cut))
     finally:
         trm.free_memory()
 
@@ -78,5 +80,6 @@ def test_random_configuration(tmp_path, seed):
 @pytest.mark.parametrize("seed", range(100, 136))
 def test_random_configuration_rules_and_clouds(tmp_path, seed):
     """The same draws under integration rules 1 and 2 (seed mod 3 picks the rule, 0 too)
-    and with a radius-ramp cloud / transparent core added to every second one."""
-    _run(tmp_path, seed, integ=seed % 3, ramp=seed % 2 == 1)
+    and with a radius-ramp cloud / transparent core added to every second one; every fourth under
+    `cut vertical` (the others under the default, `cut slant`)."""
+    _run(tmp_path, seed, integ=seed % 3, ramp=seed % 2 == 1, cut="vertical" if seed % 4 == 0 else None)

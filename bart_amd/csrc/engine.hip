@@ -688,7 +688,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     // the event log of the single-wave `cut slant` kernels (rt_eclipse_s1s.hpp): 100 bytes per lane
     const size_t need = slant_log_bytes(n, r.ntiles, block, A);
     if (need > slog_cap) {
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipDeviceSynchronize());   // (an earlier launch on any stream may still write the old log)
       if (d_slog) HIPCHK(hipFree(d_slog));
       d_slog = nullptr;
       slog_cap = 0;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <new>
 #include <cerrno>
 #include <chrono>
 #include <csignal>
@@ -126,6 +127,12 @@ TableShare *TableShare::attach(const std::string &key, size_t nbytes, const std:
       throw IoError{"shareOpacity: the shared opacity grid has another size than this configuration's (" + name + ")"};
     }
     s->nmapped.fetch_add(1);
+    if (s->state.load(std::memory_order_acquire) != kReady) {
+      // the owner let go between the check above and the count: it may have freed the grid already
+      s->nmapped.fetch_sub(1);
+      munmap(m, sizeof(Seg)); close(fd);
+      continue;
+    }
     auto *t = new TableShare;
     t->owner = false; t->seg = m; t->fd = fd; t->name = name;
     void *p = nullptr;

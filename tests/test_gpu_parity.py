@@ -284,6 +284,35 @@ def test_cloud_deck_sweep_across_layer_steps(tmp_path, nlayers, integ):
         trm.free_memory()
 
 
+def test_tau_and_intensity_come_from_the_slant_kernel(small_case):
+    """Under the default conventions (`integ 1`, `cut slant`) `bartrt_get_tau` / `_get_intensity` -- what `tau.dat` and
+    `outintens` hold (code/cf.py:46-94) -- are written by the single-wave slant kernel on its way (its OUT build), not by
+    a launch of the generic kernel; values against the oracle."""
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    c = small_case
+    engine.init(c.tcfg)
+    try:
+        assert trm.get_cut() == "slant" and trm.get_integ() == 1
+        o = orc.OracleEngine(c.tcfg)
+        prof = walkers(c, 1, seed=21)[0]
+        n = trm.get_no_samples()
+        spec = trm.run_transit(prof, n)
+        engine.walked_begin()
+        tau, last = engine.get_tau()
+        assert "outputs" in engine.walked_end()[2]
+        rspec, rtau, rlast = o.run(prof, want_tau=True)
+        assert np.array_equal(last, rlast)
+        np.testing.assert_allclose(tau, rtau, rtol=1e-9, atol=1e-300)
+        inten = np.zeros((5, n))
+        trm.check(trm.lib().bartrt_get_intensity(trm._ptr(inten), 5, n))
+        refi = o.intensity(prof)
+        np.testing.assert_allclose(inten, refi, rtol=RTOL, atol=1e-12 * np.abs(refi).max())
+        np.testing.assert_allclose(spec, rspec, rtol=RTOL, atol=1e-12 * np.abs(rspec).max())
+    finally:
+        trm.free_memory()
+
+
 def test_shards_reassemble_full_spectrum(small_case):
     """Wavenumber-block sharding: the blocks of every rank, concatenated, are the
     unsharded spectrum bit for bit (no halo)."""

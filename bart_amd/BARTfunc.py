@@ -128,6 +128,7 @@ class Worker:
         self.nwave = trm.get_no_samples()
         self.specwn = trm.get_waveno_arr(self.nwave)
         self.integ = trm.get_integ()     # logged by main(): runs under different rules are not to be confused
+        self.cut, self.cia_interp = trm.get_cut(), trm.get_cia_interp()
         if engine.species() != self.species or engine.nlayers() != self.nlayers:
             raise ValueError("atmfile of the MCMC configuration and 'atm' of the transit "
                              "configuration describe different atmospheres")
@@ -291,6 +292,8 @@ def main(comm, argv=None, group=None, worker_factory=None, shard_backend="nccl")
         if getattr(w, "integ", None) is not None:
             print("Integration rule of the eclipse geometry: integ {:d} ({})".format(
                 w.integ, ("transmittance", "simpson", "trapz_tau")[w.integ]))
+            if getattr(w, "cut", None) is not None:
+                print("toomuch cut: {}; CIA interpolation: {}".format(w.cut, w.cia_interp))
     params = np.zeros(npars, np.double)
     nfilt = np.zeros(1, int)
     if nworkers > 1:

@@ -87,6 +87,10 @@ int main(int argc, char **argv) {
     static const char *names[] = {"transmittance trapezoid", "Simpson hybrid, SURVEY App. A-4", "trapezoid in tau"};
     if (bartrt_get_integ(&rule) == 0 && rule >= 0 && rule < 3)
       std::printf("Integration rule of the eclipse geometry: integ %d (%s)\n", rule, names[rule]);
+    int slant = -1, spline = -1;
+    if (bartrt_get_cut(&slant) == 0 && bartrt_get_cia_interp(&spline) == 0)
+      std::printf("`toomuch` cuts each ray's %s optical depth (cut %s); CIA interpolation: %s\n", slant ? "slant" : "the column's vertical",
+                  slant ? "slant" : "vertical", spline ? "natural cubic splines (cia_interp spline)" : "linear (cia_interp linear)");
   }
   const double toomuch = c.count("toomuch") ? std::atof(c["toomuch"].c_str()) : 20.0;
 

@@ -96,7 +96,7 @@ int bartrt_get_integ(int *rule);
  * engine's call structure is recalled to have -- the optical depth is computed per ray angle, the
  * cut inside that loop; every angle ends on its own layer and rule 1 pads one unit of slant depth.
  * 0 = the vertical depth: the column ends on one layer for every ray angle.  Both run specialised
- * single-wave kernels (rules 0 and 1; the slant cut costs 1.15-1.35x per launch); the two differ
+ * kernels (rules 0, 1 and 2; the slant cut costs 1.10-1.18x per launch); the two differ
  * by about exp(-toomuch) of the flux.  Also the cfg key `cut vertical|slant` and BARTRT_CUT. */
 int bartrt_set_cut(int slant);
 int bartrt_get_cut(int *slant);

@@ -50,13 +50,18 @@ constexpr long kQuadMaxColumns = 640, kQuadMaxColumnsSimpson = 480;
 // extinction five times over, so on the 1e4-sample grid ONE walker already takes what the single-wave kernel takes
 // (63 against 58 us, +35 us per further walker)
 constexpr long kQuadRaysMaxColumns = 80;
-constexpr long kOctoRaysMaxColumns = 40;    // ... with eight layers per step (one wavenumber x five rays per wave) below this
+constexpr long kOctoRaysMaxColumns = 40;
+// rule 1 under `cut slant`: all rays per lane in the layer-parallel walk (rt_eclipse_quad<..., ALLR>) up to here
+// (tools/ab_small.py), eight rows per step below the second figure
+//   bench grid (W = 1e4), us per RT launch, all rays R = 8 / R = 4 / team / single wave: 1 walker 38 / 47 / 43 / 58, 2 walkers
+//   58 / 59 / 59 / 59, 3: 69 / 59 / - / 59, 4: 88 / 93 / 76 / 59; demo grid, one walker: 27.2 against one ray per lane's 24.7
+constexpr long kQuadAllMaxColumns = 200, kOctoAllMaxColumns = 200;    // ... with eight layers per step (one wavenumber x five rays per wave) below this
 // `cut slant`, rule 1: a team of three waves per column (rt_eclipse_s1t.hpp) for ONE walker's worth of columns at
 // W = 1e4 -- 44 against the single-wave kernel's 58 us; from two walkers on the team loses (59 / 59, four walkers 76 /
 // 61, ten 135 / 98, 64: 639 / 429 us): its producer wave keeps its table loads one layer ahead only (the 128
 // registers that five teams per CU allow), the Planck term and the panel weights are computed twice, and three
 // waves meet at a barrier every six layers
-constexpr long kTeamMaxColumns = 160;
+constexpr long kTeamMaxColumns = 0;   // (round 4, later: the all-rays quad kernel takes that range at 38 us; the team stays behind BARTRT_KERNEL=team)
 constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this
 constexpr long kSplitMinColumns = 1025, kSplitMaxColumns = 1300;
 constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
@@ -427,7 +432,19 @@ void rt_eclipse_split(RtArgs p) {
 // most of the chip idle anyway (one to three walkers) -- in exchange for a layer-parallel walk whose per-step work
 // is a fifth of the five-ray lane's: this is how `cut slant`, whose rays cannot share a layer sum, keeps a
 // few-walker kernel (the single-wave slant kernel walks a column's 100 layers serially: 50 us at any small batch).
-template <int AT, int MT, int CT, bool SQ, int R, int INTEG, bool RAYS = false>
+//
+// ALLR (rule 1, `cut slant`): all rays in every lane.  What `cut slant` takes away from this kernel is the single
+// integrand that crossed the lane rows -- each ray needs its own last two integrands from the rows below -- not the
+// layer parallelism: the rays' alive flags need no ballots at all (a ray is alive on layer j iff the largest optical
+// depth of the layers above, an exclusive prefix MAXIMUM across the rows on top of the previous steps' carry, is at or
+// below its threshold RtArgs::thr), the row after a ray's last layer is its padded point (alive at the start of layer
+// j - 1, dead at the start of j: the same two prefix maxima), whose panel takes weights of its own (one unit of slant
+// depth = mu_a of vertical depth: computed only in waves where some lane pads that ray), and every lane keeps one sum
+// per ray (its layers all have the parity of its row).  At the end each ray's last point index is the largest padded
+// row of its column (or the column's last layer) and the rows of that parity are added up.  Ten values cross the rows
+// per step instead of two; extinction, optical depth and Planck term are computed once per (layer, wavenumber) --
+// which the one-ray-per-lane form (RAYS) does five times.
+template <int AT, int MT, int CT, bool SQ, int R, int INTEG, bool RAYS = false, bool ALLR = false>
 __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
@@ -437,6 +454,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   constexpr int WN = 64 / R;                          // columns per wave
   constexpr int WNR = RAYS ? WN / A : WN;             // wavenumbers per wave
   static_assert(!RAYS || (WNR >= 1 && !SQ), "RAYS: the ray grid fits a lane row; no squared-transmittance shortcut");
+  static_assert(!ALLR || (INTEG == kIntegSimpson && !RAYS), "ALLR: rule 1, all rays per lane");
   constexpr bool SIMPSON = INTEG == kIntegSimpson;
   const int L = p.L, W = p.W;
   int bid = blockIdx.x;
@@ -527,6 +545,16 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   double c2_e = 0.0, c2_tau = 0.0, c_y = 0.0, c2_y = 0.0, c_S = 0.0;
   int nend = kend;
   bool pad_next = false;
+  // ALLR: per ray the lane's sum, the carries of the two integrands above the step, the padded row it evaluated;
+  // the running maximum of tau over the layers above the step (and above its last row)
+  [[maybe_unused]] double Ia[A], ca_y[A], ca2_y[A], c_tm = 0.0, c_tm1 = 0.0, thr_max = 0.0;
+  [[maybe_unused]] int Npad[A];
+  [[maybe_unused]] const int kcut = kend < L - 2 ? kend : L - 2;
+  if constexpr (ALLR) {
+    thr_max = p.thr[0];
+#pragma unroll
+    for (int a = 0; a < A; a++) { Ia[a] = ca_y[a] = ca2_y[a] = 0.0; Npad[a] = -1; thr_max = p.thr[a] > thr_max ? p.thr[a] : thr_max; }
+  }
   // no layer above this step passed `toomuch` (per column, all rows agree); columns that hold no sample of the grid
   // (past its end, or the idle columns of RAYS) are dead from the start: they must not keep the wave walking
   bool active = col_on && i0 + mw < W;
@@ -575,6 +603,64 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       tau = (q & 1) ? fma((eprev + e) * cf[0], 0.5, S) : S;
     }
     c_tau = __shfl(tau, (R - 1) * WN + m);
+    if constexpr (ALLR) {
+      // ---- all rays per lane (see the comment above the kernel)
+      // largest optical depth of the layers above this one / above the one above (layers past kcut do not count:
+      // a ray ends only where a deeper layer exists)
+      double pm = j <= kcut ? tau : 0.0;
+#pragma unroll
+      for (int d = 1; d < R; d <<= 1) {
+        const double t = __shfl(pm, (lane + 64 - d * WN) & 63);
+        if (q >= d) pm = fmax(pm, t);
+      }
+      const double incl = fmax(c_tm, pm);
+      const double incl_b = __shfl(incl, from_below);
+      const double excl = q == 0 ? c_tm : incl_b;            // over the layers < j
+      const double excl_b = __shfl(excl, from_below);
+      const double excl1 = q == 0 ? c_tm1 : excl_b;          // over the layers < j - 1
+      c_tm1 = __shfl(excl, (R - 1) * WN + m);
+      c_tm = __shfl(incl, (R - 1) * WN + m);
+      // Planck term and transmittances
+      const double tcl = fmin(tau, tcap);
+      double xs[AE + 1], ex[AE + 1], y[A];
+      xs[AE] = fmin(cf[1] * nu, 700.0);
+#pragma unroll
+      for (int a = 0; a < AE; a++) xs[a] = -tcl * p.invmu[a];
+      exp_rt_n<AE + 1>(xs, ex);
+      const double B = bnum * rcp_n1(ex[AE] - 1.0);
+#pragma unroll
+      for (int a = 0; a < AE; a++) y[a] = B * ex[a];
+      if (SQ) y[A - 1] = y[0] * ex[0];
+      // the tau grid of this lane's panel (j - 2, j - 1, j)
+      const double tau_b1 = __shfl(tau, from_below);
+      const double tau1 = q == 0 ? tau_above_step : tau_b1;
+      const double tau_b2 = __shfl(tau, from_below2);
+      const double tau2 = q < 2 ? c2_tau : tau_b2;
+      c2_tau = tau_b2;
+      double w0, w1, w2;
+      simpson_tau_weights(tau1 - tau2, tau - tau1, w0, w1, w2);
+      if (j == 1) { w0 = 0.0; w1 = 0.5 * (tau - tau1); w2 = w1; }   // the first interval: a trapezoid
+#pragma unroll
+      for (int a = 0; a < A; a++) {
+        const double yb = __shfl(y[a], from_below), yb2 = __shfl(y[a], from_below2);
+        const double y1 = q == 0 ? ca_y[a] : yb, y2 = q < 2 ? ca2_y[a] : yb2;
+        ca_y[a] = yb;
+        ca2_y[a] = yb2;
+        const bool alive = inrange && excl <= p.thr[a];
+        const bool pad = j >= 1 && j < L && !(excl <= p.thr[a]) && excl1 <= p.thr[a];   // the ray died on layer j - 1
+        double cterm = fma(w0, y2, fma(w1, y1, w2 * y[a]));
+        if (__any(pad)) {
+          double v0, v1, v2;
+          simpson_tau_weights(tau1 - tau2, p.mu[a], v0, v1, v2);   // one unit of slant depth past the last point, integrand 0
+          cterm = pad ? fma(v0, y2, v1 * y1) : cterm;
+          Npad[a] = pad ? j : Npad[a];
+        }
+        Ia[a] += ((alive || pad) && j >= 1) ? cterm : 0.0;
+        if (deck_on && j == kend && alive && !(tau > p.thr[a])) Fs = fma(p.wgt[a], y[a], Fs);   // deck reached below the ray's cut
+      }
+      active = c_tm1 <= thr_max;   // some ray was alive when the step's last row began: its pad or more layers may follow
+      return;
+    }
     // which layers of this step are still above the cut
     const unsigned long long over = __ballot(inrange && active && tau > thr_l);
     const bool live = inrange && active && (over & below_bits) == 0ull;
@@ -674,6 +760,16 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   // the rows of a wavenumber hold its layers' terms: sum them; row 0 writes
   const bool mine_counts = !SIMPSON || ((q & 1) == (nend & 1));
   double F = Fs + (mine_counts ? I : 0.0);   // the lane's layers, angle quadrature already taken
+  if constexpr (ALLR) {
+    F = Fs;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+      int np = Npad[a];                    // the ray's padded row, known to the lane that evaluated it
+      for (int o = WN; o < 64; o <<= 1) { const int t = __shfl_xor(np, o); np = t > np ? t : np; }
+      const int nlast = np >= 0 ? np : kend;   // its last point's index
+      F = fma(p.wq[a], ((q & 1) == (nlast & 1)) ? Ia[a] : 0.0, F);
+    }
+  }
   for (int o = WN; o < 64; o <<= 1) F += __shfl_xor(F, o);
   if constexpr (RAYS) {   // the rays of a wavenumber: columns mw A .. mw A + A - 1 of row 0, in ray order
     double Ft = 0.0;
@@ -834,9 +930,43 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   if (a.cut_slant) {
     // the per-ray cut: launches that leave the chip mostly idle take the layer-parallel walk with ONE RAY PER LANE
     // (rt_eclipse_quad<..., RAYS>: three wavenumbers x five rays x four layers per wave and step) ...
-    if ((kmode == "quad" || kmode == "octo" || (kmode.empty() && columns <= kQuadRaysMaxColumns)) && fits32) {
+    // which of the two layer-parallel forms: one ray per lane for the smallest launches and for rules 0 / 2, all rays per
+    // lane (rule 1) above that (BARTRT_KERNEL: quad / octo = the rule's own choice of form, quadrays / octorays = one ray
+    // per lane)
+    const bool rays_forced = kmode == "quadrays" || kmode == "octorays";
+    const bool lp_forced = kmode == "quad" || kmode == "octo";
+    const bool use_rays = rays_forced || (INTEG != kIntegSimpson && lp_forced) || (kmode.empty() && columns <= kQuadRaysMaxColumns);
+    if constexpr (INTEG == kIntegSimpson) {
+      // rule 1: the layer-parallel walk with ALL rays per lane (rt_eclipse_quad<..., ALLR>)
+      const bool octoa = kmode == "octo" || (kmode.empty() && columns <= kOctoAllMaxColumns);
+      if (!use_rays && (lp_forced || (kmode.empty() && columns <= kQuadAllMaxColumns)) && a.cia_bytes < (1ull << 32) - 4096 &&
+          (!b.window || window_fits(a, octoa ? 8 : 4))) {
+        b.ntiles = octoa ? (a.W + 31) / 32 : ntiles64;
+        const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
+        const size_t shq = sh + shp;
+        if (info) {
+          info->kernel = octoa ? "rt_eclipse_quad<R=8, all rays per lane>" : "rt_eclipse_quad<R=4, all rays per lane>";
+          info->wn_per_column = octoa ? 8 : 16; info->ncolumns = 4 * b.ntiles;
+        }
+#define BARTRT_QUADALL(MM, CC)                                                                                               \
+  if (a.M == MM && a.C == CC) {                                                                                              \
+    if (octoa) {                                                                                                             \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, 8, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);  \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 8, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);    \
+    } else {                                                                                                                 \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, 4, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);  \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);    \
+    }                                                                                                                        \
+    err = hipGetLastError();                                                                                                 \
+    return true;                                                                                                             \
+  }
+        BARTRT_MC_LIST(BARTRT_QUADALL)
+#undef BARTRT_QUADALL
+      }
+    }
+    if (use_rays && fits32) {
       // (the smallest launches -- one walker on the demo shape -- eight layers per step: one wavenumber x five rays per wave)
-      const bool octor = kmode == "octo" || (kmode.empty() && columns <= kOctoRaysMaxColumns);
+      const bool octor = kmode == "octo" || kmode == "octorays" || (kmode.empty() && columns <= kOctoRaysMaxColumns);
       const bool win_ok = !b.window || window_fits(a, octor ? 8 : 4);
       if (win_ok) {
         b.ntiles = octor ? (a.W + 3) / 4 : (a.W + 11) / 12;          // a workgroup: four waves of one / three wavenumbers

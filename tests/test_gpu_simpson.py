@@ -40,8 +40,10 @@ def check(cfg, profs, what, clouds=(None,)):
         o = orc.OracleEngine(cfg, integ=INTEG, cut=CUT)
         if CUT == "slant":          # the per-ray cut runs its own single-wave kernels, not the generic one
             engine.walked_begin(); engine.run_batch(profs); kname = engine.walked_end()[2]
-            assert "slant" in kname.lower() or "one ray per lane" in kname, kname
-            assert ("one ray per lane" in kname) == (os.environ.get("BARTRT_KERNEL") in ("quad", "octo")), kname
+            assert "slant" in kname.lower() or "per lane" in kname, kname
+            km = os.environ.get("BARTRT_KERNEL")
+            assert ("per lane" in kname) == (km in ("quad", "octo", "quadrays", "octorays")), kname
+            assert ("all rays per lane" in kname) == (km in ("quad", "octo") and INTEG == 1), kname
             assert ("team" in kname) == (os.environ.get("BARTRT_KERNEL") == "team"), kname
         for ct in clouds:
             if ct is not None:
@@ -97,13 +99,15 @@ print("ok")
 
 @pytest.mark.parametrize("cut,integ,kernel", [("vertical", 1, "mono_ilp"), ("slant", 1, "mono_ilp"), ("slant", 0, "mono_ilp"),
                                               ("slant", 2, "mono_ilp"), ("slant", 1, "quad"), ("slant", 0, "quad"),
-                                              ("slant", 2, "quad"), ("slant", 1, "team"), ("slant", 1, "octo")])
+                                              ("slant", 2, "quad"), ("slant", 1, "team"), ("slant", 1, "octo"),
+                                              ("slant", 1, "quadrays"), ("slant", 1, "octorays")])
 @pytest.mark.parametrize("mode", ["lengths", "cuts", "zero"])
 def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ, kernel):
     """(cut slant: the same sweeps through rt_eclipse_simpson_slant / rt_eclipse_fast<SLANT>, where every ray
     angle ends on its own layer -- the deaths, pads and decks of five rays land on every block position -- and,
-    kernel = quad, through the layer-parallel walk with one ray per lane, rt_eclipse_quad<..., RAYS>; kernel = team,
-    through the three waves per column of rt_eclipse_slant_team.)"""
+    kernel = quad / octo, through the layer-parallel walk with all rays per lane (rule 1: rt_eclipse_quad<..., ALLR>) or
+    one ray per lane (rules 0 / 2, and rule 1 as quadrays / octorays: <..., RAYS>); kernel = team, through the three waves
+    per column of rt_eclipse_slant_team.)"""
     env = dict(os.environ, BARTRT_KERNEL=kernel)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, mode, str(tmp_path), cut, str(integ)],
                          env=env, capture_output=True, text=True, timeout=900)

@@ -45,17 +45,25 @@ namespace bartrt {
 //   5: 60 / 54 / 47   6: 64 / 58 / 50   7: 78 / 74 / 64   8: 81 / 78 / 68   9: 91 / 79 / 69   10: 103 / 102 / 71
 // -- the single-wave kernel from four walkers on, the producer / consumer pair never.
 constexpr long kQuadMaxColumns = 640, kQuadMaxColumnsSimpson = 480;
-// `cut slant`: one ray per lane (rt_eclipse_quad<..., RAYS>) while the launch is a few thousand (walker, wavenumber)
-// pairs -- the demo shape's 2 501 samples with one walker 15 us against the single-wave kernel's 51; it redoes the
-// extinction five times over, so on the 1e4-sample grid ONE walker already takes what the single-wave kernel takes
-// (63 against 58 us, +35 us per further walker)
+// `cut slant`, rules 0 and 2: one ray per lane (rt_eclipse_quad<..., RAYS>) while the launch is a few thousand (walker,
+// wavenumber) pairs -- it redoes the extinction five times over, so on the 1e4-sample grid ONE walker already takes
+// what the single-wave kernel takes (63 against 58 us, +35 us per further walker).  (Rule 1 took this form on the demo
+// shape until the all-rays form below got 16 and 32 rows: one walker 25.1 us against 15.3.)
 constexpr long kQuadRaysMaxColumns = 80;
 constexpr long kOctoRaysMaxColumns = 40;
-// rule 1 under `cut slant`: all rays per lane in the layer-parallel walk (rt_eclipse_quad<..., ALLR>) up to here
-// (tools/ab_small.py), eight rows per step below the second figure
-//   bench grid (W = 1e4), us per RT launch, all rays R = 8 / R = 4 / team / single wave: 1 walker 38 / 47 / 43 / 58, 2 walkers
-//   58 / 59 / 59 / 59, 3: 69 / 59 / - / 59, 4: 88 / 93 / 76 / 59; demo grid, one walker: 27.2 against one ray per lane's 24.7
-constexpr long kQuadAllMaxColumns = 200, kOctoAllMaxColumns = 200;    // ... with eight layers per step (one wavenumber x five rays per wave) below this
+// rule 1 under `cut slant`: all rays per lane in the layer-parallel walk (rt_eclipse_quad<..., ALLR>), R = 32 / 16 / 8
+// layers per step by the number of 64-wide columns of the launch: the form holds two waves per SIMD (200 registers),
+// 2 048 on the chip, and a launch of more waves than that runs in rounds -- so R <= 2 048 / columns, and the
+// single-wave kernel beyond 256 columns.  us per RT launch (tools/ab_small.py, tools/ab_rows.sh):
+//   demo shape (W = 2 501, one molecule), walkers 1 .. 5 = 40 .. 200 columns
+//     R = 32: 15.3 18.1 23.7 26.7 33.9   R = 16: 18.1 21.5 21.4 25.9 34.2   R = 8: 26.4 26.7 26.9 32.7 32.6
+//     one ray per lane, R = 8: 25.1 36.6 48.9 60.3 73.0
+//   bench shape at W = 5 000, walkers 1 .. 3 = 79 / 158 / 237 columns
+//     R = 32: 29.4 40.8 56.8   R = 16: 25.3 38.6 44.0   R = 8: 29.6 37.4 37.2   single wave: 55.8 56.0 56.0
+//   bench shape (W = 1e4), one walker = 157 columns: R = 32 / 16 / 8 / 4 / team / single wave 42.8 / 40.2 / 37.6 / 47 / 43 / 58;
+//     two walkers = 314 columns: R = 8 58.4, single wave 58.0
+constexpr long kQuadAllMaxColumns = 256, kOctoAllMaxColumns = 256;    // eight layers per step up to here (R = 4: BARTRT_KERNEL=quad only)
+constexpr long kRows16AllMaxColumns = 128, kRows32AllMaxColumns = 64;  // sixteen / thirty-two layers per step (BARTRT_KERNEL=hexa / r32)
 // `cut slant`, rule 1: a team of three waves per column (rt_eclipse_s1t.hpp) for ONE walker's worth of columns at
 // W = 1e4 -- 44 against the single-wave kernel's 58 us; from two walkers on the team loses (59 / 59, four walkers 76 /
 // 61, ten 135 / 98, 64: 639 / 429 us): its producer wave keeps its table loads one layer ahead only (the 128
@@ -467,14 +475,24 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   block_to_work(bid, p.nwalkers, tile, w);
   if (tile >= p.ntiles) return;
 
+  // (16 rows and up: the rows of a wave read 16 / 32 different layer records at once -- an even record stride would
+  // put them on 2-4 of the 64 LDS banks' positions; one double of padding per record spreads them over all)
+  constexpr int NCS = (R >= 16 && NC % 2 == 0) ? NC + 1 : NC;
   double *sC = smem;
-  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NC);
-  const double *sW = smem + (size_t)L * NC + (size_t)L * NI;  // rule 1 only
-  stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
-                threadIdx.x, 256);
+  idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NCS);
+  const double *sW = smem + (size_t)L * NCS + (size_t)L * NI;  // rule 1 only
+  if constexpr (NCS == NC) {
+    stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
+                  threadIdx.x, 256);
+  } else {
+    const double *src = p.coef + (size_t)w * L * NC;
+    const idx_t *srci = p.idx + (size_t)w * L * NI;
+    for (int k = threadIdx.x; k < L * NC; k += 256) sC[(k / NC) * NCS + k % NC] = src[k];
+    for (int k = threadIdx.x; k < L * NI; k += 256) sI[k] = srci[k];
+  }
   __syncthreads();
   if (SIMPSON) {
-    simpson_radius_weights(const_cast<double *>(sW), sC, NC, L, threadIdx.x, 256);
+    simpson_radius_weights(const_cast<double *>(sW), sC, NCS, L, threadIdx.x, 256);
     __syncthreads();
   }
 
@@ -524,7 +542,9 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   auto clampk = [&](int k) { return k < kend ? k : kend; };
 
   // the lanes of one wavenumber: bits m, WN + m, 2 WN + m, ... of a ballot
-  const unsigned long long col_bits = (R == 4 ? 0x0001000100010001ull : 0x0101010101010101ull) << m;
+  constexpr unsigned long long kColBits = R == 4 ? 0x0001000100010001ull : R == 8 ? 0x0101010101010101ull
+                                          : R == 16 ? 0x1111111111111111ull : R == 32 ? 0x5555555555555555ull : ~0ull;
+  const unsigned long long col_bits = kColBits << m;
   const unsigned long long below_bits = col_bits & ((1ull << (WN * q)) - 1ull);
   const int from_below = (lane + 64 - WN) & 63;       // row q - 1 (the last row for row 0)
   const int from_below2 = (lane + 64 - 2 * WN) & 63;  // row q - 2 (rule 1)
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   auto step = [&](int s, const double (&rv)[NR]) {
     const int j = R * s + q, jc = clampk(j);
     const bool inrange = j <= kend;
-    const double *c = sC + jc * NC;
+    const double *c = sC + jc * NCS;
     double cf[NC];
 #pragma unroll
     for (int x = 0; x < NC; x++) cf[x] = c[x];
@@ -637,8 +657,15 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
       const double tau_b2 = __shfl(tau, from_below2);
       const double tau2 = q < 2 ? c2_tau : tau_b2;
       c2_tau = tau_b2;
-      double w0, w1, w2;
-      simpson_tau_weights(tau1 - tau2, tau - tau1, w0, w1, w2);
+      // Simpson weights of the panel (simpson_tau_weights, integ.hpp, with the reciprocal of the upper half-width kept:
+      // the rays' padded panels share that half)
+      const double h0 = tau1 - tau2, h1 = tau - tau1, hs = h0 + h1;
+      const bool deg0 = h0 == 0.0, deg = deg0 || h1 == 0.0;
+      const double r0 = rcp_core(deg0 ? 1.0 : h0), r1 = rcp_core(h1 == 0.0 ? 1.0 : h1);
+      const double s6 = hs * (1.0 / 6.0);
+      double w0 = deg ? 0.5 * h0 : s6 * (2.0 - h1 * r0);
+      double w1 = deg ? 0.5 * hs : s6 * (hs * hs * (r0 * r1));
+      double w2 = deg ? 0.5 * h1 : s6 * (2.0 - h0 * r1);
       if (j == 1) { w0 = 0.0; w1 = 0.5 * (tau - tau1); w2 = w1; }   // the first interval: a trapezoid
 #pragma unroll
       for (int a = 0; a < A; a++) {
@@ -650,8 +677,11 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
         const bool pad = j >= 1 && j < L && !(excl <= p.thr[a]) && excl1 <= p.thr[a];   // the ray died on layer j - 1
         double cterm = fma(w0, y2, fma(w1, y1, w2 * y[a]));
         if (__any(pad)) {
-          double v0, v1, v2;
-          simpson_tau_weights(tau1 - tau2, p.mu[a], v0, v1, v2);   // one unit of slant depth past the last point, integrand 0
+          // one unit of slant depth (mu_a of vertical depth) past the last point, integrand 0 there: the panel's first
+          // two weights, no division (1 / h0 is the step's, 1 / mu_a the ray's constant)
+          const double hp = h0 + p.mu[a], p6 = hp * (1.0 / 6.0);
+          const double v0 = deg0 ? 0.5 * h0 : p6 * (2.0 - p.mu[a] * r0);
+          const double v1 = deg0 ? 0.5 * hp : p6 * (hp * hp * (r0 * p.invmu[a]));
           cterm = pad ? fma(v0, y2, v1 * y1) : cterm;
           Npad[a] = pad ? j : Npad[a];
         }
@@ -935,33 +965,43 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     // per lane)
     const bool rays_forced = kmode == "quadrays" || kmode == "octorays";
     const bool lp_forced = kmode == "quad" || kmode == "octo";
-    const bool use_rays = rays_forced || (INTEG != kIntegSimpson && lp_forced) || (kmode.empty() && columns <= kQuadRaysMaxColumns);
+    const bool use_rays = rays_forced || (INTEG != kIntegSimpson && (lp_forced || (kmode.empty() && columns <= kQuadRaysMaxColumns)));
     if constexpr (INTEG == kIntegSimpson) {
       // rule 1: the layer-parallel walk with ALL rays per lane (rt_eclipse_quad<..., ALLR>)
-      const bool octoa = kmode == "octo" || (kmode.empty() && columns <= kOctoAllMaxColumns);
-      if (!use_rays && (lp_forced || (kmode.empty() && columns <= kQuadAllMaxColumns)) && a.cia_bytes < (1ull << 32) - 4096 &&
-          (!b.window || window_fits(a, octoa ? 8 : 4))) {
-        b.ntiles = octoa ? (a.W + 31) / 32 : ntiles64;
+      // rows = layers per step (and 64 / rows wavenumbers per wave): the fewer the columns, the more rows
+      static const int rows_env = [] { const char *v = std::getenv("BARTRT_ALLR_ROWS"); return v && *v ? atoi(v) : 0; }();
+      int rows = kmode == "quad" ? 4 : kmode == "octo" ? 8 : kmode == "hexa" ? 16 : kmode == "r32" ? 32
+                 : columns <= kRows32AllMaxColumns ? 32 : columns <= kRows16AllMaxColumns ? 16
+                 : columns <= kOctoAllMaxColumns ? 8 : 4;
+      if (rows_env == 4 || rows_env == 8 || rows_env == 16 || rows_env == 32) rows = rows_env;
+      const bool lpa_forced = lp_forced || kmode == "hexa" || kmode == "r32";
+      while (rows > 4 && b.window && !window_fits(a, rows)) rows /= 2;
+      if (!use_rays && (lpa_forced || (kmode.empty() && columns <= kQuadAllMaxColumns)) && a.cia_bytes < (1ull << 32) - 4096 &&
+          (!b.window || window_fits(a, rows))) {
+        const int wnw = 64 / rows;   // wavenumbers per wave
+        b.ntiles = (a.W + 4 * wnw - 1) / (4 * wnw);
         const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
-        const size_t shq = sh + shp;
+        const size_t shq = sh + shp + (rows >= 16 ? sizeof(double) * (size_t)a.L : 0);   // (padded records: NCS)
         if (info) {
-          info->kernel = octoa ? "rt_eclipse_quad<R=8, all rays per lane>" : "rt_eclipse_quad<R=4, all rays per lane>";
-          info->wn_per_column = octoa ? 8 : 16; info->ncolumns = 4 * b.ntiles;
+          info->kernel = rows == 32 ? "rt_eclipse_quad<R=32, all rays per lane>" : rows == 16 ? "rt_eclipse_quad<R=16, all rays per lane>"
+                         : rows == 8 ? "rt_eclipse_quad<R=8, all rays per lane>" : "rt_eclipse_quad<R=4, all rays per lane>";
+          info->wn_per_column = wnw; info->ncolumns = 4 * b.ntiles;
         }
+#define BARTRT_QUADALL_R(MM, CC, RR)                                                                                         \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, RR, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b); \
+      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, RR, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);
 #define BARTRT_QUADALL(MM, CC)                                                                                               \
   if (a.M == MM && a.C == CC) {                                                                                              \
-    if (octoa) {                                                                                                             \
-      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, 8, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);  \
-      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 8, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);    \
-    } else {                                                                                                                 \
-      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, 4, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);  \
-      else BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, false, 4, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b);    \
-    }                                                                                                                        \
+    if (rows == 32) { BARTRT_QUADALL_R(MM, CC, 32) }                                                                         \
+    else if (rows == 16) { BARTRT_QUADALL_R(MM, CC, 16) }                                                                    \
+    else if (rows == 8) { BARTRT_QUADALL_R(MM, CC, 8) }                                                                      \
+    else { BARTRT_QUADALL_R(MM, CC, 4) }                                                                                     \
     err = hipGetLastError();                                                                                                 \
     return true;                                                                                                             \
   }
         BARTRT_MC_LIST(BARTRT_QUADALL)
 #undef BARTRT_QUADALL
+#undef BARTRT_QUADALL_R
       }
     }
     if (use_rays && fits32) {

@@ -42,8 +42,8 @@ def check(cfg, profs, what, clouds=(None,)):
             engine.walked_begin(); engine.run_batch(profs); kname = engine.walked_end()[2]
             assert "slant" in kname.lower() or "per lane" in kname, kname
             km = os.environ.get("BARTRT_KERNEL")
-            assert ("per lane" in kname) == (km in ("quad", "octo", "quadrays", "octorays")), kname
-            assert ("all rays per lane" in kname) == (km in ("quad", "octo") and INTEG == 1), kname
+            assert ("per lane" in kname) == (km in ("quad", "octo", "hexa", "r32", "quadrays", "octorays")), kname
+            assert ("all rays per lane" in kname) == (km in ("quad", "octo", "hexa", "r32") and INTEG == 1), kname
             assert ("team" in kname) == (os.environ.get("BARTRT_KERNEL") == "team"), kname
         for ct in clouds:
             if ct is not None:
@@ -100,12 +100,14 @@ print("ok")
 @pytest.mark.parametrize("cut,integ,kernel", [("vertical", 1, "mono_ilp"), ("slant", 1, "mono_ilp"), ("slant", 0, "mono_ilp"),
                                               ("slant", 2, "mono_ilp"), ("slant", 1, "quad"), ("slant", 0, "quad"),
                                               ("slant", 2, "quad"), ("slant", 1, "team"), ("slant", 1, "octo"),
-                                              ("slant", 1, "quadrays"), ("slant", 1, "octorays")])
+                                              ("slant", 1, "quadrays"), ("slant", 1, "octorays"), ("slant", 1, "hexa"),
+                                              ("slant", 1, "r32")])
 @pytest.mark.parametrize("mode", ["lengths", "cuts", "zero"])
 def test_simpson_single_wave_kernel(tmp_path, mode, cut, integ, kernel):
     """(cut slant: the same sweeps through rt_eclipse_simpson_slant / rt_eclipse_fast<SLANT>, where every ray
     angle ends on its own layer -- the deaths, pads and decks of five rays land on every block position -- and,
-    kernel = quad / octo, through the layer-parallel walk with all rays per lane (rule 1: rt_eclipse_quad<..., ALLR>) or
+    kernel = quad / octo / hexa / r32, through the layer-parallel walk with all rays per lane (rule 1: rt_eclipse_quad<..., ALLR>,
+    4 / 8 / 16 / 32 layers per step) or
     one ray per lane (rules 0 / 2, and rule 1 as quadrays / octorays: <..., RAYS>); kernel = team, through the three waves
     per column of rt_eclipse_slant_team.)"""
     env = dict(os.environ, BARTRT_KERNEL=kernel)

@@ -1,6 +1,6 @@
 """Launch time of the eclipse RT kernel against batch size for small batches (kernel choice per cut).
 usage (GPU box): python tools/ab_small.py [walkers ...]   -- BARTRT_KERNEL / BARTRT_CUT in the environment;
-AB_NWAVE=5000: a shorter grid of the bench shape; AB_CASE=demo: the demo shape (2 501 samples, one molecule)"""
+AB_NWAVE=5000 / AB_NLAYERS=50: a shorter grid / fewer layers of the bench shape; AB_CASE=demo: the demo shape (2 501 samples, one molecule)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,13 +10,14 @@ import bench
 from bart_amd import engine, synth, transit_module as trm
 import tempfile
 NW = int(os.environ.get("AB_NWAVE", "10000"))
+NL = int(os.environ.get("AB_NLAYERS", "100"))
 if os.environ.get("AB_CASE") == "demo":
     NW = 2501
     case = synth.make_case(os.path.join(tempfile.gettempdir(), "bartrt_demo_latency"), nlayers=100, nwave=2501, wnlow=2500.0,
                            opmol=("CH4",), seed=7, reuse=True)
 else:
-    wd = os.path.join(tempfile.gettempdir(), "bartrt_bench_single_survey8d" + ("" if NW == 10000 else "_%d" % NW))
-    case = synth.make_case(wd, nlayers=100, nwave=NW, kappa_model="survey8d", reuse=True)
+    wd = os.path.join(tempfile.gettempdir(), "bartrt_bench_single_survey8d" + ("" if NW == 10000 else "_%d" % NW) + ("" if NL == 100 else "_L%d" % NL))
+    case = synth.make_case(wd, nlayers=NL, nwave=NW, kappa_model="survey8d", reuse=True)
 engine.init(case.tcfg)
 for n in [int(x) for x in (sys.argv[1:] or "1 2 3 4 6 8 10".split())]:
     profs = bench.make_profiles(case, n * 8, seed=3).reshape(8, n, -1)

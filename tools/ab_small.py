@@ -11,13 +11,14 @@ from bart_amd import engine, synth, transit_module as trm
 import tempfile
 NW = int(os.environ.get("AB_NWAVE", "10000"))
 NL = int(os.environ.get("AB_NLAYERS", "100"))
+TD = float(os.environ.get("AB_TEMPDELT", "100"))   # 2600: two temperature planes, shared by every walker (a 64 MB grid)
 if os.environ.get("AB_CASE") == "demo":
     NW = 2501
     case = synth.make_case(os.path.join(tempfile.gettempdir(), "bartrt_demo_latency"), nlayers=100, nwave=2501, wnlow=2500.0,
                            opmol=("CH4",), seed=7, reuse=True)
 else:
-    wd = os.path.join(tempfile.gettempdir(), "bartrt_bench_single_survey8d" + ("" if NW == 10000 else "_%d" % NW) + ("" if NL == 100 else "_L%d" % NL))
-    case = synth.make_case(wd, nlayers=NL, nwave=NW, kappa_model="survey8d", reuse=True)
+    wd = os.path.join(tempfile.gettempdir(), "bartrt_bench_single_survey8d" + ("" if NW == 10000 else "_%d" % NW) + ("" if NL == 100 else "_L%d" % NL) + ("" if TD == 100 else "_T%d" % TD))
+    case = synth.make_case(wd, nlayers=NL, nwave=NW, kappa_model="survey8d", tempdelt=TD, reuse=True)
 engine.init(case.tcfg)
 for n in [int(x) for x in (sys.argv[1:] or "1 2 3 4 6 8 10".split())]:
     profs = bench.make_profiles(case, n * 8, seed=3).reshape(8, n, -1)

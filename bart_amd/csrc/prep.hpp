@@ -13,6 +13,10 @@ __device__ inline int bracket_dev(const double *g, const double *ginv, int n, do
   if (n <= 2) return 0;
   double x = (t - g[0]) * ginv[0];
   int j = x > 0.0 ? (x < (double)(n - 2) ? (int)x : n - 2) : 0;
+  // both ends of the guessed interval in one trip to LDS: on a uniform grid the guess is the bracket, and the two
+  // walks below -- a dependent LDS read per test, two even when nothing moves -- are skipped
+  const double a = g[j], b = g[j + 1];
+  if ((j == n - 2 || b > t) && (j == 0 || a <= t)) return j;
   while (j < n - 2 && g[j + 1] <= t) j++;
   while (j > 0 && g[j] > t) j--;
   return j;
@@ -95,25 +99,42 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
       r += 0.5 * (sT[ix] / sMu[ix] + t0 / m0) * (rgas * p.ref_lnp / p.gsurf);
     }
     // blocks of 8 terms are fetched from LDS ahead of the dependent chain
+    // (the NEXT block's terms are requested before the current block's chain starts: the LDS trip runs under it)
     if (threadIdx.x == 0) {
       sR[ix] = r;
       int i = ix - 1;
-      for (; i >= 7; i -= 8) {
-        double h[8];
+      double h[8], hn[8];
+      if (i >= 7) {
 #pragma unroll
         for (int j = 0; j < 8; j++) h[j] = sH[i - j];
+      }
+      for (; i >= 7; i -= 8) {
+        if (i - 8 >= 7) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) hn[j] = sH[i - 8 - j];
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) { r = fma(-h[j], r * r, r); sR[i - j] = r; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[j] = hn[j];
       }
       for (; i >= 0; i--) { r = fma(-sH[i], r * r, r); sR[i] = r; }
     } else {
       int i = ix + 1;
-      for (; i + 7 < L; i += 8) {
-        double h[8];
+      double h[8], hn[8];
+      if (i + 7 < L) {
 #pragma unroll
         for (int j = 0; j < 8; j++) h[j] = sH[i + j - 1];
+      }
+      for (; i + 7 < L; i += 8) {
+        if (i + 8 + 7 < L) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) hn[j] = sH[i + 8 + j - 1];
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) { r = fma(h[j], r * r, r); sR[i + j] = r; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[j] = hn[j];
       }
       for (; i < L; i++) { r = fma(sH[i - 1], r * r, r); sR[i] = r; }
     }

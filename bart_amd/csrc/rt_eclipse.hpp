@@ -64,6 +64,9 @@ constexpr long kOctoRaysMaxColumns = 40;
 //     two walkers = 314 columns: R = 8 58.4, single wave 58.0
 constexpr long kQuadAllMaxColumns = 256, kOctoAllMaxColumns = 256;    // eight layers per step up to here (R = 4: BARTRT_KERNEL=quad only)
 constexpr long kRows16AllMaxColumns = 128, kRows32AllMaxColumns = 64;  // sixteen / thirty-two layers per step (BARTRT_KERNEL=hexa / r32)
+// ... one or two table molecules (the demo shape: lighter steps, the rounds cost less than the longer walk): by the
+// demo-shape figures above, 32 rows to 96 columns, 16 rows to 176
+constexpr long kRows16AllMaxColumnsFewMol = 176, kRows32AllMaxColumnsFewMol = 96;
 // `cut slant`, rule 1: a team of three waves per column (rt_eclipse_s1t.hpp) for ONE walker's worth of columns at
 // W = 1e4 -- 44 against the single-wave kernel's 58 us; from two walkers on the team loses (59 / 59, four walkers 76 /
 // 61, ten 135 / 98, 64: 639 / 429 us): its producer wave keeps its table loads one layer ahead only (the 128
@@ -971,7 +974,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       // rows = layers per step (and 64 / rows wavenumbers per wave): the fewer the columns, the more rows
       static const int rows_env = [] { const char *v = std::getenv("BARTRT_ALLR_ROWS"); return v && *v ? atoi(v) : 0; }();
       int rows = kmode == "quad" ? 4 : kmode == "octo" ? 8 : kmode == "hexa" ? 16 : kmode == "r32" ? 32
-                 : columns <= kRows32AllMaxColumns ? 32 : columns <= kRows16AllMaxColumns ? 16
+                 : columns <= (a.M <= 2 ? kRows32AllMaxColumnsFewMol : kRows32AllMaxColumns) ? 32
+                 : columns <= (a.M <= 2 ? kRows16AllMaxColumnsFewMol : kRows16AllMaxColumns) ? 16
                  : columns <= kOctoAllMaxColumns ? 8 : 4;
       if (rows_env == 4 || rows_env == 8 || rows_env == 16 || rows_env == 32) rows = rows_env;
       const bool lpa_forced = lp_forced || kmode == "hexa" || kmode == "r32";

@@ -616,3 +616,36 @@ def test_cia_interpolated_by_splines(tmp_path, npairs, solution):
     open(bad, "w").write(open(c.tcfg).read().replace("cia_interp spline", "cia_interp cubic"))
     with pytest.raises(Exception, match="cia_interp"):
         engine.init(bad)
+
+
+def test_default_kernel_choice_under_cut_slant(demo_case, small_case):
+    """The launcher's table under the default conventions (csrc/rt_eclipse.hpp, rule 1, `cut slant`): the all-rays
+    layer-parallel kernel with 32 / 16 / 8 layers per step by the 64-wide columns of the launch -- to 96 / 176 / 256
+    columns on grids of one or two table molecules, 64 / 128 / 256 otherwise -- and the single-wave kernel beyond; every
+    choice against the oracle on two walkers' whole spectra."""
+    from bart_amd import engine, transit_module as trm
+    from oracle import rt_oracle as orc
+    # (case, walkers) -> columns = walkers * ceil(W / 64) and the kernel that goes with them
+    table = [(demo_case, 1, "R=32, all rays"), (demo_case, 2, "R=32, all rays"), (demo_case, 3, "R=16, all rays"),
+             (demo_case, 4, "R=16, all rays"), (demo_case, 5, "R=8, all rays"), (demo_case, 6, "R=8, all rays"),
+             (demo_case, 7, "rt_eclipse_simpson_slant"),
+             (small_case, 1, "R=32, all rays"), (small_case, 4, "R=32, all rays"), (small_case, 5, "R=16, all rays"),
+             (small_case, 9, "R=16, all rays"), (small_case, 10, "R=8, all rays"), (small_case, 19, "R=8, all rays"),
+             (small_case, 20, "rt_eclipse_simpson_slant")]
+    for case in (demo_case, small_case):
+        engine.init(case.tcfg)
+        try:
+            assert trm.get_cut() == "slant" and trm.get_integ() == 1
+            o = orc.OracleEngine(case.tcfg)
+            for c, n, want in table:
+                if c is not case:
+                    continue
+                profs = walkers(case, n, seed=60 + n)
+                engine.walked_begin()
+                got = engine.run_batch(profs)
+                kname = engine.walked_end()[2]
+                assert want in kname, (n, kname)
+                ref = o.run_batch(profs[:2])
+                np.testing.assert_allclose(got[:2], ref, rtol=RTOL, atol=1e-12 * np.abs(ref).max(), err_msg=kname)
+        finally:
+            trm.free_memory()

@@ -12,8 +12,8 @@ LIB = os.path.join(HERE, "libbartrt.so")
 CLI = os.path.join(HERE, "transit")
 SOURCES = ["rt_eclipse_angles.hip", "rt_eclipse_slant_ilp.hip", "rt_eclipse_team.hip", "rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
            "transit_geom.hip",
-           "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "share.hip", "io.cpp"]   # longest first
-HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "rt_eclipse_s1t.hpp", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp", "share.hpp",
+           "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "share.hip", "svc.hip", "io.cpp"]   # longest first
+HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "rt_eclipse_s1t.hpp", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp", "share.hpp", "svc.hpp", "svc_core.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
 
 

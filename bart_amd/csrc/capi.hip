@@ -8,10 +8,21 @@
 #include "lbl.hpp"
 #include "share.hpp"
 #include "step.hpp"
+#include "svc.hpp"
+
+#include <climits>
+#include <cstdlib>
+
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace bartrt;
 
+// One of two shapes per process: an engine of its own (g_eng), or -- `shareOpacity` as the chain service,
+// svc.hpp -- a client slot (g_cli) of the engine some worker process of the run owns (g_svc set in that one).
 static Engine *g_eng = nullptr;
+static ChainService *g_svc = nullptr;
+static svc::Client *g_cli = nullptr;
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string &m) {
@@ -27,13 +38,136 @@ static int guarded(F &&f) {
     return fail(BARTRT_EIO, e.msg);
   } catch (const HipError &e) {
     return fail(BARTRT_ENODEV, std::string(e.what) + ": " + hipGetErrorString(e.e));
+  } catch (const svc::Error &e) {
+    return fail(e.code, e.msg);
   } catch (const std::exception &e) {
     return fail(BARTRT_EINVAL, e.what());
   }
 }
 
-#define NEED_ENGINE() \
-  if (!g_eng) return fail(BARTRT_EINVAL, "engine not initialised: call bartrt_init first")
+#define NEED_ENGINE()                                                                                              \
+  if (!g_eng)                                                                                                      \
+  return g_cli ? fail(BARTRT_ENOTSUP, std::string(__func__) +                                                      \
+                                          ": this process is a client of the shareOpacity chain service (the engine lives in " \
+                                          "process " + std::to_string(g_cli->seg.hdr()->owner_pid.load()) +         \
+                                          "); the reference module's eight calls and the plain getters are served -- " \
+                                          "BARTRT_SHARE_MODE=ipc (or off) gives every process its own engine")      \
+               : fail(BARTRT_EINVAL, "engine not initialised: call bartrt_init first")
+// the calls a service client answers itself
+#define CLIENT_OR_ENGINE() \
+  if (!g_eng && !g_cli) return fail(BARTRT_EINVAL, "engine not initialised: call bartrt_init first")
+
+// ---- start-up: which shape this process takes ---------------------------
+namespace {
+
+struct InitArgs {
+  std::string cfile;
+  int shard_rank = 0, shard_n = 1, device = -1;
+  bool no_service = false;
+};
+
+InitArgs parse_init_args(int argc, const char **argv) {
+  InitArgs a;
+  for (int i = 1; i < argc; i++) {
+    const std::string s = argv[i];
+    if ((s == "-c" || s == "--config_file") && i + 1 < argc) a.cfile = argv[++i];
+    else if (s == "--shard" && i + 2 < argc) { a.shard_rank = std::atoi(argv[++i]); a.shard_n = std::atoi(argv[++i]); }
+    else if (s == "--device" && i + 1 < argc) a.device = std::atoi(argv[++i]);
+    else if (s == "--no-service") a.no_service = true;
+  }
+  return a;
+}
+
+std::string service_key(const InitArgs &a) {
+  struct stat st;
+  if (stat(a.cfile.c_str(), &st) != 0) throw IoError{"cannot open configuration file '" + a.cfile + "'"};
+  char rp[PATH_MAX];
+  const std::string real = realpath(a.cfile.c_str(), rp) ? std::string(rp) : a.cfile;
+  // (no HIP call here: a client never makes one -- the GPU is named by what selects it)
+  const char *lr = std::getenv("LOCAL_RANK"), *hv = std::getenv("HIP_VISIBLE_DEVICES"), *rv = std::getenv("ROCR_VISIBLE_DEVICES");
+  const std::string dev = a.device >= 0 ? std::to_string(a.device) : std::string(lr ? lr : "0");
+  return real + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtime) + "|" +
+         std::to_string((long long)getuid()) + "|dev " + dev + "|hip " + (hv ? hv : "") + "|rocr " + (rv ? rv : "") +
+         "|shard " + std::to_string(a.shard_rank) + "/" + std::to_string(a.shard_n) + "|svc v2";
+}
+
+std::string what_failed() {
+  try {
+    throw;
+  } catch (const IoError &e) { return e.msg;
+  } catch (const HipError &e) { return std::string(e.what) + ": " + hipGetErrorString(e.e);
+  } catch (const svc::Error &e) { return e.msg;
+  } catch (const std::exception &e) { return e.what();
+  } catch (...) { return "unknown error"; }
+}
+
+void teardown(double wait_s) {
+  if (g_cli) {
+    g_cli->detach();
+    g_cli->seg.unmap();
+    delete g_cli;
+    g_cli = nullptr;
+  }
+  if (g_svc) {
+    ChainService *s = g_svc;
+    g_svc = nullptr;
+    s->shutdown(wait_s);
+  }
+  if (g_eng) {
+    (void)hipDeviceSynchronize();
+    delete g_eng;
+    g_eng = nullptr;
+  }
+}
+
+// a process that exits without trm.free_memory(): the dispatcher thread must not outlive the HIP runtime
+void at_exit() {
+  try { teardown(0.0); } catch (...) {}
+}
+
+void start_service(int argc, const char **argv, const InitArgs &ia) {
+  const std::string name = svc::hashed_name("bartrt_svc_", service_key(ia));
+  svc::Segment seg;
+  const bool owner = svc::elect(name, seg);
+  auto *cli = new svc::Client;
+  try {
+    if (owner) {
+      Engine *e = new Engine();
+      e->share_mode = kShareOff;      // (the grid is this process's own: nobody maps it)
+      try {
+        e->init(argc, argv);
+        g_svc = ChainService::start(std::move(seg), e);
+      } catch (...) {
+        const std::string why = what_failed();
+        svc::retire(seg, why.c_str());
+        seg.unmap();
+        delete e;
+        throw;
+      }
+      static bool hooked = false;
+      if (!hooked) { std::atexit(at_exit); hooked = true; }
+      // this process's own calls go through a slot like everybody's (a second mapping of the segment)
+      cli->seg.name = name;
+      cli->seg.fd = shm_open(name.c_str(), O_RDWR | O_CLOEXEC, 0600);
+      if (cli->seg.fd < 0) throw svc::Error{BARTRT_EIO, "shareOpacity: cannot reopen " + name};
+      cli->seg.remap(g_svc->seg.hdr()->total_bytes);
+      cli->attach(false);
+      svc::open_for_clients(g_svc->seg);
+    } else {
+      cli->seg = seg;
+      cli->attach(true);
+    }
+  } catch (...) {
+    cli->detach();
+    cli->seg.unmap();
+    delete cli;
+    if (g_svc) { ChainService *s = g_svc; g_svc = nullptr; s->shutdown(0.0); }
+    throw;
+  }
+  g_cli = cli;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -42,9 +176,16 @@ const char *bartrt_last_error(void) { return g_err.c_str(); }
 int bartrt_init(int argc, const char **argv) {
   if (argc < 1 || !argv) return fail(BARTRT_EINVAL, "bartrt_init: empty argv");
   return guarded([&] {
-    delete g_eng;
-    g_eng = nullptr;
+    teardown(svc::env_num("BARTRT_SHARE_WAIT_S", 60.0));
+    const InitArgs ia = parse_init_args(argc, argv);
+    if (ia.cfile.empty()) throw IoError{"transit_init: no '-c <configuration file>' in argv"};
+    const int mode = resolve_share_mode(read_tcfg(ia.cfile), ia.no_service);
+    if (mode == kShareService) {
+      start_service(argc, argv, ia);
+      return BARTRT_OK;
+    }
     Engine *e = new Engine();
+    e->share_mode = mode;
     try {
       e->init(argc, argv);
     } catch (...) {
@@ -58,42 +199,46 @@ int bartrt_init(int argc, const char **argv) {
 
 int bartrt_free_memory(void) {
   return guarded([&] {
-    if (g_eng) (void)hipDeviceSynchronize();
-    delete g_eng;
-    g_eng = nullptr;
+    // (the owner of a chain service keeps serving until the other workers have let go, BARTRT_SHARE_WAIT_S at most)
+    teardown(svc::env_num("BARTRT_SHARE_WAIT_S", 60.0));
     return BARTRT_OK;
   });
 }
 
 int bartrt_get_no_samples(void) {
-  NEED_ENGINE();
-  return g_eng->Wfull;
+  CLIENT_OR_ENGINE();
+  return g_cli ? g_cli->info.Wfull : g_eng->Wfull;
 }
 
 int bartrt_get_waveno_arr(double *out, int n) {
-  NEED_ENGINE();
-  if (!out || n != g_eng->Wfull) return fail(BARTRT_EINVAL, "get_waveno_arr: n must equal get_no_samples()");
-  std::memcpy(out, g_eng->wn_full.data(), sizeof(double) * n);
+  CLIENT_OR_ENGINE();
+  const std::vector<double> &wn = g_cli ? g_cli->info.wn_full : g_eng->wn_full;
+  if (!out || n != (int)wn.size()) return fail(BARTRT_EINVAL, "get_waveno_arr: n must equal get_no_samples()");
+  std::memcpy(out, wn.data(), sizeof(double) * n);
   return BARTRT_OK;
 }
 
+// (a service client keeps its setters to itself: they ride with each of ITS profiles, per walker of the batch)
 int bartrt_set_radius(double r_km) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
   if (!(r_km > 0)) return fail(BARTRT_EINVAL, "set_radius: radius must be positive");
-  g_eng->refradius = r_km * 1e5;
+  if (g_cli) g_cli->over[0] = r_km * 1e5;
+  else g_eng->refradius = r_km * 1e5;
   return BARTRT_OK;
 }
 
 int bartrt_set_cloudtop(double logp) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
+  if (g_cli) { g_cli->over[1] = std::pow(10.0, logp) * 1e6; return BARTRT_OK; }
   g_eng->has_cloud = 1;
   g_eng->cloudtop = std::pow(10.0, logp) * 1e6;
   return BARTRT_OK;
 }
 
 int bartrt_set_scattering(int flag, double value) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
   if (flag < 0 || flag > 2) return fail(BARTRT_EINVAL, "set_scattering: flag must be 0, 1 or 2");
+  if (g_cli) { g_cli->scat_flag = flag; g_cli->over[2] = value; return BARTRT_OK; }
   g_eng->scat_flag = flag;
   g_eng->scat_value = value;
   return BARTRT_OK;
@@ -114,21 +259,26 @@ int bartrt_set_cut(int slant) {
 }
 
 int bartrt_get_cut(int *slant) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
   if (!slant) return fail(BARTRT_EINVAL, "get_cut: null output pointer");
-  *slant = g_eng->cut_slant ? 1 : 0;
+  *slant = g_cli ? g_cli->info.cut_slant : (g_eng->cut_slant ? 1 : 0);
   return BARTRT_OK;
 }
 
 int bartrt_get_cia_interp(int *spline) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
   if (!spline) return fail(BARTRT_EINVAL, "get_cia_interp: null output pointer");
-  *spline = g_eng->cia_spline ? 1 : 0;
+  *spline = g_cli ? g_cli->info.cia_spline : (g_eng->cia_spline ? 1 : 0);
   return BARTRT_OK;
 }
 
 int bartrt_get_share(int *shared, int *owner) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
+  if (g_cli) {
+    if (shared) *shared = 1;
+    if (owner) *owner = g_svc ? 1 : 0;
+    return BARTRT_OK;
+  }
   if (shared) *shared = g_eng->kappa_share ? 1 : 0;
   if (owner) *owner = (g_eng->kappa_share && g_eng->kappa_share->owner) ? 1 : 0;
   return BARTRT_OK;
@@ -143,44 +293,95 @@ int bartrt_prefetch_profiles_dev(const double *d_prof_next, int nwalkers) {
 }
 
 int bartrt_get_integ(int *rule) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
   if (!rule) return fail(BARTRT_EINVAL, "get_integ: null output pointer");
-  *rule = g_eng->integ;
+  *rule = g_cli ? g_cli->info.integ : g_eng->integ;
   return BARTRT_OK;
 }
 
-int bartrt_get_nlayers(void) { NEED_ENGINE(); return g_eng->L; }
-int bartrt_get_nspecies(void) { NEED_ENGINE(); return g_eng->S; }
-int bartrt_get_nprof(void) { NEED_ENGINE(); return (g_eng->S + 1) * g_eng->L; }
+int bartrt_get_service(int *mode, int *owner_pid, int *slot, int *nclients) {
+  CLIENT_OR_ENGINE();
+  if (g_cli) {
+    const svc::Header *h = g_cli->seg.hdr();
+    if (mode) *mode = g_svc ? 2 : 1;
+    if (owner_pid) *owner_pid = h->owner_pid.load();
+    if (slot) *slot = g_cli->slot;
+    if (nclients) {
+      int n = 0;
+      for (int i = 0; i < h->maxclients; i++) n += g_cli->seg.slot(i)->pid.load() != 0;
+      *nclients = n;
+    }
+  } else {
+    if (mode) *mode = 0;
+    if (owner_pid) *owner_pid = (int)getpid();
+    if (slot) *slot = -1;
+    if (nclients) *nclients = 0;
+  }
+  return BARTRT_OK;
+}
+
+int bartrt_get_service_stats(unsigned long long *nlaunches, unsigned long long *nprofiles, unsigned long long *nfull) {
+  if (!g_cli) return fail(BARTRT_EINVAL, "get_service_stats: this process is not on a chain service");
+  const svc::Header *h = g_cli->seg.hdr();
+  if (nlaunches) *nlaunches = h->nbatches.load();
+  if (nprofiles) *nprofiles = h->nserved.load();
+  if (nfull) *nfull = h->nfull.load();
+  return BARTRT_OK;
+}
+
+int bartrt_get_nlayers(void) { CLIENT_OR_ENGINE(); return g_cli ? g_cli->info.L : g_eng->L; }
+int bartrt_get_nspecies(void) { CLIENT_OR_ENGINE(); return g_cli ? g_cli->info.S : g_eng->S; }
+int bartrt_get_nprof(void) { CLIENT_OR_ENGINE(); return g_cli ? g_cli->info.nprof() : (g_eng->S + 1) * g_eng->L; }
 
 int bartrt_get_local_range(int *lo, int *hi) {
-  NEED_ENGINE();
-  if (lo) *lo = g_eng->lo;
-  if (hi) *hi = g_eng->hi;
+  CLIENT_OR_ENGINE();
+  if (lo) *lo = g_cli ? g_cli->info.lo : g_eng->lo;
+  if (hi) *hi = g_cli ? g_cli->info.hi : g_eng->hi;
   return BARTRT_OK;
 }
 
 int bartrt_get_species(char *buf, int buflen) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
   std::string s;
-  for (auto &n : g_eng->atm.species) s += (s.empty() ? "" : " ") + n;
+  if (g_cli) s = g_cli->info.species;
+  else for (auto &n : g_eng->atm.species) s += (s.empty() ? "" : " ") + n;
   if (!buf || (int)s.size() + 1 > buflen) return fail(BARTRT_EINVAL, "get_species: buffer too small");
   std::memcpy(buf, s.c_str(), s.size() + 1);
   return BARTRT_OK;
 }
 
 int bartrt_get_pressure(double *out, int n) {
-  NEED_ENGINE();
-  if (!out || n != g_eng->L) return fail(BARTRT_EINVAL, "get_pressure: n must equal the layer count");
-  std::memcpy(out, g_eng->atm.press.data(), sizeof(double) * n);
+  CLIENT_OR_ENGINE();
+  const std::vector<double> &press = g_cli ? g_cli->info.press : g_eng->atm.press;
+  if (!out || n != (int)press.size()) return fail(BARTRT_EINVAL, "get_pressure: n must equal the layer count");
+  std::memcpy(out, press.data(), sizeof(double) * n);
   return BARTRT_OK;
 }
 
 // host-buffer calls up to this size skip the staging copies (see below)
 static constexpr size_t kZeroCopyBytes = 512 * 1024;
 
+// trm.run_transit of a chain-service client: the profile goes into this process's slot, the dispatcher of the
+// owning process launches it together with the other workers' (svc_core.hpp); a batch from ONE client is posted
+// profile by profile (the batched callers own their engine: bart_amd.engine initialises with --no-service)
+static int client_run(const double *prof, int nwalkers, int nprof, double *spec, int nwave, unsigned char *ok) {
+  svc::Client *c = g_cli;
+  if (!prof || !spec || nwalkers < 0) return fail(BARTRT_EINVAL, "run_transit: null buffer");
+  if (nprof != c->info.nprof()) return fail(BARTRT_EINVAL, "run_transit: profile length must be (nspecies+1)*nlayers");
+  const int Wl = c->info.Wl();
+  if (nwave != Wl && nwave != c->info.Wfull)
+    return fail(BARTRT_EINVAL, "run_transit: nwave must equal get_no_samples() (or the shard size)");
+  return guarded([&] {
+    const size_t off = nwave == Wl ? 0 : (size_t)c->info.lo;
+    for (int w = 0; w < nwalkers; w++)
+      c->call(prof + (size_t)w * nprof, spec + (size_t)w * nwave + off, ok ? ok + w : nullptr);
+    return BARTRT_OK;
+  });
+}
+
 int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
                              double *spec, int nwave, unsigned char *ok) {
+  if (g_cli) return client_run(prof, nwalkers, nprof, spec, nwave, ok);
   NEED_ENGINE();
   Engine *e = g_eng;
   if (!prof || !spec || nwalkers < 0) return fail(BARTRT_EINVAL, "run_transit: null buffer");
@@ -278,7 +479,12 @@ int bartrt_get_tau_of(int walker, double *tau, int *last, int nwave, int nlayers
 }
 
 int bartrt_get_atm_profile(double *prof, int nprof) {
-  NEED_ENGINE();
+  CLIENT_OR_ENGINE();
+  if (g_cli) {
+    if (!prof || nprof != g_cli->info.nprof()) return fail(BARTRT_EINVAL, "get_atm_profile: bad length");
+    std::memcpy(prof, g_cli->info.atm_prof.data(), sizeof(double) * nprof);
+    return BARTRT_OK;
+  }
   Engine *e = g_eng;
   if (!prof || nprof != (e->S + 1) * e->L) return fail(BARTRT_EINVAL, "get_atm_profile: bad length");
   for (int l = 0; l < e->L; l++) {
@@ -298,7 +504,7 @@ int bartrt_get_radius(double *rad, int nlayers) {
   });
 }
 
-int bartrt_get_nangles(void) { NEED_ENGINE(); return g_eng->A; }
+int bartrt_get_nangles(void) { CLIENT_OR_ENGINE(); return g_cli ? g_cli->info.A : g_eng->A; }
 
 int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
   NEED_ENGINE();
@@ -308,9 +514,10 @@ int bartrt_get_tau(double *tau, int *last, int nwave, int nlayers) {
 }
 
 int bartrt_get_angles(double *deg, int n) {
-  NEED_ENGINE();
-  if (!deg || n != g_eng->A) return fail(BARTRT_EINVAL, "get_angles: bad length");
-  std::memcpy(deg, g_eng->angles.data(), sizeof(double) * n);
+  CLIENT_OR_ENGINE();
+  const std::vector<double> &ang = g_cli ? g_cli->info.angles : g_eng->angles;
+  if (!deg || n != (int)ang.size()) return fail(BARTRT_EINVAL, "get_angles: bad length");
+  std::memcpy(deg, ang.data(), sizeof(double) * n);
   return BARTRT_OK;
 }
 

@@ -4,6 +4,7 @@
 #include "lbl.hpp"
 #include "share.hpp"
 #include "step.hpp"
+#include "svc.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -42,17 +43,42 @@ Engine::~Engine() {
 void Engine::init(int argc, const char **argv) {
   std::string cfile;
   int shard_rank = 0, shard_n = 1;
+  bool no_service = false;
   device = -1;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     if ((a == "-c" || a == "--config_file") && i + 1 < argc) cfile = argv[++i];
     else if (a == "--shard" && i + 2 < argc) { shard_rank = std::atoi(argv[++i]); shard_n = std::atoi(argv[++i]); }
     else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+    else if (a == "--no-service") no_service = true;
   }
   if (cfile.empty()) throw IoError{"transit_init: no '-c <configuration file>' in argv"};
   if (shard_n < 1 || shard_rank < 0 || shard_rank >= shard_n)
     throw IoError{"transit_init: bad --shard rank/nranks"};
-  setup(read_tcfg(cfile), shard_rank, shard_n);
+  const TCfg c = read_tcfg(cfile);
+  if (share_mode < 0) share_mode = resolve_share_mode(c, no_service);
+  if (share_mode == kShareService) share_mode = kShareIpc;   // (an engine of its own was asked for: capi.hip runs the service)
+  setup(c, shard_rank, shard_n);
+}
+
+int resolve_share_mode(const TCfg &cfg, bool no_service) {
+  auto truthy = [](const std::string &v) { return v != "0" && v != "no" && v != "false" && v != "False"; };
+  // (makeTransit writes the key bare -- code/makecfg.py:106-107: present without a value means yes)
+  bool on = false;
+  if (auto it = cfg.find("shareOpacity"); it != cfg.end()) on = truthy(it->second);
+  if (const char *e = std::getenv("BARTRT_SHARE_OPACITY")) if (*e) on = std::string(e) != "0";
+  int mode = kShareService;
+  if (const char *e = std::getenv("BARTRT_SHARE_MODE")) if (*e) {
+    const std::string v = e;
+    if (v == "service") mode = kShareService;
+    else if (v == "ipc") mode = kShareIpc;
+    else if (v == "off" || v == "0" || v == "none") mode = kShareOff;
+    else throw IoError{"BARTRT_SHARE_MODE: '" + v + "' is none of service, ipc, off"};
+  }
+  if (const char *e = std::getenv("BARTRT_SERVICE")) if (*e && std::string(e) != "0") { on = true; mode = kShareService; }
+  if (!on) return kShareOff;
+  if (mode == kShareService && no_service) mode = kShareIpc;
+  return mode;
 }
 
 int parse_integ(const std::string &v) {
@@ -106,6 +132,7 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
       gcfg.erase("opacityfile");
       Engine gen;
       gen.device = device;
+      gen.share_mode = kShareOff;
       gen.setup(gcfg, 0, 1);
       std::vector<double> tg;
       const double tlow = cfg_num(cfg, "tlow", 500.0), thigh = cfg_num(cfg, "thigh", 3000.0),
@@ -281,11 +308,8 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     // `shareOpacity` (code/makecfg.py:106-107: BART's worker processes share ONE opacity grid; a bare key in
     // the cfg makeTransit writes) or BARTRT_SHARE_OPACITY=1: the first process of this (file, device, block)
     // uploads the grid, the others map its HBM allocation through an IPC handle (share.hpp)
-    bool share = false;     // (makeTransit writes the key bare: present without a value means yes)
-    if (auto it = cfg.find("shareOpacity"); it != cfg.end())
-      share = it->second != "0" && it->second != "no" && it->second != "false" && it->second != "False";
-    if (const char *e = std::getenv("BARTRT_SHARE_OPACITY")) if (*e) share = std::string(e) != "0";
-    if (share) {
+    if (share_mode < 0) share_mode = resolve_share_mode(cfg, true);
+    if (share_mode == kShareIpc) {
       struct stat fst;
       if (stat(cfg["opacityfile"].c_str(), &fst) != 0) throw IoError{"opacity file: cannot stat " + cfg["opacityfile"]};
       char rp[PATH_MAX];

@@ -17,6 +17,9 @@ hipError_t launch_chord_table(const PrepArgs &a, hipStream_t st);  // transit ge
 hipError_t launch_grid_transpose(const double *src, double *dst, long planes, int M, int W, hipStream_t st);
 
 int parse_integ(const std::string &v);  // "0" / "transmittance", "1" / "simpson", "2" / "trapz_tau"
+// what `shareOpacity` means for this process (ShareMode, svc.hpp): cfg key, BARTRT_SHARE_OPACITY, BARTRT_SHARE_MODE,
+// BARTRT_SERVICE; no_service: the caller needs the engine in its own process (the service reading becomes IPC)
+int resolve_share_mode(const TCfg &cfg, bool no_service);
 
 struct TableShare;  // the opacity grid shared between processes (share.hpp)
 struct StepArgs;  // converters around the engine (step.hip)
@@ -47,6 +50,7 @@ struct Engine {
   double *d_kappa = nullptr, *d_cia = nullptr, *d_wn = nullptr, *d_wn_full = nullptr;
   double *d_press = nullptr, *d_mass = nullptr, *d_diam = nullptr;
   TableShare *kappa_share = nullptr;  // cfg `shareOpacity`: d_kappa is (or is mapped from) another process's allocation
+  int share_mode = -1;                // ShareMode (svc.hpp); -1: resolved from the cfg and the environment by setup()
   double *d_prep_consts = nullptr;  // PrepArgs::consts
   PrepArgs prep{};  // static part filled at init
   RtArgs rt{};

@@ -1,6 +1,8 @@
 // Host-side readers for the engine's input files (transit formats).
 #include "io.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -237,15 +239,106 @@ void read_opacity_rows(const std::string &path, const OpacityHeader &h, long lo,
   if (!ok) throw IoError{"short read from opacity file '" + path + "'"};
 }
 
+// Two layouts, told apart by the first line that is neither blank nor a comment:
+//  * a line starting with '@': the sectioned text layout (`@SPECIES`, `@TEMPERATURES`, `@DATA` rows of
+//    `wn alpha(T1) alpha(T2) ...`, cm-1 amagat-2) of the CIA files shipped with the reference's engine
+//    (examples/demo/BART_eclipse.cfg:119 names one; the files themselves are not in the checkout);
+//  * anything else: the HITRAN collision-induced-absorption layout, the only format the reference's manual
+//    names ("They must be in HITRAN cross-section format", doc/BART_user_manual/BART_user_manual.tex:506-510):
+//    per temperature a 100-column header -- symbol `A-B` [0,20), first and last wavenumber [20,30) [30,40),
+//    number of points [40,47), temperature [47,54), then maximum, resolution, comment, reference -- followed
+//    by that many `wavenumber  value` rows in cm5 molecule-2.  Converted on reading to the engine's cm-1
+//    amagat-2 (x Loschmidt^2, the constant the kernels divide the densities by).  All blocks of a file must
+//    be on one wavenumber grid (one spectral range per file); blocks are sorted by temperature.
+static Cia read_cia_hitran(std::ifstream &f, const std::string &path, std::string line) {
+  constexpr double kLoschmidt = 2.68679e19;     // = kAMAGAT (kernels.hpp)
+  Cia c;
+  struct Block { double T; std::vector<double> wn, v; };
+  std::vector<Block> blocks;
+  auto header = [&](const std::string &h, std::string &sym, double &w0, double &w1, long &n, double &T) {
+    auto num = [&](const std::string &x, double &out) {
+      const std::string t = trim(x);
+      if (t.empty()) return false;
+      char *end = nullptr;
+      out = std::strtod(t.c_str(), &end);
+      return end && *end == 0 && std::isfinite(out);
+    };
+    double dn = 0;
+    if (h.size() >= 54 && num(h.substr(20, 10), w0) && num(h.substr(30, 10), w1) && num(h.substr(40, 7), dn) &&
+        num(h.substr(47, 7), T)) {
+      sym = trim(h.substr(0, 20));
+    } else {
+      auto t = split_ws(h);      // (a hand-made file: the same fields separated by blanks)
+      if (t.size() < 5 || !num(t[1], w0) || !num(t[2], w1) || !num(t[3], dn) || !num(t[4], T))
+        throw IoError{"cross-section file '" + path + "': not a HITRAN CIA header: '" + trim(h).substr(0, 60) + "'"};
+      sym = t[0];
+    }
+    if (!(dn >= 2) || dn > 5e7 || dn != std::floor(dn)) throw IoError{"cross-section file '" + path + "': bad number of points in a block header"};
+    if (!(T > 0) || !(w1 > w0)) throw IoError{"cross-section file '" + path + "': bad temperature or spectral range in a block header"};
+    n = (long)dn;
+  };
+  std::string sym0;
+  for (;;) {
+    std::string sym;
+    double w0, w1, T;
+    long n;
+    header(line, sym, w0, w1, n, T);
+    if (sym0.empty()) sym0 = sym;
+    else if (sym != sym0) throw IoError{"cross-section file '" + path + "': blocks of different pairs (" + sym0 + ", " + sym + ")"};
+    Block b;
+    b.T = T;
+    b.wn.reserve((size_t)std::min<long>(n, 1 << 20)); b.v.reserve((size_t)std::min<long>(n, 1 << 20));
+    for (long i = 0; i < n; i++) {
+      if (!std::getline(f, line)) throw IoError{"cross-section file '" + path + "' is truncated (a block is shorter than its header says)"};
+      auto t = split_ws(line);
+      if (t.size() < 2) throw IoError{"cross-section file '" + path + "': a data row needs a wavenumber and a value"};
+      b.wn.push_back(to_num(t[0], path));
+      b.v.push_back(to_num(t[1], path) * kLoschmidt * kLoschmidt);
+      if (i && !(b.wn[i] > b.wn[i - 1])) throw IoError{"cross-section file '" + path + "': wavenumbers must increase within a block"};
+    }
+    blocks.push_back(std::move(b));
+    bool more = false;
+    while (std::getline(f, line)) {
+      const std::string s = trim(line);
+      if (!s.empty() && s[0] != '#') { more = true; break; }
+    }
+    if (!more) break;
+  }
+  const size_t dash = sym0.find('-');
+  if (dash == std::string::npos || dash == 0 || dash + 1 >= sym0.size())
+    throw IoError{"cross-section file '" + path + "': the pair must read A-B, not '" + sym0 + "'"};
+  c.s1 = sym0.substr(0, dash);
+  c.s2 = sym0.substr(dash + 1);
+  std::stable_sort(blocks.begin(), blocks.end(), [](const Block &a, const Block &b) { return a.T < b.T; });
+  for (size_t i = 0; i < blocks.size(); i++) {
+    if (i && blocks[i].T == blocks[i - 1].T)
+      throw IoError{"cross-section file '" + path + "': two blocks at one temperature (one spectral range per file)"};
+    if (blocks[i].wn != blocks[0].wn)
+      throw IoError{"cross-section file '" + path + "': the blocks are on different wavenumber grids (resample the file onto one)"};
+  }
+  const size_t nw = blocks[0].wn.size(), nt = blocks.size();
+  c.wn = blocks[0].wn;
+  c.temp.resize(nt);
+  c.alpha.resize(nt * nw);
+  for (size_t t = 0; t < nt; t++) {
+    c.temp[t] = blocks[t].T;
+    std::copy(blocks[t].v.begin(), blocks[t].v.end(), c.alpha.begin() + t * nw);
+  }
+  return c;
+}
+
 Cia read_cia(const std::string &path) {
   std::ifstream f(path);
   if (!f) throw IoError{"cannot open cross-section file '" + path + "'"};
   Cia c;
   std::string line, mode;
   std::vector<std::vector<double>> rows;
+  bool first = true;
   while (std::getline(f, line)) {
     std::string s = trim(line);
     if (s.empty() || s[0] == '#') continue;
+    if (first && s[0] != '@') return read_cia_hitran(f, path, line);
+    first = false;
     if (s[0] == '@') { mode = s; continue; }
     auto t = split_ws(s);
     if (mode == "@SPECIES" && c.s1.empty()) {

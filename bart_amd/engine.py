@@ -19,7 +19,10 @@ _check, _ptr = trm.check, trm._ptr
 
 
 def init(tcfg: str, shard: tuple[int, int] | None = None, device: int | None = None) -> None:
-    argv = ["transit", "-c", tcfg]
+    """An engine IN THIS PROCESS (this module's batched / device-resident calls need one): with `shareOpacity`
+    in the cfg the grid is shared through HIP IPC, never through the chain service (include/bartrt.h,
+    bartrt_get_share) -- the service is for the reference's one-profile-per-process workers."""
+    argv = ["transit", "-c", tcfg, "--no-service"]
     if shard is not None:
         argv += ["--shard", str(shard[0]), str(shard[1])]
     if device is not None:

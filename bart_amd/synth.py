@@ -106,7 +106,7 @@ def write_opacity(path: str, mol_ids, temps, press_barye, wn, kappa=None,
                 f.write(s.tobytes())
 
 
-def write_cia(path: str, s1: str, s2: str, temps, wn, alpha) -> None:
+def write_cia(path: str, s1: str, s2: str, temps, wn, alpha, fmt: str = "%.9e") -> None:
     """Cross-section (CIA) text file: ``@SPECIES`` pair, ``@TEMPERATURES`` row,
     ``@DATA`` rows of ``wn  alpha(T1) alpha(T2) ...`` in cm-1 amagat-2."""
     alpha = np.asarray(alpha, float)
@@ -116,7 +116,23 @@ def write_cia(path: str, s1: str, s2: str, temps, wn, alpha) -> None:
         f.write("@TEMPERATURES\n" + " ".join("%.1f" % t for t in temps) + "\n\n")
         f.write("# wavenumber (cm-1), absorption (cm-1 amagat-2)\n@DATA\n")
         for i, w in enumerate(wn):
-            f.write("%.4f " % w + " ".join("%.9e" % a for a in alpha[:, i]) + "\n")
+            f.write("%.4f " % w + " ".join(fmt % a for a in alpha[:, i]) + "\n")
+
+
+LOSCHMIDT = 2.68679e19     # cm-3 per amagat, the engine's constant (csrc/kernels.hpp kAMAGAT)
+
+
+def write_cia_hitran(path: str, s1: str, s2: str, temps, wn, k_cm5) -> None:
+    """A table in the HITRAN CIA layout (the format the reference's manual names for CS files,
+    doc/BART_user_manual/BART_user_manual.tex:506-510): one 100-column header + `wavenumber value` rows per
+    temperature; k_cm5[ntemp][nwn] in cm5 molecule-2 (x LOSCHMIDT^2 = write_cia's cm-1 amagat-2)."""
+    k = np.asarray(k_cm5, float)
+    with open(path, "w") as f:
+        for t, T in enumerate(temps):
+            f.write("%20s%10.3f%10.3f%7d%7.1f%10.3e%6.3f%27s%3d\n" % (
+                "%s-%s" % (s1, s2), wn[0], wn[-1], len(wn), T, k[t].max(), -.999, "synthetic (bart_amd.synth)", 0))
+            for w, a in zip(wn, k[t]):
+                f.write("%10.4f %.17e\n" % (w, a))
 
 
 def write_filter(path: str, wl_um, transm) -> None:

@@ -92,6 +92,8 @@ def lib():
         L.bartrt_get_cut.argtypes = [C.POINTER(i)]
         L.bartrt_get_cia_interp.argtypes = [C.POINTER(i)]
         L.bartrt_get_share.argtypes = [C.POINTER(i), C.POINTER(i)]
+        L.bartrt_get_service.argtypes = [C.POINTER(i)] * 4
+        L.bartrt_get_service_stats.argtypes = [C.POINTER(C.c_ulonglong)] * 3
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
@@ -112,10 +114,18 @@ def _ptr(a: np.ndarray):
 
 
 # ---- the eight reference entry points ----------------------------------
+_whole_grid = False      # this process's engine writes every sample of a spectrum (no --shard)
+
+
 def transit_init(argc, argv):
+    global _whole_grid
     args = [str(a).encode() for a in argv][:argc]
     arr = (C.c_char_p * len(args))(*args)
+    _whole_grid = False
     check(lib().bartrt_init(len(args), arr))
+    lo, hi = C.c_int(0), C.c_int(0)
+    check(lib().bartrt_get_local_range(C.byref(lo), C.byref(hi)))
+    _whole_grid = lo.value == 0 and hi.value == lib().bartrt_get_no_samples()
 
 
 def get_no_samples():
@@ -142,9 +152,14 @@ def set_scattering(flag, value):
 
 def run_transit(profiles, nwave):
     """profiles: flat (nspecies+1)*nlayers doubles -> new ndarray[nwave]."""
+    # (the per-call cost of this wrapper is part of every MCMC step: ~3 us as written -- plain integer addresses
+    # instead of ctypes pointer objects, no clearing of an array the engine fills completely)
     prof = np.ascontiguousarray(profiles, np.double).ravel()
-    spec = np.zeros(int(nwave), np.double)
-    check(lib().bartrt_run_transit(_ptr(prof), prof.size, _ptr(spec), int(nwave)))
+    nwave = int(nwave)
+    spec = np.empty(nwave, np.double) if _whole_grid else np.zeros(nwave, np.double)   # (a shard writes its block only)
+    rc = (_lib or lib()).bartrt_run_transit(prof.ctypes.data, prof.size, spec.ctypes.data, nwave)
+    if rc < 0:
+        check(rc)
     return spec
 
 
@@ -190,6 +205,23 @@ def get_share():
     a, b = C.c_int(0), C.c_int(0)
     check(lib().bartrt_get_share(C.byref(a), C.byref(b)))
     return bool(a.value), bool(b.value)
+
+
+def get_service():
+    """-> dict(mode, owner_pid, slot, nclients): mode 'engine' (this process runs its own), 'client' or 'owner'
+    of the shareOpacity chain service (include/bartrt.h, bartrt_get_share)."""
+    v = [C.c_int(0) for _ in range(4)]
+    check(lib().bartrt_get_service(*[C.byref(x) for x in v]))
+    return {"mode": ("engine", "client", "owner")[v[0].value], "owner_pid": v[1].value, "slot": v[2].value,
+            "nclients": v[3].value}
+
+
+def get_service_stats():
+    """-> dict(launches, profiles, full): the dispatcher's rounds, the profiles they served, the rounds that held
+    every registered client."""
+    v = [C.c_ulonglong(0) for _ in range(3)]
+    check(lib().bartrt_get_service_stats(*[C.byref(x) for x in v]))
+    return {"launches": v[0].value, "profiles": v[1].value, "full": v[2].value}
 
 
 def get_integ() -> int:

@@ -43,7 +43,8 @@ extern "C" {
 /* trm.transit_init(argc, argv)  [BARTfunc.py:229-230]
  * argv = {"transit", "-c", <transit cfg>}.  Extra flags accepted after the
  * cfg: "--shard <rank> <nranks>" keeps only that contiguous block of the
- * wavenumber grid on this process's GPU; "--device <n>". */
+ * wavenumber grid on this process's GPU; "--device <n>"; "--no-service"
+ * (see bartrt_get_share). */
 int bartrt_init(int argc, const char **argv);
 
 /* trm.get_no_samples()  [BARTfunc.py:233].  Full-grid sample count (>=0),
@@ -108,14 +109,40 @@ int bartrt_get_cut(int *slant);
 int bartrt_get_cia_interp(int *spline);
 
 /* `shareOpacity` (a key of the reference's transit cfg: code/makecfg.py:106-107, BART.py:259-262 --
- * BART's worker processes, one per chain, keep ONE copy of the opacity grid): with the key in the
- * cfg (or BARTRT_SHARE_OPACITY=1) the first process to initialise on a (file, GPU, wavenumber block)
- * uploads the grid and the others map its HBM allocation through a HIP IPC handle published in a
- * POSIX shared-memory segment.  *shared = 1 if this engine's grid is such an allocation, *owner = 1
- * if this process made it (it frees it in bartrt_free_memory once the other processes have let go,
- * or after BARTRT_SHARE_WAIT_S seconds, default 60).  HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the
- * environment where the host driver supports dmabuf IPC only. */
+ * BART's worker processes, one per chain, keep ONE copy of the opacity grid).  With the key in the
+ * cfg (or BARTRT_SHARE_OPACITY=1) the worker processes of a run share one grid in one of two ways,
+ * chosen by BARTRT_SHARE_MODE:
+ *   service (default)  THE CHAIN SERVICE.  The first process to initialise on a (cfg, GPU, wavenumber
+ *       block) builds the engine and starts a dispatcher thread; every worker process -- that one's
+ *       own caller included -- is a client: bartrt_run_transit copies the profile into the process's
+ *       slot of a POSIX shared-memory segment and sleeps on a futex, the dispatcher launches ONE batch
+ *       for all the profiles posted together (MC3 releases its workers together: code/BARTfunc.py:312,
+ *       399) and wakes the callers.  A client makes no HIP call at all: one context, one grid, one
+ *       launch per MCMC step.  The setters (set_radius / set_cloudtop / set_scattering) of a client
+ *       act on ITS profiles only, per walker of the batch.  Served to clients: the reference module's
+ *       eight calls, bartrt_run_transit_batch and the plain getters; the other entry points return
+ *       BARTRT_ENOTSUP.  A client whose owner has gone gets BARTRT_ENODEV; the owner's
+ *       bartrt_free_memory keeps serving until the other workers have let go (BARTRT_SHARE_WAIT_S
+ *       seconds at most, default 60).  Tunables: BARTRT_SVC_WINDOW_US (30: how long the dispatcher
+ *       waits for the workers of the previous batch after the latest arrival), BARTRT_SVC_SPIN_US
+ *       (200: a waiting client polls this long before it sleeps), BARTRT_SVC_MAXCLIENTS (32).
+ *   ipc  every process runs its own engine; the first uploads the grid, the others map that HBM
+ *       allocation through a HIP IPC handle published in a POSIX shared-memory segment
+ *       (HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment where the host driver supports
+ *       dmabuf IPC only).  What "--no-service" in bartrt_init's argv (a caller that needs the whole
+ *       API in its own process: bart_amd.engine) turns `service` into.
+ *   off  the key is ignored.
+ * BARTRT_SERVICE=1 asks for the service without the key.
+ * bartrt_get_share: *shared = 1 if this process's grid is shared in either way, *owner = 1 if this
+ * process holds the allocation (ipc) / the engine (service). */
 int bartrt_get_share(int *shared, int *owner);
+/* *mode = 0 engine of its own, 1 chain-service client, 2 client that also owns the service;
+ * *owner_pid, this process's *slot, *nclients registered.  Any pointer may be NULL. */
+int bartrt_get_service(int *mode, int *owner_pid, int *slot, int *nclients);
+/* Chain service only: dispatcher rounds so far, profiles served by them, rounds that held every
+ * registered client (nprofiles / nlaunches = the mean batch). */
+int bartrt_get_service_stats(unsigned long long *nlaunches, unsigned long long *nprofiles,
+                             unsigned long long *nfull);
 
 /* Prefetched preparation.  Names the profile batch of the bartrt_run_transit_batch_dev call
  * AFTER the next one: the next call's RT launch prepares that batch's layer records

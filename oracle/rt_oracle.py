@@ -127,9 +127,44 @@ def read_opacity(path: str):
     return dict(ids=ids, temps=temps, press=press, wn=wn, kappa=k)
 
 
+LOSCHMIDT = 2.68679e19      # cm-3 per amagat (the engine's kAMAGAT)
+
+
+def read_cia_hitran(lines, path):
+    """HITRAN collision-induced-absorption layout -- the format the reference's manual names for CS files
+    (doc/BART_user_manual/BART_user_manual.tex:506-510): per temperature a 100-column header (symbol A-B [0,20),
+    first / last wavenumber [20,30) [30,40), number of points [40,47), temperature [47,54), ...) and that many
+    `wavenumber value` rows in cm5 molecule-2; returned in cm-1 amagat-2 like the sectioned layout."""
+    blocks, sym0, i = [], None, 0
+    while i < len(lines):
+        h = lines[i]
+        if not h.strip() or h.lstrip()[0] == "#":
+            i += 1
+            continue
+        try:
+            sym, w0, w1, n, T = h[:20].strip(), float(h[20:30]), float(h[30:40]), int(float(h[40:47])), float(h[47:54])
+        except ValueError:
+            t = h.split()
+            sym, w0, w1, n, T = t[0], float(t[1]), float(t[2]), int(float(t[3])), float(t[4])
+        assert sym0 in (None, sym), "blocks of different pairs in " + path
+        sym0 = sym
+        rows = np.array([[float(x) for x in l.split()[:2]] for l in lines[i + 1:i + 1 + n]])
+        assert rows.shape == (n, 2), "truncated block in " + path
+        blocks.append((T, rows[:, 0], rows[:, 1] * LOSCHMIDT * LOSCHMIDT))
+        i += 1 + n
+    blocks.sort(key=lambda b: b[0])
+    assert all(np.array_equal(b[1], blocks[0][1]) for b in blocks), "blocks on different grids in " + path
+    return dict(species=sym0.split("-", 1), temps=np.array([b[0] for b in blocks]), wn=blocks[0][1],
+                alpha=np.array([b[2] for b in blocks]))
+
+
 def read_cia(path: str):
     mode, sp, temps, rows = None, None, None, []
-    for line in open(path):
+    lines = open(path).read().split("\n")
+    first = next((l.strip() for l in lines if l.strip() and l.strip()[0] != "#"), "")
+    if first and first[0] != "@":
+        return read_cia_hitran(lines, path)
+    for line in lines:
         s = line.strip()
         if not s or s[0] == "#":
             continue

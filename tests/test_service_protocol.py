@@ -1,0 +1,106 @@
+"""The chain service's protocol on CPU (bart_amd/csrc/svc_core.hpp; include/bartrt.h, bartrt_get_share): the reference
+runs one worker process per chain, released together by MC3 (code/BARTfunc.py:312,399; ten chains in
+examples/WASP-12b/BART.cfg:113); here those processes elect one owner, post their profiles into shared-memory slots and
+are served by one launch.  tests/svc_harness.cpp runs the library's own election / slot / futex / dispatcher code with an
+arithmetic stand-in for the engine, so the host logic is covered without a GPU; the GPU tests (tests/test_gpu_share.py)
+cover the same flow on the engine."""
+import json
+import os
+import subprocess
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("svc") / "svc_harness")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-pthread",
+                           os.path.join(ROOT, "tests", "svc_harness.cpp"), "-o", exe, "-lrt"])
+    return exe
+
+
+def run(exe, key, n, rounds, env=None, die=None, ranks=None):
+    e = dict(os.environ, SVC_HARNESS_NCLIENTS=str(n), BARTRT_SVC_SPIN_US="20", **(env or {}))
+    ps = []
+    for r in (ranks or range(n)):
+        args = [exe, key, str(r), str(rounds)] + ([str(die[1])] if die and die[0] == r else [])
+        ps.append(subprocess.Popen(args, stdout=subprocess.PIPE, text=True, env=e))
+    out = []
+    for p in ps:
+        txt = p.communicate(timeout=120)[0].strip()
+        out.append((p.returncode, json.loads(txt) if txt else None))
+    return out
+
+
+def leftovers():
+    return [f for f in os.listdir("/dev/shm") if f.startswith("bartrt_svctest_")]
+
+
+def test_eight_workers_one_owner_batched_and_exact(harness):
+    res = run(harness, "a%f" % time.time(), 8, 400)
+    assert all(rc == 0 for rc, _ in res)
+    rep = [r for _, r in res]
+    assert sum(r["owner"] for r in rep) == 1
+    # every client: all its rounds served, every sample what its own profile, radius override and scattering flag give
+    assert all(r["done"] == 400 and r["bad"] == 0 and r["err"] == 0 for r in rep), rep
+    owner = [r for r in rep if r["owner"]][0]
+    # ... by far fewer rounds than calls (3200 calls): the workers' profiles went out together
+    assert owner["served"] == 3200
+    assert owner["batches"] < 1200, owner
+    assert not leftovers()
+
+
+def test_a_single_worker_is_served_at_once(harness):
+    (rc, r), = run(harness, "b%f" % time.time(), 1, 300)
+    assert rc == 0 and r["owner"] and r["done"] == 300 and r["bad"] == 0 and r["batches"] == 300
+    assert r["us_per_call"] < 2000
+    assert not leftovers()
+
+
+def test_owner_killed_mid_run_is_a_clean_error_and_the_name_is_taken_over(harness):
+    key = "c%f" % time.time()
+    # rank 0 starts alone (it is the owner), the others join; it is killed at its 50th round
+    e = dict(os.environ, SVC_HARNESS_NCLIENTS="4", BARTRT_SVC_SPIN_US="20")
+    p0 = subprocess.Popen([harness, key, "0", "100000", "50"], stdout=subprocess.PIPE, text=True, env=e)
+    time.sleep(0.3)
+    others = [subprocess.Popen([harness, key, str(r), "100000"], stdout=subprocess.PIPE, text=True, env=e) for r in (1, 2, 3)]
+    assert p0.wait(timeout=60) == -9
+    rep = [json.loads(p.communicate(timeout=60)[0]) for p in others]
+    for r in rep:
+        assert not r["owner"] and r["err"] == -3 and "gone" in r["msg"], r       # BARTRT_ENODEV, no hang, no crash
+        assert r["bad"] == 0 and 0 < r["done"] < 100000
+    # the dead owner's name is still there ...
+    assert leftovers()
+    # ... and six processes that start together on it agree on ONE new owner (the takeover is serialised)
+    res = run(harness, key, 6, 50)
+    rep = [r for _, r in res]
+    assert sum(r["owner"] for r in rep) == 1
+    assert all(r["done"] == 50 and r["bad"] == 0 for r in rep), rep
+    assert not leftovers()
+
+
+def test_owner_that_fails_to_start_tells_its_clients_why(harness):
+    key = "d%f" % time.time()
+    res = run(harness, key, 3, 5, env={"SVC_HARNESS_SLOW_OWNER": "1", "SVC_HARNESS_OWNER_FAILS": "1"})
+    rep = [r for _, r in res]
+    failed = [r for r in rep if r.get("failed_start")]
+    assert failed
+    for r in rep:
+        if not r.get("failed_start"):
+            # a client that was waiting hears the reason; one that came after the name was gone may have become the
+            # next owner (and failed the same way)
+            assert r.get("attach_error") == -3 and "did not start" in r["msg"], r
+    assert not leftovers()
+
+
+def test_a_failed_batch_fails_its_callers_only(harness):
+    res = run(harness, "e%f" % time.time(), 3, 40, env={"SVC_HARNESS_FAIL_BATCH": "1"})
+    rep = [r for _, r in res]
+    assert sum(r["owner"] for r in rep) == 1
+    assert any(r["err"] == -1 and "stand-in failure" in r["msg"] for r in rep)
+    # everybody kept going afterwards
+    assert all(r["done"] >= 39 and r["bad"] == 0 for r in rep), rep
+    assert not leftovers()

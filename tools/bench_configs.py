@@ -279,8 +279,11 @@ def mc3_processes(headline_dir, kappa, nprocs=(3, 10), steps=1500):
     """INTEGRATION.md section 1 taken literally: MC3 starts one worker process per chain (examples/WASP-12b/BART.cfg:113:
     ten; the demo three) and each holds its own transit instance -- transit_init, then run_transit once per step.  N
     such processes (tools/mc3_child.py) on ONE GPU and the headline grid, in lockstep: with every process uploading its
-    own 864 MB grid, and with `shareOpacity` (code/makecfg.py:106-107): one process uploads, the others map that
-    allocation (csrc/share.hip).  Reported: aggregate spectra/s, time per call, init time, device memory in use."""
+    own 864 MB grid (own_copies_N); with `shareOpacity` (code/makecfg.py:106-107) as the chain service, the default
+    (shared_N: one process owns the engine, all post their profiles into shared-memory slots, one batched launch per
+    step -- csrc/svc_core.hpp); and with the key read as BARTRT_SHARE_MODE=ipc (ipc_N: every process its own engine,
+    the grid one allocation mapped through HIP IPC -- csrc/share.hip).  Reported: aggregate spectra/s, time per call,
+    init time, device memory in use, and for the service the mean batch per launch."""
     import subprocess
     import torch
     from bart_amd import synth
@@ -303,12 +306,14 @@ def mc3_processes(headline_dir, kappa, nprocs=(3, 10), steps=1500):
     out = {"note": "N processes x one walker per call through trm.run_transit (host buffers in and out), all on one GPU; "
                    "the grouped worker (BARTfunc.main(comm, group): the chains of all workers batched into one call) and "
                    "the in-process sampler are the forms that reach the bench line's rate -- this is the unmodified path"}
-    for share in (False, True):
+    for mode in ("own_copies", "ipc", "shared"):
+        share = mode != "own_copies"
+        menv = dict(env, BARTRT_SHARE_MODE="ipc") if mode == "ipc" else env
         for n in nprocs:
             base = used()
             t0 = time.perf_counter()
             procs = [subprocess.Popen([sys.executable, child, shared_cfg if share else case.tcfg, str(r), str(steps)],
-                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=menv)
                      for r in range(n)]
             try:
                 ready = [expect(p, "ready") for p in procs]
@@ -326,12 +331,21 @@ def mc3_processes(headline_dir, kappa, nprocs=(3, 10), steps=1500):
                     if p.poll() is None:
                         p.kill()
             loop = max(d["loop_s"] for d in done)
-            out["%s_%d" % ("shared" if share else "own_copies", n)] = {
+            leg = {
                 "processes": n, "steps_per_process": steps, "aggregate_spectra_per_s": n * steps / loop,
                 "us_per_call_median": float(np.median([d["us_per_step"] for d in done])),
+                "call_us_median_of_medians": float(np.median([d["call_us_median"] for d in done])),
+                "call_us_p90_max": float(max(d["call_us_p90"] for d in done)),
                 "init_s_median": float(np.median([r["init_s"] for r in ready])), "all_ready_after_s": t_up,
                 "device_memory_in_use_GB": mem / 1e9, "owners": int(sum(r["owner"] for r in ready)),
-                "shared": bool(all(r["shared"] for r in ready))}
+                "shared": bool(all(r["shared"] for r in ready)),
+                "hip_contexts": int(sum(bool(d.get("hip_context")) for d in done))}
+            if mode == "shared":
+                st = max((d.get("service_stats", {"launches": 0, "profiles": 0, "full": 0}) for d in done), key=lambda x: x["launches"])
+                leg["service"] = {"launches": st["launches"], "profiles": st["profiles"], "full_rounds": st["full"],
+                                  "mean_batch": st["profiles"] / max(st["launches"], 1),
+                                  "roles": sorted(r["service"] for r in ready)}
+            out["%s_%d" % (mode, n)] = leg
     return out
 
 

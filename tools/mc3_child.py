@@ -7,7 +7,11 @@ tests/test_gpu_share.py; talks to its parent over stdin / stdout:
     parent -> "go"               once every child is ready
     child  -> "done {json}"      after its steps
     parent -> "bye"              once every child is done (the grid's owner must outlive the others' use)
-usage: mc3_child.py <transit.cfg> <rank> <nsteps> [<out.npy>]"""
+usage: mc3_child.py <transit.cfg> <rank> <nsteps> [<out.npy>] [--radius km] [--cloudtop log10bar]
+                    [--scattering flag value] [--until-error]
+The setters are this process's own trm.set_radius / set_cloudtop / set_scattering (code/BARTfunc.py:350-360);
+--until-error: keep calling until the engine refuses (a chain-service client whose owner has died), report it."""
+import argparse
 import json
 import os
 import sys
@@ -18,15 +22,36 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def kfd_touched() -> bool:
+    """Has this process opened the GPU driver (a HIP context exists)?  A chain-service client must not have."""
+    try:
+        return any("kfd" in os.readlink("/proc/self/fd/" + f) for f in os.listdir("/proc/self/fd"))
+    except OSError:
+        return False
+
+
 def main():
-    tcfg, rank, nsteps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    out = sys.argv[4] if len(sys.argv) > 4 else None
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tcfg"); ap.add_argument("rank", type=int); ap.add_argument("nsteps", type=int)
+    ap.add_argument("out", nargs="?")
+    ap.add_argument("--radius", type=float); ap.add_argument("--cloudtop", type=float)
+    ap.add_argument("--scattering", nargs=2, type=float)
+    ap.add_argument("--until-error", action="store_true")
+    a = ap.parse_args()
+    tcfg, rank, nsteps, out = a.tcfg, a.rank, a.nsteps, a.out
     from bart_amd import transit_module as trm
     t0 = time.perf_counter()
     trm.transit_init(3, ["transit", "-c", tcfg])
     t_init = time.perf_counter() - t0
     n = trm.get_no_samples()
     shared, owner = trm.get_share()
+    svc = trm.get_service()
+    if a.radius is not None:
+        trm.set_radius(a.radius)
+    if a.cloudtop is not None:
+        trm.set_cloudtop(a.cloudtop)
+    if a.scattering is not None:
+        trm.set_scattering(int(a.scattering[0]), a.scattering[1])
     prof0 = np.zeros(trm.lib().bartrt_get_nprof())
     trm.check(trm.lib().bartrt_get_atm_profile(trm._ptr(prof0), prof0.size))
     L = trm.lib().bartrt_get_nlayers()
@@ -34,16 +59,42 @@ def main():
     mine = prof0.copy()
     mine[:L] = np.clip(mine[:L] + 20.0 * rank, 410.0, 2990.0)
     trm.run_transit(mine, n)                       # first call (workspaces)
-    print("ready " + json.dumps({"rank": rank, "init_s": t_init, "shared": shared, "owner": owner}), flush=True)
+    print("ready " + json.dumps({"rank": rank, "init_s": t_init, "shared": shared, "owner": owner, "service": svc["mode"],
+                                 "slot": svc["slot"], "pid": os.getpid(), "hip_context": kfd_touched()}), flush=True)
     assert sys.stdin.readline().strip() == "go"
+    if a.until_error:
+        k, err = 0, None
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 60.0:
+            try:
+                trm.run_transit(mine, n)
+                k += 1
+            except trm.TransitError as e:
+                err = str(e)
+                break
+        print("done " + json.dumps({"rank": rank, "steps": k, "error": err, "waited_s": time.perf_counter() - t0}), flush=True)
+        sys.stdin.readline()
+        try:
+            trm.free_memory()
+        except trm.TransitError:
+            pass
+        return
+    lat = np.zeros(max(nsteps, 1))
     t0 = time.perf_counter()
-    for _ in range(nsteps):
+    for i in range(nsteps):
+        t1 = time.perf_counter()
         spec = trm.run_transit(mine, n)
+        lat[i] = time.perf_counter() - t1
     dt = time.perf_counter() - t0
     common = trm.run_transit(prof0, n)
     if out:
         np.save(out, np.stack([common, spec]))
-    print("done " + json.dumps({"rank": rank, "steps": nsteps, "loop_s": dt, "us_per_step": dt / max(nsteps, 1) * 1e6}), flush=True)
+    rep = {"rank": rank, "steps": nsteps, "loop_s": dt, "us_per_step": dt / max(nsteps, 1) * 1e6,
+           "call_us_median": float(np.median(lat) * 1e6), "call_us_p90": float(np.percentile(lat, 90) * 1e6),
+           "hip_context": kfd_touched()}
+    if svc["mode"] != "engine":
+        rep["service_stats"] = trm.get_service_stats()
+    print("done " + json.dumps(rep), flush=True)
     sys.stdin.readline()
     trm.free_memory()
 

@@ -258,6 +258,20 @@ int bartrt_set_cut(int slant) {
   return BARTRT_OK;
 }
 
+int bartrt_set_kernel_by(int local) {
+  NEED_ENGINE();
+  if (local != 0 && local != 1) return fail(BARTRT_EINVAL, "set_kernel_by: 0 (whole grid) or 1 (local block)");
+  g_eng->kernel_by_local = local != 0;
+  return BARTRT_OK;
+}
+
+int bartrt_get_kernel_by(int *local) {
+  NEED_ENGINE();
+  if (!local) return fail(BARTRT_EINVAL, "get_kernel_by: null output pointer");
+  *local = g_eng->kernel_by_local ? 1 : 0;
+  return BARTRT_OK;
+}
+
 int bartrt_get_cut(int *slant) {
   CLIENT_OR_ENGINE();
   if (!slant) return fail(BARTRT_EINVAL, "get_cut: null output pointer");

@@ -176,6 +176,12 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
     if (v != "vertical" && v != "slant") throw IoError{"cut: '" + v + "' is neither vertical nor slant"};
     cut_slant = v == "slant";
   }
+  {
+    std::string v = cfg_has(cfg, "kernel_by") ? cfg["kernel_by"] : "local";
+    if (const char *ev = std::getenv("BARTRT_KERNEL_BY")) if (*ev) v = ev;
+    if (v != "whole" && v != "local") throw IoError{"kernel_by: '" + v + "' is neither whole nor local"};
+    kernel_by_local = v == "local";
+  }
   atm = read_atm(cfg["atm"]);
   mol = read_molfile(cfg["molfile"]);
   L = (int)atm.press.size();
@@ -671,6 +677,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
 
   RtArgs r = rt;
   r.nwalkers = n;
+  if (kernel_by_local) r.Wfull = r.W;
   r.coef = coef_b[bset]; r.idx = idx_b[bset]; r.kstop = kstop_b[bset];
   r.ext = d_ext;
   r.nprep = 0;

@@ -40,6 +40,11 @@ struct Engine {
   int solution = 0;       // 0 eclipse (emergent flux), 1 transit (modulation)
   int integ = 0;          // integration rule of the eclipse geometry (integ.hpp); cfg `integ`, BARTRT_INTEG
   bool cut_slant = false; // cfg `cut slant` / BARTRT_CUT: the toomuch cut per ray angle, on its slant depth (C19)
+  // Sharded engines (--shard): is the kernel variant chosen by this block's own columns (true, the default since round 5:
+  // a WASP-12b block of 303 samples x 10 walkers takes the layer-parallel kernel, 16 us, instead of the single-wave
+  // kernel's latency floor, 52 us; spectra agree with the unsharded run's to 4e-16) or by the WHOLE grid's (false: cfg
+  // `kernel_by whole` / BARTRT_KERNEL_BY=whole / bartrt_set_kernel_by -- the blocks then are the unsharded run's bits)
+  bool kernel_by_local = true;
   bool cia_spline = false; // cfg `cia_interp spline` / BARTRT_CIA_INTERP: natural cubic splines in wavenumber and T (C20)
   double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;

@@ -60,7 +60,7 @@ ChainService *ChainService::start(svc::Segment &&elected, Engine *e) {
     // spectra up to this many bytes per launch go to host memory straight from the RT kernel; above, the
     // kernel writes HBM and one DMA copy follows (measured: DESIGN.md 6, "chain service")
     s->direct_spec_bytes = (size_t)svc::env_num("BARTRT_SVC_DIRECT_BYTES", 4.0 * 1024 * 1024);
-    s->sync_mode = (int)svc::env_num("BARTRT_SVC_SYNC", 0.0);
+    s->sync_mode = (int)svc::env_num("BARTRT_SVC_SYNC", 1.0);   // (measured at ten clients: 121 us per call against 128 with hipStreamSynchronize, 130 with an event)
     if (s->sync_mode == 1 && !s->registered) s->sync_mode = 0;
     if (s->sync_mode == 2) {
       hipEvent_t ev;

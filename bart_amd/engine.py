@@ -18,7 +18,7 @@ from . import transit_module as trm
 _check, _ptr = trm.check, trm._ptr
 
 
-def init(tcfg: str, shard: tuple[int, int] | None = None, device: int | None = None) -> None:
+def init(tcfg: str, shard: tuple[int, int] | None = None, device: int | None = None, kernel_by: str | None = None) -> None:
     """An engine IN THIS PROCESS (this module's batched / device-resident calls need one): with `shareOpacity`
     in the cfg the grid is shared through HIP IPC, never through the chain service (include/bartrt.h,
     bartrt_get_share) -- the service is for the reference's one-profile-per-process workers."""
@@ -28,6 +28,10 @@ def init(tcfg: str, shard: tuple[int, int] | None = None, device: int | None = N
     if device is not None:
         argv += ["--device", str(device)]
     trm.transit_init(len(argv), argv)
+    if kernel_by is not None:
+        # 'whole': a sharded engine's blocks are the unsharded spectrum bit for bit; 'local' (default): the kernel
+        # variant fits the block (include/bartrt.h, bartrt_set_kernel_by)
+        trm.set_kernel_by(kernel_by)
 
 
 def nlayers() -> int:
@@ -205,6 +209,24 @@ def allgather_blocks(local, group=None, total=None, async_op=False, out=None):
     send = pad_block(local, wmax)
     if out is None:
         out = torch.empty((world * n, wmax), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # Device blocks under a process group that moves host memory only (two ranks on ONE GPU, which RCCL
+        # refuses -- tests/test_gpu_two_ranks.py; a node without xGMI): the block goes through pinned host memory.
+        # The collective must not start before the kernels that write `local` have finished: the stream is waited
+        # for here (RCCL orders that on the device; gloo cannot).
+        h_send = torch.empty(send.shape, dtype=send.dtype, pin_memory=True)
+        h_send.copy_(send, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        h_out = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        hwork = dist.all_gather_into_tensor(h_out, h_send, group=group, async_op=async_op)
+
+        def finish_host():
+            if hwork is not None:
+                hwork.wait()
+            out.copy_(h_out, non_blocking=True)      # on the current stream, ahead of the reassembly
+            return reassemble_blocks(out, n, sizes)
+
+        return (hwork, finish_host) if async_op else finish_host()
     work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
 
     def finish():

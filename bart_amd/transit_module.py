@@ -90,6 +90,8 @@ def lib():
         L.bartrt_set_integ.argtypes = [i]
         L.bartrt_set_cut.argtypes = [i]
         L.bartrt_get_cut.argtypes = [C.POINTER(i)]
+        L.bartrt_set_kernel_by.argtypes = [i]
+        L.bartrt_get_kernel_by.argtypes = [C.POINTER(i)]
         L.bartrt_get_cia_interp.argtypes = [C.POINTER(i)]
         L.bartrt_get_share.argtypes = [C.POINTER(i), C.POINTER(i)]
         L.bartrt_get_service.argtypes = [C.POINTER(i)] * 4
@@ -183,6 +185,18 @@ def set_cut(cut):
     """'slant' (default) or 'vertical': which optical depth `toomuch` is compared with
     (include/bartrt.h, bartrt_set_cut)."""
     check(lib().bartrt_set_cut({"vertical": 0, "slant": 1, 0: 0, 1: 1}[cut]))
+
+
+def set_kernel_by(which):
+    """'whole' (default) or 'local': the column count that picks a sharded engine's kernel variant
+    (include/bartrt.h, bartrt_set_kernel_by)."""
+    check(lib().bartrt_set_kernel_by({"whole": 0, "local": 1, 0: 0, 1: 1}[which]))
+
+
+def get_kernel_by() -> str:
+    v = C.c_int(-1)
+    check(lib().bartrt_get_kernel_by(C.byref(v)))
+    return "local" if v.value else "whole"
 
 
 def get_cut() -> str:

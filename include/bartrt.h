@@ -102,6 +102,16 @@ int bartrt_get_integ(int *rule);
 int bartrt_set_cut(int slant);
 int bartrt_get_cut(int *slant);
 
+/* Sharded engines ("--shard r n"): which column count picks the kernel variant.  1 (DEFAULT) = this
+ * block's own: a block of a few hundred samples takes the layer-parallel kernels instead of the
+ * single-wave kernel's latency floor (the WASP-12b grid on eight GPUs, 303 samples x 10 walkers per
+ * rank: 16 us against 52 us per launch); spectra agree with the unsharded run's to rounding (4e-16
+ * measured), not bit for bit -- north_star asks for 1e-6.  0 = the WHOLE grid's: every block is computed
+ * by the kernel the unsharded run would use, so the blocks concatenate to its spectrum bit for bit.
+ * Also cfg `kernel_by local|whole` and BARTRT_KERNEL_BY.  No effect on an unsharded engine. */
+int bartrt_set_kernel_by(int local);
+int bartrt_get_kernel_by(int *local);
+
 /* How the engine interpolates the cross-section (CIA) files, fixed at bartrt_init by the cfg key
  * `cia_interp linear|spline` / BARTRT_CIA_INTERP: *spline = 1 (default since round 4)
  * natural cubic splines in wavenumber and temperature, 0 linear in both.  Read-only: the tables are

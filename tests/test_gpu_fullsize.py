@@ -98,7 +98,7 @@ def test_full_grid_shards_concatenate(full_case):
     trm.free_memory()
     parts = []
     for r in range(8):
-        engine.init(c.tcfg, shard=(r, 8))
+        engine.init(c.tcfg, shard=(r, 8), kernel_by="whole")     # (bit for bit: every block by the unsharded run's kernel)
         assert engine.local_range() == (1250 * r, 1250 * (r + 1))
         parts.append(engine.run_batch(np.tile(profs, (8, 1)))[:10])   # 80 walkers per step, as at N = 8
         trm.free_memory()

@@ -324,12 +324,20 @@ def test_shards_reassemble_full_spectrum(small_case):
     trm.free_memory()
     parts = []
     for r in range(3):
-        engine.init(c.tcfg, shard=(r, 3))
+        engine.init(c.tcfg, shard=(r, 3), kernel_by="whole")
         lo, hi = engine.local_range()
         parts.append(engine.run_batch(profs))
         assert parts[-1].shape[1] == hi - lo
         trm.free_memory()
     assert np.array_equal(np.concatenate(parts, axis=1), full)
+    # the default: every block by the kernel that fits the block (`kernel_by local`) -- the same spectrum to rounding
+    parts = []
+    for r in range(3):
+        engine.init(c.tcfg, shard=(r, 3))
+        assert trm.get_kernel_by() == "local"
+        parts.append(engine.run_batch(profs))
+        trm.free_memory()
+    np.testing.assert_allclose(np.concatenate(parts, axis=1), full, rtol=1e-12, atol=1e-14 * np.abs(full).max())
 
 
 def test_setters_cloud_scattering_radius(small_case):

@@ -186,7 +186,7 @@ def test_sharded_step_equals_unsharded(demo_case, wg, ptg):
     d_par = torch.from_numpy(params).cuda()
     n, world, blocks = len(params), 3, []
     for r in range(world):
-        engine.init(c.tcfg, shard=(r, world))
+        engine.init(c.tcfg, shard=(r, world), kernel_by="whole")
         try:
             imol = [c.species.index("CH4")]
             engine.step_setup(ptg["line_args"], 400.0, 3000.0, c.abund0, imol, wg["demo_idx0"],

@@ -200,6 +200,118 @@ def wasp12b_step(integ):
         w.close()
 
 
+def full_step_10(integ, headline_dir=None, kappa="survey8d"):
+    """The whole MCMC step at the HEADLINE shape: 100 layers x 1e4 samples, 4 molecules, 10 walkers,
+    10 filters with the energy-balance check on -- parameters -> T(p) / abundances / layer records -> RT -> band fluxes
+    (code/BARTfunc.py:309-399), device buffers in and out, one host synchronisation per step as an MCMC driver needs
+    it.  The bench line's `value` times the RT call alone; this is what a sampler pays per iteration."""
+    import torch
+    from bart_amd import BARTfunc, engine, synthcfg, transit_module as trm
+    mols = ("H2O", "CO", "CO2", "CH4")
+    p0 = (-2.0, 0.0, 1.0, 0.0, 0.98, -0.5, -0.5, -0.5, -0.5)
+    d = os.path.join(tempfile.gettempdir(), "bartrt_cfg_fullstep")
+    case, cfg = synthcfg.make_worker_case(d, nwave=10000, wnlow=1000.0, opmol=mols, molfit=mols, params=p0,
+                                          nfilters=10, ebalance=True, kappa_model=kappa, reuse=True)
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
+    try:
+        trm.set_integ(integ)
+        rng = np.random.default_rng(5)
+        nsets, n, steps = 16, 10, 300
+        pars = np.array(p0) + rng.normal(0, [0.3, 0.2, 0.2, 0.05, 0.02, 0.5, 0.5, 0.5, 0.5], (nsets, n, 9))
+        pars[..., 3] = np.clip(pars[..., 3], 0, 1)
+        d_par = torch.from_numpy(pars).cuda()
+        out = {}
+        for sync_each in (True, False):
+            for i in range(20):
+                band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
+            torch.cuda.synchronize()
+            engine.timing_begin(1)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
+                if sync_each:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            kms, nl = engine.timing_end()
+            out["synchronised_every_step" if sync_each else "queued_back_to_back"] = {
+                "us_per_step": dt * 1e6, "walker_steps_per_s": n / dt, "rt_kernel_us": kms / max(nl, 1) * 1e3,
+                "step_minus_rt_kernel_us": dt * 1e6 - kms / max(nl, 1) * 1e3}
+        # run to run: the same parameters give the same band-flux bits
+        b1, _ = engine.step_batch_dev(d_par[0], w.nfilters); b1 = b1.clone()
+        b2, _ = engine.step_batch_dev(d_par[0], w.nfilters)
+        torch.cuda.synchronize()
+        out["workload"] = ("whole step at the headline shape: 100 layers x 1e4 samples, 4 molecules, 10 filters, energy "
+                           "balance on, 10 walkers per step, integ %d; parameters in, band fluxes out, on the device" % integ)
+        out["accepted_in_last_batch"] = int((status.cpu().numpy() == 0).sum())
+        out["band_fluxes_bit_stable"] = bool(torch.equal(b1, b2))
+        out["launches_per_step"] = int(os.environ.get("BARTRT_STEP_LAUNCHES", "0")) or None
+        return out
+    finally:
+        w.close()
+
+
+def wasp12b_shard8(integ):
+    """BASELINE config 4 at N = 8 as ONE rank sees it: rank 3 of 8 of the WASP-12b grid (303 of 2424 samples), ten walkers
+    per step -- parameters -> profiles -> RT on the block (the all-gather and the band integration on the gathered
+    spectrum are the other ranks' business too and are not in this figure).  Twice: with the kernel chosen by the WHOLE
+    grid's columns (the default: blocks bit-identical to the unsharded run) and by the LOCAL block's
+    (include/bartrt.h, bartrt_set_kernel_by).  DESIGN.md section 5 takes its N = 8 recommendation from these two."""
+    import ctypes as C
+    import torch
+    from bart_amd import BARTfunc, engine, synthcfg, transit_module as trm
+    mols = ("H2O", "CO", "CO2", "CH4")
+    p0 = (-2.0, 0.0, 1.0, 0.0, 0.98, -0.5, -0.5, -0.5, -0.5)
+    d = os.path.join(tempfile.gettempdir(), "bartrt_cfg_wasp")
+    case, cfg = synthcfg.make_worker_case(d, nwave=2424, wnlow=910.0, opmol=mols, molfit=mols, params=p0,
+                                          nfilters=4, reuse=True)
+    out = {"workload": "BASELINE config 4, one rank's share at N = 8: block 3 of 8 of the WASP-12b grid (303 samples, 100 "
+                       "layers, 4 molecules), 10 walkers per step: parameters -> profiles -> RT on the block, integ %d" % integ}
+    w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg), shard=(3, 8))
+    try:
+        trm.set_integ(integ)
+        lo, hi = engine.local_range()
+        rng = np.random.default_rng(5)
+        nsets, n, steps = 16, 10, 400
+        pars = np.array(p0) + rng.normal(0, [0.3, 0.2, 0.2, 0.05, 0.02, 0.5, 0.5, 0.5, 0.5], (nsets, n, 9))
+        pars[..., 3] = np.clip(pars[..., 3], 0, 1)
+        d_par = torch.from_numpy(pars).cuda()
+        prof = torch.empty((n, engine.nprof()), dtype=torch.float64, device="cuda")
+        stat = torch.empty(n, dtype=torch.int32, device="cuda")
+        spec = torch.empty((n, hi - lo), dtype=torch.float64, device="cuda")
+        sp = engine._stream_ptr()
+
+        def one(i):
+            trm.check(trm.lib().bartrt_step_profiles_dev(C.c_void_p(d_par[i % nsets].data_ptr()), n, 9, C.c_void_p(prof.data_ptr()),
+                                                         C.c_void_p(stat.data_ptr()), sp))
+            engine.run_batch_dev(prof, spec)
+        res = {}
+        for which in ("whole", "local"):
+            trm.set_kernel_by(which)
+            for i in range(20):
+                one(i)
+            torch.cuda.synchronize()
+            engine.timing_begin(1)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one(i)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            kms, nl = engine.timing_end()
+            engine.walked_begin()
+            one(0)
+            torch.cuda.synchronize()
+            _, _, kname = engine.walked_end()
+            res[which] = spec.cpu().numpy().copy()
+            out["kernel_by_" + which] = {"us_per_step": dt * 1e6, "rt_kernel_us": kms / max(nl, 1) * 1e3, "kernel": kname,
+                                         "walker_steps_per_s_per_rank": n / dt}
+        out["local_vs_whole_max_rel_diff"] = float(np.max(np.abs(res["local"] / res["whole"] - 1.0)))
+        out["block"] = [int(lo), int(hi)]
+    finally:
+        w.close()
+    return out
+
+
 def transit_geometry(integ, batches=(10, 256)):
     import torch
     import bench
@@ -356,7 +468,8 @@ def run_all(integ, headline_dir=None, kappa="survey8d"):
             res["mc3_processes"] = mc3_processes(headline_dir, kappa)
         except Exception as e:
             res["mc3_processes"] = {"error": repr(e)}
-    for name, fn in (("demo_1walker", demo_1walker), ("wasp12b_step", wasp12b_step)):
+    for name, fn in (("demo_1walker", demo_1walker), ("wasp12b_step", wasp12b_step), ("wasp12b_shard8", wasp12b_shard8),
+                     ("full_step_10", full_step_10)):
         try:
             res[name] = fn(integ)
         except Exception as e:      # an extra leg must not take the contract's line down

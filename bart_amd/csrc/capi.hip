@@ -8,9 +8,11 @@
 #include "lbl.hpp"
 #include "share.hpp"
 #include "step.hpp"
+#include "rtc.hpp"
 #include "svc.hpp"
 
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 
 #include <sys/stat.h>
@@ -433,7 +435,7 @@ int bartrt_run_transit_batch(const double *prof, int nwalkers, int nprof,
       HIPCHK(hipMemcpyAsync(hs, e->d_spec, sb, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipMemcpyAsync(hok, e->d_ok, nwalkers, hipMemcpyDeviceToHost, e->stream));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    e->wait(e->stream);
     const size_t off = nwave == Wl ? 0 : (size_t)e->lo;
     for (int w = 0; w < nwalkers; w++)
       std::memcpy(spec + (size_t)w * nwave + off, hs + (size_t)w * Wl, sizeof(double) * Wl);
@@ -643,8 +645,7 @@ int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *w
     if (ncolumns) *ncolumns = nc;
     if (wn_per_column) *wn_per_column = e->walked_info.wn_per_column;
     if (kernel && kernel_len > 0) {
-      std::strncpy(kernel, e->walked_info.kernel, kernel_len - 1);
-      kernel[kernel_len - 1] = 0;
+      std::snprintf(kernel, (size_t)kernel_len, "%s%s", e->walked_info.kernel, e->walked_info.rtc ? " [instantiated at run time]" : "");
     }
     if (walked && n > 0) {
       if ((size_t)cap < (size_t)n * nc) throw std::invalid_argument("walked_end: buffer too small");
@@ -652,6 +653,24 @@ int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *w
     }
     return BARTRT_OK;
   });
+}
+
+int bartrt_get_rtc_stats(int *available, int *compiled, int *from_disk, int *failed, double *compile_seconds) {
+  const RtcStats st = rtc_stats();
+  if (available) *available = rtc_available() ? 1 : 0;
+  if (compiled) *compiled = st.compiled;
+  if (from_disk) *from_disk = st.from_disk;
+  if (failed) *failed = st.failed;
+  if (compile_seconds) *compile_seconds = st.compile_seconds;
+  return BARTRT_OK;
+}
+
+int bartrt_rtc_compile(const char *expr, int ilp, long *code_bytes) {
+  if (!expr) return fail(BARTRT_EINVAL, "rtc_compile: null expression");
+  std::string why;
+  const long n = rtc_compile_only(expr, ilp != 0, why);
+  if (code_bytes) *code_bytes = n;
+  return n < 0 ? fail(BARTRT_ENOTSUP, why) : BARTRT_OK;
 }
 
 double bartrt_algorithmic_bytes(int nwalkers) {

@@ -36,6 +36,7 @@ Engine::~Engine() {
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
   fr(d_walked); fr(d_coef2); fr(d_idx2); fr(d_kstop2); fr(d_ok2); fr(d_slog);
   if (h_pin) (void)hipHostFree(h_pin);
+  if (h_flag) (void)hipHostFree(h_flag);
   for (auto e : ev) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -273,6 +274,21 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   }
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  {
+    const char *e = std::getenv("BARTRT_SYNC");
+    sync_poll = !(e && std::string(e) == "stream");
+    if (sync_poll) {
+      void *dv = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void **>(&h_flag), 64, hipHostMallocDefault) == hipSuccess &&
+          hipHostGetDevicePointer(&dv, h_flag, 0) == hipSuccess) {
+        *h_flag = 0;
+        d_flag = static_cast<unsigned int *>(dv);
+      } else {
+        (void)hipGetLastError();
+        sync_poll = false;
+      }
+    }
+  }
 
   // ---- tables to HBM
   std::vector<double> wn_loc(wn_full.begin() + lo, wn_full.begin() + hi);
@@ -562,6 +578,20 @@ void Engine::ensure_walkers(int n) {
   cap_walkers = cap;
 }
 
+void Engine::wait(hipStream_t st) {
+  if (!sync_poll || !h_flag) { HIPCHK(hipStreamSynchronize(st)); return; }
+  const unsigned int want = ++flag_seq;
+  HIPCHK(hipStreamWriteValue32(st, d_flag, want, 0));
+  volatile unsigned int *f = h_flag;
+  long spins = 0;
+  while (*f != want) {
+    __builtin_ia32_pause();
+    // (a launch that failed never writes: the stream itself is asked now and then, and reports the error)
+    if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) { HIPCHK(hipStreamSynchronize(st)); break; }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
 void Engine::ensure_pin(size_t bytes) {
   if (bytes <= h_pin_bytes) return;
   if (h_pin) HIPCHK(hipHostFree(h_pin));
@@ -603,6 +633,28 @@ void Engine::run_dev(const double *d_prof_in, int n, double *d_spec_out,
     }
     prep_over_once = nullptr;
     return;
+  }
+  // `cut slant`, rule 1: the single-wave kernels keep an event log of 100 bytes per (walker, wavenumber) lane
+  // (RtArgs::slog) -- 1 MB per walker at W = 1e4.  A batch whose log would pass BARTRT_SLOG_CAP_BYTES (1 GiB) goes
+  // out in chunks of walkers (results are per walker: the same bits either way).
+  if (cut_slant && integ == 1 && solution == 0 && !prep_hook) {   // (the fused per-step launch addresses its batch whole)
+    static const size_t cap = [] {
+      const char *c = std::getenv("BARTRT_SLOG_CAP_BYTES");
+      return c && *c ? std::max<size_t>(1, std::strtoull(c, nullptr, 10)) : (size_t)1 << 30;
+    }();
+    const size_t per = std::max<size_t>(1, slant_log_bytes(1, (W() + 63) / 64, 64, A));
+    const int chunk = (int)std::max<size_t>(1, cap / per);
+    if (n > chunk) {
+      const int nprof = (S + 1) * L;
+      const double *over = prep_over_once;
+      for (int off = 0; off < n; off += chunk) {
+        const int m = std::min(chunk, n - off);
+        prep_over_once = over ? over + (size_t)3 * off : nullptr;
+        run_chunk(d_prof_in + (size_t)off * nprof, m, d_spec_out + (size_t)off * W(), (d_okp ? d_okp : d_ok) + off, st, want_tau, nullptr);
+      }
+      prep_over_once = nullptr;
+      return;
+    }
   }
   run_chunk(d_prof_in, n, d_spec_out, d_okp, st, want_tau, nullptr);
 }
@@ -715,8 +767,9 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   r.ntiles = (r.W + block - 1) / block;
   r.rtop = d_rtop; r.ds = d_ds;
   r.slog = nullptr;
-  if (cut_slant && solution == 0 && !lbl_fused) {
-    // the event log of the single-wave `cut slant` kernels (rt_eclipse_s1s.hpp): 100 bytes per lane
+  if (cut_slant && integ == 1 && solution == 0 && !lbl_fused) {
+    // the event log of rule 1's single-wave `cut slant` kernels (rt_eclipse_s1s.hpp): 100 bytes per lane
+    // (rules 0 / 2 -- rt_eclipse_fast<SLANT> -- keep none)
     const size_t need = slant_log_bytes(n, r.ntiles, block, A);
     if (need > slog_cap) {
       HIPCHK(hipDeviceSynchronize());   // (an earlier launch on any stream may still write the old log)

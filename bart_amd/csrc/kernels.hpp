@@ -1,7 +1,23 @@
 // Device-side argument blocks shared by the kernels and the host engine.
 #pragma once
+// (The kernel headers -- this file, integ.hpp, prep.hpp, rt_eclipse*.hpp -- also compile under hiprtc, which knows no
+// host headers: csrc/rtc.hip builds the shapes the ahead-of-time set does not hold from these same sources.  Host-only
+// parts sit behind !__HIPCC_RTC__; the few std:: names the kernels use are declared below for that compiler.)
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cstdint>
+#else
+typedef struct ihipEvent_t *hipEvent_t;
+namespace std {
+template <class T, T v> struct integral_constant { static constexpr T value = v; using value_type = T; constexpr operator T() const { return v; } };
+using true_type = integral_constant<bool, true>;
+using false_type = integral_constant<bool, false>;
+template <bool B, class T, class F> struct conditional { using type = T; };
+template <class T, class F> struct conditional<false, T, F> { using type = F; };
+template <bool B, class T, class F> using conditional_t = typename conditional<B, T, F>::type;
+}  // namespace std
+#endif
 
 // (molecules, CIA pairs) the specialised kernels are instantiated for
 // (four CIA slots = two cross-section files under the default `cia_interp spline`: BART's usual H2-H2 + H2-He)
@@ -9,6 +25,8 @@
   X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) \
   X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2) X(7, 1) X(7, 2) X(8, 1) X(8, 2)                 \
   X(1, 4) X(2, 4) X(3, 4) X(4, 4) X(5, 4) X(6, 4)
+// ... of the adjacent-rows layer-parallel kernel (rt_eclipse_qadj.hpp)
+#define BARTRT_QADJ_LIST(X) X(1, 1) X(1, 2) X(4, 1) X(4, 2)
 // CIA slot counts of the line-by-line hand-off kernels (no table molecules)
 #define BARTRT_EXT_C_LIST(X) X(0) X(1) X(2) X(4)
 
@@ -258,6 +276,7 @@ struct RtLaunchInfo {
   int wn_per_column = 64;   // granularity of RtArgs::walked_out
   int ncolumns = 0;         // entries of walked_out per walker
   bool prep_fused = false;  // the launch carried RtArgs::nprep workgroups of the next batch's preparation
+  bool rtc = false;         // the kernel was instantiated at run time (rtc.hpp), not taken from the ahead-of-time set
 };
 
 // ---------------------------------------------------------------------------

@@ -4,6 +4,16 @@
 #pragma once
 #include "kernels.hpp"
 
+// Phase clock of the latency-shaped preparation kernels (a development build only: tools/ab_build.py with
+// -DBARTRT_PHASE_CLOCK, read back by tools/debug/phase_clock.py): workgroup 0's lane 0 stamps the 100 MHz
+// real-time counter at the phase boundaries.
+#ifdef BARTRT_PHASE_CLOCK
+extern __device__ unsigned long long g_phase_clock[32];
+#define BARTRT_PHASE(n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clock[n] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BARTRT_PHASE(n) do {} while (0)
+#endif
+
 namespace bartrt {
 
 // Largest j with g[j] <= t, clamped to [0, n-2].  Starts from the uniform-grid
@@ -62,6 +72,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
   __shared__ int sBad;
   if (threadIdx.x == 0) sBad = 0;
   __syncthreads();
+  BARTRT_PHASE(8);
   // Hydrostatic radii, makeatm.py:229-258 (layers bottom -> top).  The
   // reference steps r_i = r_{i+-1} -+ H_i / g and rescales g by (r_old/r_new)^2,
   // i.e. g r^2 stays g0 R0^2: the step is r -+ (H_i / (g0 R0^2)) r^2.  The
@@ -86,6 +97,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     }
   }
   __syncthreads();
+  BARTRT_PHASE(9);
   const bool bad = sBad != 0;
   // (a 64-lane workgroup -- the preparation fused into an RT launch -- walks both chains in one wave)
   const unsigned up_lane = blockDim.x >= 128 ? 64 : blockDim.x / 2;
@@ -140,6 +152,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     }
   }
   __syncthreads();
+  BARTRT_PHASE(10);
   const int NC = coef_stride(M, C), NI = idx_stride(C);
   double *coef = p.coef + (size_t)w * L * NC;
   idx_t *idx = p.idx + (size_t)w * L * NI;
@@ -234,6 +247,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     p.kstop[w] = ks;
     if (p.ok) p.ok[w] = bad ? 0 : 1;
   }
+  BARTRT_PHASE(11);
 }
 
 // One workgroup's whole job for walker w: everything the body reads from HBM (the walker's
@@ -242,6 +256,7 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
 // each dependent trip to memory it avoids is worth most of a microsecond.
 __device__ inline void prep_block(const PrepArgs &p, int w, double *sm) {
   const int L = p.L, S = p.S;
+  BARTRT_PHASE(7);
   stage2_to_lds(prep_lds_profile(sm, L), p.prof + (size_t)w * (S + 1) * L, (S + 1) * L,
                 prep_lds_consts(sm, L, S), p.consts, 2 * L + S + 2 * p.Nt + 2 * p.ncia_temps,
                 threadIdx.x, blockDim.x);

@@ -16,11 +16,13 @@
 #include "kernels.hpp"
 #include "prep.hpp"
 
+#ifndef __HIPCC_RTC__
 #include <cmath>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
 #include <utility>
+#endif
 
 // upper bound on resident waves per SIMD the specialised kernels are compiled
 // for: lets the compiler spend registers on loads in flight (measured best: 3-4)
@@ -823,6 +825,27 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
 #include "rt_eclipse_s1t.hpp"  // ... as a team of three waves per column
 namespace bartrt {
 
+#ifndef __HIPCC_RTC__   // ---- host side: the launchers (to the end of the file)
+}  // namespace bartrt
+#include "rtc.hpp"
+#include <cstdarg>
+#include <cstdio>
+namespace bartrt {
+// A shape the ahead-of-time set does not hold: the same kernel template, instantiated at run time (rtc.hpp).
+// fmt / ...: the template-id in namespace bartrt.  false: no compiler at hand -- the caller falls through to the
+// generic kernel as before.
+inline bool rtc_try(RtLaunchInfo *info, bool ilp, dim3 grid, dim3 block, size_t sh, hipStream_t st, const RtArgs &b,
+                    hipError_t &err, const char *fmt, ...) {
+  char ex[192];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(ex, sizeof ex, fmt, ap);
+  va_end(ap);
+  if (!rtc_launch(ex, ilp, grid, block, sh, st, b, err)) return false;
+  if (info) info->rtc = true;
+  return true;
+}
+inline const char *tf(bool b) { return b ? "true" : "false"; }
 // If one ray angle has exactly half the cosine of another (0 and 60 degrees of
 // the usual raygrid 0 20 40 60 80), put that pair first and last: the SQ kernels
 // take the last transmittance as the square of the first.
@@ -861,6 +884,10 @@ bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t
 bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 bool launch_rt_slant_out(const RtArgs &b, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+
+// the layer-parallel walk of rule 1 / `cut slant` with a column's rows on adjacent lanes (rt_eclipse_qadj.hpp, built in
+// rt_eclipse_qadj.hip): five angles, rows = 8 or 16; false: no instantiation for this shape
+bool launch_rt_qadj(const RtArgs &b, bool sq, int rows, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
 // ... and for ray grids of 1 .. 9 angles other than five (rt_eclipse_angles.hip, one object per size)
 #define BARTRT_ANGLE_SIZES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(9)
@@ -905,12 +932,15 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     if (info) { info->kernel = "rt_eclipse_simpson_slant (with optical-depth / intensity outputs)"; info->wn_per_column = block; info->ncolumns = a.ntiles; info->prep_fused = false; }
     err = hipSuccess;
     if (launch_rt_slant_out(a, block, nblocks, sh, st, err)) return true;
+    if (rtc_try(info, false, dim3(nblocks), dim3(block), sh, st, a, err, "rt_eclipse_simpson_slant<5, %d, %d, false, 0, false, true>", a.M, a.C)) return true;
   }
   if (!(!a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
-  if (a.cut_slant && (!a.slog || (INTEG == kIntegTrapzTau && a.A != 5))) return false;   // (rule 2 on other ray grids: generic kernel)
+  // (the event log serves rule 1's single-wave kernels only -- rt_eclipse_s1s.hpp, rt_eclipse_s1t.hpp; rule 2 on other
+  // ray grids: generic kernel)
+  if (a.cut_slant && ((INTEG == kIntegSimpson && !a.slog) || (INTEG == kIntegTrapzTau && a.A != 5))) return false;
   if (a.A != 5) {
     // other ray-grid sizes: the single-wave kernel of rule 0 / rule 1 at every batch size
-    if (INTEG == kIntegTrapzTau || a.A < 1 || a.A > 9 || kmode == "quad" || kmode == "octo" || kmode == "split") return false;
+    if (INTEG == kIntegTrapzTau || a.A < 1 || a.A > kMaxAngles || kmode == "quad" || kmode == "octo" || kmode == "split") return false;
     size_t sha = sh;
     int nba = nblocks;
     if (a.nprep > 0) {
@@ -930,6 +960,18 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       BARTRT_ANGLE_SIZES(BARTRT_CASE_ANGLES)
 #undef BARTRT_CASE_ANGLES
       default: break;
+    }
+    if (!done) {
+      // (a ray grid of ten and more angles, or a (molecules, slots) pair outside the ahead-of-time list)
+      const dim3 g(nba), bl(block);
+      if (a.cut_slant)
+        done = INTEG == kIntegTransmittance
+                   ? rtc_try(info, true, g, bl, sha, st, a, err, "rt_eclipse_fast<%d, %d, %d, false, 0, 1, false, true>", a.A, a.M, a.C)
+                   : rtc_try(info, true, g, bl, sha, st, a, err, "rt_eclipse_simpson_slant<%d, %d, %d, false, %d>", a.A, a.M, a.C, a.A <= 6 ? 1 : 0);
+      else
+        done = INTEG == kIntegTransmittance
+                   ? rtc_try(info, true, g, bl, sha, st, a, err, "rt_eclipse_fast<%d, %d, %d, false, 0, 1>", a.A, a.M, a.C)
+                   : rtc_try(info, true, g, bl, sha, st, a, err, "rt_eclipse_simpson<%d, %d, %d, false, 1>", a.A, a.M, a.C);
     }
     if (!done && info) info->prep_fused = false;
     return done;
@@ -978,7 +1020,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
                  : columns <= (a.M <= 2 ? kRows16AllMaxColumnsFewMol : kRows16AllMaxColumns) ? 16
                  : columns <= kOctoAllMaxColumns ? 8 : 4;
       if (rows_env == 4 || rows_env == 8 || rows_env == 16 || rows_env == 32) rows = rows_env;
-      const bool lpa_forced = lp_forced || kmode == "hexa" || kmode == "r32";
+      const bool lpa_forced = lp_forced || kmode == "hexa" || kmode == "r32" || kmode == "adj8" || kmode == "adj16";
       while (rows > 4 && b.window && !window_fits(a, rows)) rows /= 2;
       if (!use_rays && (lpa_forced || (kmode.empty() && columns <= kQuadAllMaxColumns)) && a.cia_bytes < (1ull << 32) - 4096 &&
           (!b.window || window_fits(a, rows))) {
@@ -990,6 +1032,27 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
           info->kernel = rows == 32 ? "rt_eclipse_quad<R=32, all rays per lane>" : rows == 16 ? "rt_eclipse_quad<R=16, all rays per lane>"
                          : rows == 8 ? "rt_eclipse_quad<R=8, all rays per lane>" : "rt_eclipse_quad<R=4, all rays per lane>";
           info->wn_per_column = wnw; info->ncolumns = 4 * b.ntiles;
+        }
+        // the same walk with a column's rows on adjacent lanes (rt_eclipse_qadj.hpp: DPP row shifts instead of
+        // ds_bpermute), 8 or 16 rows; BARTRT_KERNEL=adj8 / adj16 force it, BARTRT_ADJ=1 makes it the choice where 8 / 16 rows are
+        static const int adj_env = [] { const char *v = std::getenv("BARTRT_ADJ"); return v && *v ? atoi(v) : -1; }();
+        const bool adj_forced = kmode == "adj8" || kmode == "adj16";
+        if (adj_forced || (adj_env == 1 && kmode.empty() && (rows == 8 || rows == 16))) {
+          const int ar = kmode == "adj16" ? 16 : kmode == "adj8" ? 8 : rows;
+          const int awn = 64 / ar;
+          RtArgs ba = b;
+          ba.ntiles = (a.W + 4 * awn - 1) / (4 * awn);
+          const int nba = (ba.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
+          const size_t sha = sh + shp + (ar >= 16 ? sizeof(double) * (size_t)a.L : 0);
+          if (!b.window || window_fits(a, ar)) {
+            if (info) {
+              info->kernel = ar == 16 ? "rt_eclipse_qadj<R=16> (rows on adjacent lanes)" : "rt_eclipse_qadj<R=8> (rows on adjacent lanes)";
+              info->wn_per_column = awn; info->ncolumns = 4 * ba.ntiles;
+            }
+            err = hipSuccess;
+            if (launch_rt_qadj(ba, sq, ar, nba, sha, st, err)) return true;
+            if (rtc_try(info, false, dim3(nba), dim3(256), sha, st, ba, err, "rt_eclipse_qadj<5, %d, %d, %s, %d, true>", a.M, a.C, tf(sq), ar)) return true;
+          }
         }
 #define BARTRT_QUADALL_R(MM, CC, RR)                                                                                         \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, RR, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b); \
@@ -1006,6 +1069,9 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         BARTRT_MC_LIST(BARTRT_QUADALL)
 #undef BARTRT_QUADALL
 #undef BARTRT_QUADALL_R
+        if (rtc_try(info, false, dim3(nbq), dim3(256), shq, st, b, err, "rt_eclipse_quad<5, %d, %d, %s, %d, %d, false, true>", a.M, a.C,
+                    tf(sq), rows, INTEG))
+          return true;
       }
     }
     if (use_rays && fits32) {
@@ -1029,6 +1095,9 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
         BARTRT_MC_LIST(BARTRT_QUADRAYS)
 #undef BARTRT_QUADRAYS
+        if (rtc_try(info, false, dim3(nbq), dim3(256), shq, st, b, err, "rt_eclipse_quad<5, %d, %d, false, %d, %d, true>", a.M, a.C,
+                    octor ? 8 : 4, INTEG))
+          return true;
       }
     }
     // ... a team of three waves per column (rule 1) while single-wave columns would load the SIMDs unevenly ...
@@ -1045,6 +1114,11 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       info->wn_per_column = block; info->ncolumns = b.ntiles;
     }
     if (launch_rt_slant(b, INTEG, sq, block, nblocks + pslots, sh + shp, st, err)) return true;
+    if (INTEG == kIntegSimpson
+            ? rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_simpson_slant<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))
+            : rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d, 1, false, true>", a.M,
+                      a.C, tf(sq), INTEG))
+      return true;
     if (info) info->prep_fused = false;
     return false;
   }
@@ -1068,6 +1142,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
     BARTRT_MC_LIST(BARTRT_QUAD)
 #undef BARTRT_QUAD
+    if (rtc_try(info, false, dim3(nbq), dim3(256), shq, st, b, err, "rt_eclipse_quad<5, %d, %d, %s, %d, %d>", a.M, a.C, tf(sq), octo ? 8 : 4, INTEG))
+      return true;
   }
   if (kmode == "split" ||
       (kmode.empty() && INTEG != kIntegSimpson && columns >= kSplitMinColumns && columns <= kSplitMaxColumns)) {
@@ -1084,6 +1160,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
     BARTRT_MC_LIST(BARTRT_SPLIT)
 #undef BARTRT_SPLIT
+    if (rtc_try(info, false, dim3(nbs), dim3(128), shs, st, b, err, "rt_eclipse_split<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), INTEG)) return true;
   }
   b.ntiles = a.ntiles;
   if (info) { info->kernel = "rt_eclipse_fast"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
@@ -1097,6 +1174,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     // resident waves, or drops the record read-ahead for three and waits on LDS instead)
     if (info) info->kernel = "rt_eclipse_simpson (ILP-scheduled build)";
     if (launch_rt_simpson_ilp(b, sq, block, nblocks1, sh1, st, err)) return true;
+    if (rtc_try(info, true, dim3(nblocks1), dim3(block), sh1, st, b, err, "rt_eclipse_simpson<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))) return true;
   } else {
     if (INTEG == kIntegTransmittance && ilp) {
       if (info) info->kernel = "rt_eclipse_fast (ILP-scheduled build)";
@@ -1111,8 +1189,10 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
     BARTRT_MC_LIST(BARTRT_FAST)
 #undef BARTRT_FAST
+    if (rtc_try(info, false, dim3(nblocks1), dim3(block), sh1, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), INTEG)) return true;
   }
   return false;
 }
 
+#endif  // !__HIPCC_RTC__
 }  // namespace bartrt

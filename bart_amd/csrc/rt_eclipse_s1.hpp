@@ -35,7 +35,9 @@
 #include "integ.hpp"
 #include "kernels.hpp"
 
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 namespace bartrt {
 
@@ -295,7 +297,9 @@ void rt_eclipse_simpson(RtArgs p) {
   }
   if (__any(!(fabs(F) < __builtin_huge_val()))) {
     // a zero-width panel somewhere in this wave (or an overflow): the plain accumulator,
-    // one layer at a time
+    // one layer at a time; the lanes whose own result is finite keep it (rt_eclipse_s1s.hpp)
+    const double F_fast = F;
+    const bool fast_ok = fabs(F) < __builtin_huge_val();
     double se = 0.0, ep = 0.0, ep2 = 0.0, tau = 0.0;
     ColumnFlux<kIntegSimpson, A> cf(p);
     bool act = true;
@@ -326,6 +330,7 @@ void rt_eclipse_simpson(RtArgs p) {
       if (!__any(act)) break;
     }
     F = cf.flux(p, A, deck_on && act, 0.0, L);
+    F = fast_ok ? F_fast : F;
   }
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
@@ -333,7 +338,9 @@ void rt_eclipse_simpson(RtArgs p) {
 }
 
 // the ILP-scheduled build (rt_eclipse_i1_ilp.hip), and the line-by-line hand-off
+#ifndef __HIPCC_RTC__
 bool launch_rt_simpson_ilp(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 bool launch_rt_simpson_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+#endif
 
 }  // namespace bartrt

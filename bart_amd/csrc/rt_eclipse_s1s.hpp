@@ -40,7 +40,9 @@
 #include "kernels.hpp"
 #include "rt_eclipse_s1.hpp"
 
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 namespace bartrt {
 
@@ -395,7 +397,12 @@ void rt_eclipse_simpson_slant(RtArgs p) {
     }
   }
   if (__any(!(fabs(F) < __builtin_huge_val()))) {
-    // a zero-width panel somewhere in this wave (or an overflow): ray by ray, one layer at a time
+    // a zero-width panel somewhere in this wave (or an overflow): ray by ray, one layer at a time.  Only the lanes
+    // whose own result is not finite TAKE the slow walk's numbers: a finite lane keeps the bits of the fast walk, so
+    // a wavenumber's result does not depend on which other wavenumbers share its wave (blocks of a sharded grid
+    // start their tiles elsewhere: the concatenated blocks stay the unsharded spectrum bit for bit)
+    const double F_fast = F;
+    const bool fast_ok = fabs(F) < __builtin_huge_val();
     double se = 0.0, ep = 0.0, ep2 = 0.0, tau = 0.0;
     SlantRay<kIntegSimpson> ray[A];
     bool alive_a[A];
@@ -438,9 +445,10 @@ void rt_eclipse_simpson_slant(RtArgs p) {
       const double Ia = ray[a].result(deck_on && alive_a[a], L);
       F += p.wgt[a] * Ia;
       if constexpr (OUT) {
-        if (p.intens_out && valid) p.intens_out[(size_t)a * W + i] = Ia;
+        if (p.intens_out && valid && !fast_ok) p.intens_out[(size_t)a * W + i] = Ia;
       }
     }
+    F = fast_ok ? F_fast : F;
   }
   if constexpr (OUT) {
     if (p.tau_out && valid) {

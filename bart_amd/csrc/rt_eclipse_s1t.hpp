@@ -26,7 +26,9 @@
 #include "kernels.hpp"
 #include "rt_eclipse_s1.hpp"
 
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 namespace bartrt {
 
@@ -400,6 +402,8 @@ void rt_eclipse_slant_team(RtArgs p) {
   if (valid) p.spec[(size_t)w * W + i] = F;
 }
 
+#ifndef __HIPCC_RTC__
 bool launch_rt_slant_team(const RtArgs &b, bool sq, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
+#endif
 
 }  // namespace bartrt

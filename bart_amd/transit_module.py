@@ -95,6 +95,8 @@ def lib():
         L.bartrt_get_cia_interp.argtypes = [C.POINTER(i)]
         L.bartrt_get_share.argtypes = [C.POINTER(i), C.POINTER(i)]
         L.bartrt_get_service.argtypes = [C.POINTER(i)] * 4
+        L.bartrt_get_rtc_stats.argtypes = [C.POINTER(i)] * 4 + [C.POINTER(d)]
+        L.bartrt_rtc_compile.argtypes = [C.c_char_p, i, C.POINTER(C.c_long)]
         L.bartrt_get_service_stats.argtypes = [C.POINTER(C.c_ulonglong)] * 3
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
@@ -219,6 +221,16 @@ def get_share():
     a, b = C.c_int(0), C.c_int(0)
     check(lib().bartrt_get_share(C.byref(a), C.byref(b)))
     return bool(a.value), bool(b.value)
+
+
+def get_rtc_stats():
+    """-> dict(available, compiled, from_disk, failed, compile_seconds): kernels instantiated at run time for shapes
+    outside the ahead-of-time set (include/bartrt.h, bartrt_get_rtc_stats)."""
+    v = [C.c_int(0) for _ in range(4)]
+    s = C.c_double(0.0)
+    check(lib().bartrt_get_rtc_stats(*[C.byref(x) for x in v], C.byref(s)))
+    return {"available": bool(v[0].value), "compiled": v[1].value, "from_disk": v[2].value, "failed": v[3].value,
+            "compile_seconds": s.value}
 
 
 def get_service():

@@ -97,8 +97,11 @@ int bartrt_get_integ(int *rule);
  * engine's call structure is recalled to have -- the optical depth is computed per ray angle, the
  * cut inside that loop; every angle ends on its own layer and rule 1 pads one unit of slant depth.
  * 0 = the vertical depth: the column ends on one layer for every ray angle.  Both run specialised
- * kernels (rules 0, 1 and 2; the slant cut costs 1.10-1.18x per launch); the two differ
- * by about exp(-toomuch) of the flux.  Also the cfg key `cut vertical|slant` and BARTRT_CUT. */
+ * kernels (rules 0, 1 and 2; the slant cut costs 1.10-1.18x per launch, MEASUREMENTS.md); under rule 0
+ * the two differ by about exp(-toomuch) of the flux, under rule 1 (the default) by far more -- the padded
+ * point moves with the cut: 4.6e-3 relative on a 40-layer synthetic column at toomuch 10 (and spline
+ * against linear CIA 3.5e-3: the round-4 change of defaults moved spectra at the 0.5 % level).  Also
+ * the cfg key `cut vertical|slant` and BARTRT_CUT. */
 int bartrt_set_cut(int slant);
 int bartrt_get_cut(int *slant);
 
@@ -115,7 +118,9 @@ int bartrt_get_kernel_by(int *local);
 /* How the engine interpolates the cross-section (CIA) files, fixed at bartrt_init by the cfg key
  * `cia_interp linear|spline` / BARTRT_CIA_INTERP: *spline = 1 (default since round 4)
  * natural cubic splines in wavenumber and temperature, 0 linear in both.  Read-only: the tables are
- * resampled at init. */
+ * resampled at init.  A natural spline may undershoot zero between two samples of a steep table: the
+ * values are used as the spline gives them, NOT clamped (engine and oracle alike) -- a clamp would be
+ * one more unverified convention. */
 int bartrt_get_cia_interp(int *spline);
 
 /* `shareOpacity` (a key of the reference's transit cfg: code/makecfg.py:106-107, BART.py:259-262 --
@@ -314,6 +319,17 @@ int bartrt_timing_end(double *kernel_ms, int *nlaunch);
 int bartrt_walked_begin(void);
 int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *wn_per_column,
                       char *kernel, int kernel_len);
+/* Shapes outside the ahead-of-time set (seven and more table molecules with two cross-section files under the default
+ * spline, nine and more molecules, ten and more ray angles) are instantiated from the same kernel templates when they
+ * are first launched (hiprtc; cached under BARTRT_RTC_CACHE, default ~/.cache/bartrt; BARTRT_RTC=0 or a machine without
+ * libhiprtc: the generic kernel serves them, 3-10x slower).  *available: a compiler is at hand; kernels compiled /
+ * loaded from the disk cache / failed by this process so far, and the seconds spent compiling.  bartrt_walked_end's
+ * kernel name carries " [instantiated at run time]" for such a launch.  Pointers may be NULL. */
+int bartrt_get_rtc_stats(int *available, int *compiled, int *from_disk, int *failed, double *compile_seconds);
+/* Compiles bartrt::<expr> (a template-id of the kernel headers, e.g. "rt_eclipse_simpson_slant<5, 9, 4, true, 1>")
+ * for gfx950 and discards the result: *code_bytes = the code object's size.  Needs no GPU -- a check that the embedded
+ * sources and the compiler at hand agree.  BARTRT_ENOTSUP without a compiler or on a compile error (bartrt_last_error). */
+int bartrt_rtc_compile(const char *expr, int ilp, long *code_bytes);
 /* algorithmic bytes one launch of the RT kernel moves for `nwalkers`
  * (2*L*W*M*8 + 2*L*W*8*ncia + (S+1)*L*8 + W*8 per spectrum) */
 double bartrt_algorithmic_bytes(int nwalkers);

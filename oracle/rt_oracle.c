@@ -228,7 +228,9 @@ static double simps_hybrid(const double *h, const double *y, int n) {
  * from the TOP layer (k = 0) downwards.  Returns intensities per angle and
  * tau[k]; *last_out = index of the deepest layer included.
  *
- * integ = ORC_INTEG_TRAPZ (0, the default):
+ * (The wrapper's default is rule 1, ORC_INTEG_SIMPSON, and the slant cut -- oracle/rt_oracle.py OracleEngine --
+ * the product's defaults since round 4.)
+ * integ = ORC_INTEG_TRAPZ (0):
  *   tau by trapezoid in radius from the top; I = int B d(exp(-tau/mu)),
  *   trapezoid in the transmittance.
  * integ = ORC_INTEG_SIMPSON (1), App. A-4 as recalled:
@@ -271,12 +273,14 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
     last = k;
   }
   if (kend == 0) last = 0;
-  /* The `toomuch` cut (cfg `cut`).  vertical (default): the column ends on the
-   * first layer whose vertical optical depth passes toomuch, for every ray angle.  slant: App.
+  /* The `toomuch` cut (cfg `cut`).  vertical: the column ends on the
+   * first layer whose vertical optical depth passes toomuch, for every ray angle.  slant (the default): App.
    * A-4 read literally -- "slant path ds = dr / cos(theta); tau accumulated from the top; the
    * loop stops where tau > toomuch" -- each ray ends on the first layer whose SLANT depth
    * tau / mu passes toomuch (its own `last`), and rule 1's padded point sits one unit of SLANT
-   * depth further.  The optical depths themselves are the same numbers either way. */
+   * depth further.  The optical depths themselves are the same numbers either way.  The slant depth is
+   * formed as tau * (1 / mu), the product the kernels compare (RtArgs::invmu, slant_thresholds): tau / mu
+   * may round the other way by one ulp on a layer that sits exactly on the cut. */
   int last_v = last;   /* (the slant cuts lie at or above the vertical one: mu <= 1) */
   for (int k = last + 1; k < L; k++) tau[k] = tau[last]; /* not computed deeper */
   double *f = (double *)malloc(sizeof(double) * (L + 1));
@@ -286,15 +290,16 @@ static void column_eclipse(const rt_oracle_cfg *c, double wn, int L,
   for (int k = 0; k <= last_v; k++) bk[k] = orc_planck(wn, t_col[k]);
   for (int a = 0; a < A; a++) {
     double mu = cos(c->angles_deg[a] * ORC_PI / 180.0);
+    const double invmu = 1.0 / mu;
     int last = last_v;
     if (c->cut_slant) {
       last = kend;
       for (int k = 1; k <= kend; k++)
-        if (tau[k] / mu > c->toomuch) { last = k; break; }
+        if (tau[k] * invmu > c->toomuch) { last = k; break; }
       if (last > last_v) last = last_v;
     }
     const int deck = kcloud >= 0 && last == kcloud &&
-                     !((c->cut_slant ? tau[last] / mu : tau[last]) > c->toomuch);
+                     !((c->cut_slant ? tau[last] * invmu : tau[last]) > c->toomuch);
     for (int k = 0; k <= last; k++) {
       ek[k] = exp(-tau[k] / mu);
       f[k] = bk[k] * ek[k];

@@ -152,3 +152,23 @@ def test_generated_coefficient_tables_are_reproducible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_imw_table.py"), "--check"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "identical to the header: True" in r.stdout, r.stdout + r.stderr
+
+
+def test_embedded_kernel_sources_compile_at_run_time(lib):
+    """csrc/rtc.hpp: shapes outside the ahead-of-time set are instantiated from the kernel headers embedded in the library
+    (hiprtc).  No GPU is needed to COMPILE: one kernel of each family the launcher may ask for, on shapes the library
+    does not ship -- the embedded text, its !__HIPCC_RTC__ guards and the compiler at hand agree."""
+    import ctypes as C
+    avail = C.c_int(0)
+    assert lib.bartrt_get_rtc_stats(C.byref(avail), None, None, None, None) == 0
+    if not avail.value:
+        pytest.skip("no libhiprtc.so on this machine")
+    for expr, ilp in (("rt_eclipse_simpson_slant<5, 9, 4, true, 1>", 1),
+                      ("rt_eclipse_quad<5, 7, 4, false, 16, 1, false, true>", 0),
+                      ("rt_eclipse_qadj<5, 8, 4, true, 16, true>", 0),
+                      ("rt_eclipse_fast<12, 4, 2, false, 0, 1, false, true>", 1)):
+        n = C.c_long(0)
+        rc = lib.bartrt_rtc_compile(expr.encode(), ilp, C.byref(n))
+        assert rc == 0 and n.value > 10000, (expr, lib.bartrt_last_error().decode()[:2000])
+    n = C.c_long(0)
+    assert lib.bartrt_rtc_compile(b"rt_eclipse_no_such_kernel<1>", 0, C.byref(n)) == -4 and n.value < 0

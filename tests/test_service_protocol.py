@@ -35,12 +35,23 @@ def run(exe, key, n, rounds, env=None, die=None, ranks=None):
     return out
 
 
-def leftovers():
-    return [f for f in os.listdir("/dev/shm") if f.startswith("bartrt_svctest_")]
+def seg_name(key):
+    """svc::hashed_name("bartrt_svctest_", key): FNV-1a, as the harness names its segment."""
+    h = 1469598103934665603
+    for c in key.encode():
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "bartrt_svctest_%016x" % h
+
+
+def leftovers(key):
+    """What the run on `key` left in /dev/shm (segment and lock file)."""
+    n = seg_name(key)
+    return [f for f in os.listdir("/dev/shm") if f in (n, n + ".lock")]
 
 
 def test_eight_workers_one_owner_batched_and_exact(harness):
-    res = run(harness, "a%f" % time.time(), 8, 400)
+    key = "a%f" % time.time()
+    res = run(harness, key, 8, 400)
     assert all(rc == 0 for rc, _ in res)
     rep = [r for _, r in res]
     assert sum(r["owner"] for r in rep) == 1
@@ -50,14 +61,15 @@ def test_eight_workers_one_owner_batched_and_exact(harness):
     # ... by far fewer rounds than calls (3200 calls): the workers' profiles went out together
     assert owner["served"] == 3200
     assert owner["batches"] < 1200, owner
-    assert not leftovers()
+    assert not leftovers(key)
 
 
 def test_a_single_worker_is_served_at_once(harness):
-    (rc, r), = run(harness, "b%f" % time.time(), 1, 300)
+    key = "b%f" % time.time()
+    (rc, r), = run(harness, key, 1, 300)
     assert rc == 0 and r["owner"] and r["done"] == 300 and r["bad"] == 0 and r["batches"] == 300
     assert r["us_per_call"] < 2000
-    assert not leftovers()
+    assert not leftovers(key)
 
 
 def test_owner_killed_mid_run_is_a_clean_error_and_the_name_is_taken_over(harness):
@@ -71,15 +83,15 @@ def test_owner_killed_mid_run_is_a_clean_error_and_the_name_is_taken_over(harnes
     rep = [json.loads(p.communicate(timeout=60)[0]) for p in others]
     for r in rep:
         assert not r["owner"] and r["err"] == -3 and "gone" in r["msg"], r       # BARTRT_ENODEV, no hang, no crash
-        assert r["bad"] == 0 and 0 < r["done"] < 100000
+        assert r["bad"] == 0 and 0 <= r["done"] < 100000
     # the dead owner's name is still there ...
-    assert leftovers()
+    assert leftovers(key)
     # ... and six processes that start together on it agree on ONE new owner (the takeover is serialised)
     res = run(harness, key, 6, 50)
     rep = [r for _, r in res]
     assert sum(r["owner"] for r in rep) == 1
     assert all(r["done"] == 50 and r["bad"] == 0 for r in rep), rep
-    assert not leftovers()
+    assert not leftovers(key)
 
 
 def test_owner_that_fails_to_start_tells_its_clients_why(harness):
@@ -93,14 +105,15 @@ def test_owner_that_fails_to_start_tells_its_clients_why(harness):
             # a client that was waiting hears the reason; one that came after the name was gone may have become the
             # next owner (and failed the same way)
             assert r.get("attach_error") == -3 and "did not start" in r["msg"], r
-    assert not leftovers()
+    assert not leftovers(key)
 
 
 def test_a_failed_batch_fails_its_callers_only(harness):
-    res = run(harness, "e%f" % time.time(), 3, 40, env={"SVC_HARNESS_FAIL_BATCH": "1"})
+    key = "e%f" % time.time()
+    res = run(harness, key, 3, 40, env={"SVC_HARNESS_FAIL_BATCH": "1"})
     rep = [r for _, r in res]
     assert sum(r["owner"] for r in rep) == 1
     assert any(r["err"] == -1 and "stand-in failure" in r["msg"] for r in rep)
     # everybody kept going afterwards
     assert all(r["done"] >= 39 and r["bad"] == 0 for r in rep), rep
-    assert not leftovers()
+    assert not leftovers(key)

@@ -836,6 +836,9 @@ namespace bartrt {
 // generic kernel as before.
 inline bool rtc_try(RtLaunchInfo *info, bool ilp, dim3 grid, dim3 block, size_t sh, hipStream_t st, const RtArgs &b,
                     hipError_t &err, const char *fmt, ...) {
+  // (engines without an opacity table -- cross sections only, the line-by-line hand-off -- keep the generic kernel / the
+  // EXT builds: the table kernels were never instantiated, let alone tested, for zero molecules)
+  if (b.M < 1) return false;
   char ex[192];
   va_list ap;
   va_start(ap, fmt);
@@ -1022,6 +1025,36 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       if (rows_env == 4 || rows_env == 8 || rows_env == 16 || rows_env == 32) rows = rows_env;
       const bool lpa_forced = lp_forced || kmode == "hexa" || kmode == "r32" || kmode == "adj8" || kmode == "adj16";
       while (rows > 4 && b.window && !window_fits(a, rows)) rows /= 2;
+      // The same walk with a column's rows on ADJACENT lanes (rt_eclipse_qadj.hpp: DPP row shifts instead of ds_bpermute,
+      // carries in place), where it was measured ahead (round 5, us per launch, this kernel / the choice before it):
+      //   bench shape, W = 1e4: 157 columns 34.6 / 38.2 (R = 8), 314 columns 50.2 / 57.7 (single wave), 471: 70 / 58 -- not
+      //   there; W = 5 000: 79 columns 24.5 / 25.9, 158: 34.8 / 37.0, 237: 40.4 / 37.1 -- not there, 316: 49.5 / 58.6
+      //   demo shape (one molecule): 40 / 80 columns 16.2 / 15.4, 19.5 / 18.2 -- not there (R = 32 stays), 120: 19.6 / 21.4,
+      //   160: 27.9 / 25.8 -- not there, 200: 29.6 / 32.7 and 240: 29.0 / 32.6 with eight rows
+      // BARTRT_KERNEL=adj8 / adj16 force it, BARTRT_ADJ=0 switches it off.
+      static const int adj_env = [] { const char *v = std::getenv("BARTRT_ADJ"); return v && *v ? atoi(v) : -1; }();
+      int adj_rows = kmode == "adj8" ? 8 : kmode == "adj16" ? 16 : 0;
+      if (kmode.empty() && adj_env != 0 && rows_env == 0) {
+        if (a.M >= 3) adj_rows = ((columns > 64 && columns <= 176) || (columns > 280 && columns <= 330)) ? 16 : 0;
+        else adj_rows = (columns > 96 && columns <= 140) ? 16 : (columns > 176 && columns <= 256) ? 8 : 0;
+      }
+      if (adj_rows && !use_rays && a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, adj_rows))) {
+        const int awn = 64 / adj_rows;
+        RtArgs ba = b;
+        ba.ntiles = (a.W + 4 * awn - 1) / (4 * awn);
+        const int nba = (ba.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
+        const size_t sha = sh + shp + (adj_rows >= 16 ? sizeof(double) * (size_t)a.L : 0);
+        RtLaunchInfo keep;
+        if (info) {
+          keep = *info;
+          info->kernel = adj_rows == 16 ? "rt_eclipse_qadj<R=16> (rows on adjacent lanes)" : "rt_eclipse_qadj<R=8> (rows on adjacent lanes)";
+          info->wn_per_column = awn; info->ncolumns = 4 * ba.ntiles;
+        }
+        err = hipSuccess;
+        if (launch_rt_qadj(ba, sq, adj_rows, nba, sha, st, err)) return true;
+        if (rtc_try(info, false, dim3(nba), dim3(256), sha, st, ba, err, "rt_eclipse_qadj<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), adj_rows)) return true;
+        if (info) *info = keep;    // (neither an instantiation nor a compiler: the choice before it)
+      }
       if (!use_rays && (lpa_forced || (kmode.empty() && columns <= kQuadAllMaxColumns)) && a.cia_bytes < (1ull << 32) - 4096 &&
           (!b.window || window_fits(a, rows))) {
         const int wnw = 64 / rows;   // wavenumbers per wave
@@ -1032,27 +1065,6 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
           info->kernel = rows == 32 ? "rt_eclipse_quad<R=32, all rays per lane>" : rows == 16 ? "rt_eclipse_quad<R=16, all rays per lane>"
                          : rows == 8 ? "rt_eclipse_quad<R=8, all rays per lane>" : "rt_eclipse_quad<R=4, all rays per lane>";
           info->wn_per_column = wnw; info->ncolumns = 4 * b.ntiles;
-        }
-        // the same walk with a column's rows on adjacent lanes (rt_eclipse_qadj.hpp: DPP row shifts instead of
-        // ds_bpermute), 8 or 16 rows; BARTRT_KERNEL=adj8 / adj16 force it, BARTRT_ADJ=1 makes it the choice where 8 / 16 rows are
-        static const int adj_env = [] { const char *v = std::getenv("BARTRT_ADJ"); return v && *v ? atoi(v) : -1; }();
-        const bool adj_forced = kmode == "adj8" || kmode == "adj16";
-        if (adj_forced || (adj_env == 1 && kmode.empty() && (rows == 8 || rows == 16))) {
-          const int ar = kmode == "adj16" ? 16 : kmode == "adj8" ? 8 : rows;
-          const int awn = 64 / ar;
-          RtArgs ba = b;
-          ba.ntiles = (a.W + 4 * awn - 1) / (4 * awn);
-          const int nba = (ba.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
-          const size_t sha = sh + shp + (ar >= 16 ? sizeof(double) * (size_t)a.L : 0);
-          if (!b.window || window_fits(a, ar)) {
-            if (info) {
-              info->kernel = ar == 16 ? "rt_eclipse_qadj<R=16> (rows on adjacent lanes)" : "rt_eclipse_qadj<R=8> (rows on adjacent lanes)";
-              info->wn_per_column = awn; info->ncolumns = 4 * ba.ntiles;
-            }
-            err = hipSuccess;
-            if (launch_rt_qadj(ba, sq, ar, nba, sha, st, err)) return true;
-            if (rtc_try(info, false, dim3(nba), dim3(256), sha, st, ba, err, "rt_eclipse_qadj<5, %d, %d, %s, %d, true>", a.M, a.C, tf(sq), ar)) return true;
-          }
         }
 #define BARTRT_QUADALL_R(MM, CC, RR)                                                                                         \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_quad<5, MM, CC, true, RR, INTEG, false, true>), dim3(nbq), dim3(256), shq, st, b); \

@@ -7,13 +7,9 @@ namespace bartrt {
 
 bool launch_rt_qadj(const RtArgs &b, bool sq, int rows, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
   if (b.A != 5) return false;
-  static const bool deep = [] { const char *v = std::getenv("BARTRT_QADJ_DEEP"); return !(v && v[0] == '0'); }();   // A/B: 0 = one step ahead
 #define BARTRT_QADJ(MM, CC)                                                                                       \
   if (b.M == MM && b.C == CC) {                                                                                   \
-    if (!deep) {                                                                                                  \
-      if (rows == 16) BARTRT_RT_LAUNCH((rt_eclipse_qadj<5, MM, CC, true, 16, false>), dim3(nblocks), dim3(256), sh, st, b); \
-      else BARTRT_RT_LAUNCH((rt_eclipse_qadj<5, MM, CC, true, 8, false>), dim3(nblocks), dim3(256), sh, st, b);  \
-    } else if (rows == 16) {                                                                                      \
+    if (rows == 16) {                                                                                             \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_qadj<5, MM, CC, true, 16>), dim3(nblocks), dim3(256), sh, st, b);      \
       else BARTRT_RT_LAUNCH((rt_eclipse_qadj<5, MM, CC, false, 16>), dim3(nblocks), dim3(256), sh, st, b);        \
     } else {                                                                                                      \

@@ -57,8 +57,8 @@ __device__ __forceinline__ double rows_prefix_max(double v, int q) {   // (value
   return v;
 }
 
-template <int AT, int MT, int CT, bool SQ, int R, bool DEEP = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rt_eclipse_qadj(RtArgs p) {
+template <int AT, int MT, int CT, bool SQ, int R>
+__global__ __launch_bounds__(256) void rt_eclipse_qadj(RtArgs p) {
   static_assert(R == 8 || R == 16, "a column's rows lie inside one 16-lane DPP row");
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
@@ -244,42 +244,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // rule 1 may need the row after the column's last layer for the padded point
   const int klast = kend + 1 < L ? kend + 1 : L - 1;
-  // Loads in flight ahead of the step that uses them: two steps' worth (three register slots).  The launches this
-  // kernel serves are bound by round trips to memory, not by arithmetic -- a step's time follows the number of table
-  // loads it waits for (1.2 us on the one-molecule demo grid, 2.4 us with four molecules) -- and 176-200 registers
-  // leave room for a third slot under the 256 of two waves per SIMD.  DEEP = false: one step ahead (two slots).
-  double rbuf[DEEP ? 3 : 2][NR];
+  // Loads in flight ahead of the step that uses them: the next step's.  (Two steps ahead -- a third register slot, 256
+  // registers with a handful of spills at four molecules -- was measured in round 5: no gain on either grid, 35.2 -> 36.6 us
+  // for one walker at W = 1e4.  Nor does the launch react to the max-ILP schedule or to a table that fits the Infinity
+  // Cache: MEASUREMENTS.md, round 5.)
+  double rbuf[2][NR];
   int slast = 0;   // the last step walked
-  if constexpr (DEEP) {
-    load_layer(clampk(qe), rbuf[0]);
-    load_layer(clampk(R + qo), rbuf[1]);
-#define BARTRT_QADJ_STEP(T, ODD, BUF, PBUF)                                                        \
-    if (R * (s + T) > klast) break;                                                                \
-    load_layer(clampk(R * (s + T + 2) + ((ODD) ? qo : qe)), rbuf[PBUF]);                           \
-    step(s + T, rbuf[BUF], std::integral_constant<bool, ODD>{});                                   \
-    slast = s + T;                                                                                 \
+  load_layer(clampk(qe), rbuf[0]);
+  for (int s = 0; R * s <= klast; s += 2) {
+    load_layer(clampk(R * (s + 1) + qo), rbuf[1]);
+    step(s, rbuf[0], std::false_type{});
+    slast = s;
+    if (!__any(active) || R * (s + 1) > klast) break;
+    load_layer(clampk(R * (s + 2) + qe), rbuf[0]);
+    step(s + 1, rbuf[1], std::true_type{});
+    slast = s + 1;
     if (!__any(active)) break;
-    for (int s = 0;; s += 6) {
-      BARTRT_QADJ_STEP(0, false, 0, 2)
-      BARTRT_QADJ_STEP(1, true, 1, 0)
-      BARTRT_QADJ_STEP(2, false, 2, 1)
-      BARTRT_QADJ_STEP(3, true, 0, 2)
-      BARTRT_QADJ_STEP(4, false, 1, 0)
-      BARTRT_QADJ_STEP(5, true, 2, 1)
-    }
-#undef BARTRT_QADJ_STEP
-  } else {
-    load_layer(clampk(qe), rbuf[0]);
-    for (int s = 0; R * s <= klast; s += 2) {
-      load_layer(clampk(R * (s + 1) + qo), rbuf[1]);
-      step(s, rbuf[0], std::false_type{});
-      slast = s;
-      if (!__any(active) || R * (s + 1) > klast) break;
-      load_layer(clampk(R * (s + 2) + qe), rbuf[0]);
-      step(s + 1, rbuf[1], std::true_type{});
-      slast = s + 1;
-      if (!__any(active)) break;
-    }
   }
   // the rows of a wavenumber hold its layers' terms.  Each ray's last point is its padded row (known to the lane that
   // evaluated it) or the column's last layer; the terms of the rows of that parity are added up, one lane writes.

@@ -165,7 +165,7 @@ def test_embedded_kernel_sources_compile_at_run_time(lib):
         pytest.skip("no libhiprtc.so on this machine")
     for expr, ilp in (("rt_eclipse_simpson_slant<5, 9, 4, true, 1>", 1),
                       ("rt_eclipse_quad<5, 7, 4, false, 16, 1, false, true>", 0),
-                      ("rt_eclipse_qadj<5, 8, 4, true, 16, true>", 0),
+                      ("rt_eclipse_qadj<5, 8, 4, true, 16>", 0),
                       ("rt_eclipse_fast<12, 4, 2, false, 0, 1, false, true>", 1)):
         n = C.c_long(0)
         rc = lib.bartrt_rtc_compile(expr.encode(), ilp, C.byref(n))

@@ -629,17 +629,19 @@ def test_cia_interpolated_by_splines(tmp_path, npairs, solution):
 def test_default_kernel_choice_under_cut_slant(demo_case, small_case):
     """The launcher's table under the default conventions (csrc/rt_eclipse.hpp, rule 1, `cut slant`): the all-rays
     layer-parallel kernel with 32 / 16 / 8 layers per step by the 64-wide columns of the launch -- to 96 / 176 / 256
-    columns on grids of one or two table molecules, 64 / 128 / 256 otherwise -- and the single-wave kernel beyond; every
+    columns on grids of one or two table molecules, 64 / 128 / 256 otherwise -- its adjacent-rows form
+    (rt_eclipse_qadj.hpp) on the column ranges where it was measured ahead, and the single-wave kernel beyond; every
     choice against the oracle on two walkers' whole spectra."""
     from bart_amd import engine, transit_module as trm
     from oracle import rt_oracle as orc
     # (case, walkers) -> columns = walkers * ceil(W / 64) and the kernel that goes with them
-    table = [(demo_case, 1, "R=32, all rays"), (demo_case, 2, "R=32, all rays"), (demo_case, 3, "R=16, all rays"),
-             (demo_case, 4, "R=16, all rays"), (demo_case, 5, "R=8, all rays"), (demo_case, 6, "R=8, all rays"),
+    table = [(demo_case, 1, "R=32, all rays"), (demo_case, 2, "R=32, all rays"), (demo_case, 3, "qadj<R=16>"),
+             (demo_case, 4, "R=16, all rays"), (demo_case, 5, "qadj<R=8>"), (demo_case, 6, "qadj<R=8>"),
              (demo_case, 7, "rt_eclipse_simpson_slant"),
-             (small_case, 1, "R=32, all rays"), (small_case, 4, "R=32, all rays"), (small_case, 5, "R=16, all rays"),
-             (small_case, 9, "R=16, all rays"), (small_case, 10, "R=8, all rays"), (small_case, 19, "R=8, all rays"),
-             (small_case, 20, "rt_eclipse_simpson_slant")]
+             (small_case, 1, "R=32, all rays"), (small_case, 4, "R=32, all rays"), (small_case, 5, "qadj<R=16>"),
+             (small_case, 9, "qadj<R=16>"), (small_case, 13, "qadj<R=16>"), (small_case, 14, "R=8, all rays"),
+             (small_case, 19, "R=8, all rays"), (small_case, 20, "rt_eclipse_simpson_slant"), (small_case, 22, "qadj<R=16>"),
+             (small_case, 25, "qadj<R=16>"), (small_case, 26, "rt_eclipse_simpson_slant")]
     for case in (demo_case, small_case):
         engine.init(case.tcfg)
         try:

@@ -57,9 +57,13 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kms, nl = engine.timing_end()
+        engine.walked_begin()
+        engine.run_batch_dev(d_prof[0], out)
+        torch.cuda.synchronize()
+        kname = engine.walked_end()[2]
         print(json.dumps({"shape": "%s, %d molecules, %d CIA pairs, %d layers x %d samples, %d ray angles, integ %d"
                           % (a.solution, a.nmol, a.cia, a.layers, a.nwave, a.angles, trm.get_integ()),
-                          "kernel": os.environ.get("BARTRT_KERNEL", "default"), "walkers": n,
+                          "kernel": os.environ.get("BARTRT_KERNEL", "default"), "launched": kname, "rtc": trm.get_rtc_stats(), "walkers": n,
                           "spectra_per_s": round(n * steps / dt), "ms_per_step": round(dt / steps * 1e3, 4),
                           "rt_kernel_ms": round(kms / max(nl, 1), 4)}), flush=True)
     trm.free_memory()

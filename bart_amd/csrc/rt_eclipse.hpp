@@ -849,6 +849,12 @@ inline bool rtc_try(RtLaunchInfo *info, bool ilp, dim3 grid, dim3 block, size_t 
   return true;
 }
 inline const char *tf(bool b) { return b ? "true" : "false"; }
+// The single-wave kernels keep three slots of 2 M + 2 C loads in flight: beyond 20 loads per layer (the widest shapes
+// of the ahead-of-time list: eight molecules with two slots, six with four) they spill and the generic kernel is as
+// fast or faster at ten walkers and up (round 5, W = 1e4: 7 molecules + 4 slots 507 against 585 us at ten walkers,
+// 2 258 / 2 250 at 64; 9 + 2: 448 / 456 and 1 885 / 1 688) -- such shapes are instantiated for the layer-parallel
+// kernels only (one walker: 58 against 245 us), their batches stay with the generic kernel.
+inline bool rtc_single_wave_ok(const RtArgs &a) { return 2 * a.M + 2 * a.C <= 20; }
 // If one ray angle has exactly half the cosine of another (0 and 60 degrees of
 // the usual raygrid 0 20 40 60 80), put that pair first and last: the SQ kernels
 // take the last transmittance as the square of the first.
@@ -935,7 +941,9 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     if (info) { info->kernel = "rt_eclipse_simpson_slant (with optical-depth / intensity outputs)"; info->wn_per_column = block; info->ncolumns = a.ntiles; info->prep_fused = false; }
     err = hipSuccess;
     if (launch_rt_slant_out(a, block, nblocks, sh, st, err)) return true;
-    if (rtc_try(info, false, dim3(nblocks), dim3(block), sh, st, a, err, "rt_eclipse_simpson_slant<5, %d, %d, false, 0, false, true>", a.M, a.C)) return true;
+    if (rtc_single_wave_ok(a) &&
+        rtc_try(info, false, dim3(nblocks), dim3(block), sh, st, a, err, "rt_eclipse_simpson_slant<5, %d, %d, false, 0, false, true>", a.M, a.C))
+      return true;
   }
   if (!(!a.intens_out && !a.tau_out && plane_ok && sh <= 55 * 1024)) return false;
   // (the event log serves rule 1's single-wave kernels only -- rt_eclipse_s1s.hpp, rt_eclipse_s1t.hpp; rule 2 on other
@@ -964,7 +972,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
 #undef BARTRT_CASE_ANGLES
       default: break;
     }
-    if (!done) {
+    if (!done && rtc_single_wave_ok(a)) {
       // (a ray grid of ten and more angles, or a (molecules, slots) pair outside the ahead-of-time list)
       const dim3 g(nba), bl(block);
       if (a.cut_slant)
@@ -1126,6 +1134,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       info->wn_per_column = block; info->ncolumns = b.ntiles;
     }
     if (launch_rt_slant(b, INTEG, sq, block, nblocks + pslots, sh + shp, st, err)) return true;
+    if (!rtc_single_wave_ok(a)) { if (info) info->prep_fused = false; return false; }
     if (INTEG == kIntegSimpson
             ? rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_simpson_slant<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))
             : rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d, 1, false, true>", a.M,
@@ -1186,7 +1195,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     // resident waves, or drops the record read-ahead for three and waits on LDS instead)
     if (info) info->kernel = "rt_eclipse_simpson (ILP-scheduled build)";
     if (launch_rt_simpson_ilp(b, sq, block, nblocks1, sh1, st, err)) return true;
-    if (rtc_try(info, true, dim3(nblocks1), dim3(block), sh1, st, b, err, "rt_eclipse_simpson<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))) return true;
+    if (rtc_single_wave_ok(a) && rtc_try(info, true, dim3(nblocks1), dim3(block), sh1, st, b, err, "rt_eclipse_simpson<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))) return true;
   } else {
     if (INTEG == kIntegTransmittance && ilp) {
       if (info) info->kernel = "rt_eclipse_fast (ILP-scheduled build)";
@@ -1201,7 +1210,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   }
     BARTRT_MC_LIST(BARTRT_FAST)
 #undef BARTRT_FAST
-    if (rtc_try(info, false, dim3(nblocks1), dim3(block), sh1, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), INTEG)) return true;
+    if (rtc_single_wave_ok(a) && rtc_try(info, false, dim3(nblocks1), dim3(block), sh1, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), INTEG)) return true;
   }
   return false;
 }

@@ -1,6 +1,6 @@
 """Shapes outside the ahead-of-time set: seven / eight table molecules with two cross-section files
 under the default spline (four slots), nine and more molecules, three cross-section files, ten and more ray angles used
-to take the generic kernel, 3-10x slower.  They are instantiated from the same kernel templates at their first launch
+to take the generic kernel, 3-4x slower on the few-walker launches.  They are instantiated from the same kernel templates at their first launch
 (csrc/rtc.hpp, hiprtc), cached on disk, and held to the oracle like every other kernel; with BARTRT_RTC=0 the generic
 kernel still serves them."""
 import json
@@ -57,17 +57,23 @@ def test_shapes_outside_the_aot_set_are_instantiated_and_match_the_oracle(tmp_pa
               ("m9v0", dict(cia=1, **many_molecules(9)), 0, "vertical"),         # another rule, the other cut
               ("m7c4i2", dict(cia=2, **many_molecules(7)), 2, None)]
     jobs, cases = [], {}
-    nws = (1, 3, 12)
+    nws = (1, 3, 12, 70)      # (5 columns per walker: 70 walkers = 350 columns, past the layer-parallel kernels' range)
     for name, kw, integ, cut in shapes:
         c = synth.make_case(str(tmp_path / name), nlayers=61, nwave=300, tlow=400.0, thigh=3000.0, tempdelt=650.0, **kw)
-        profs = walkers(c, 12, seed=31)
+        profs = walkers(c, 70, seed=31)
         np.save(os.path.join(c.dir, "p.npy"), profs)
         jobs.append((c.tcfg, os.path.join(c.dir, "p.npy"), os.path.join(c.dir, "s.npy"), nws, integ, cut))
         cases[name] = (c, integ, cut)
     rep = run_child(jobs, {"BARTRT_RTC_CACHE": cache})
     assert rep["rtc"]["available"] and rep["rtc"]["compiled"] >= 8 and rep["rtc"]["failed"] == 0, rep["rtc"]
+    wide = ("m7c4", "m8c4", "m9c2", "m7c4i2")       # more than 20 loads per layer, single-wave kernel at 350 columns (m9v0: rule 0 + vertical cut keeps the layer-parallel kernel to 640)
     for key, kname in rep["names"].items():
-        assert "generic" not in kname and "instantiated at run time" in kname, (key, kname)
+        shape = os.path.basename(os.path.dirname(key.split("|")[0]))
+        if key.endswith("|70") and shape in wide:
+            # the single-wave kernels spill on these shapes: their BATCHES stay with the generic kernel (measured equal or faster)
+            assert "generic" in kname, (key, kname)
+        else:
+            assert "generic" not in kname and "instantiated at run time" in kname, (key, kname)
     for name, (c, integ, cut) in cases.items():
         profs = np.load(os.path.join(c.dir, "p.npy"))
         o = orc.OracleEngine(c.tcfg, integ=integ, cut=cut)

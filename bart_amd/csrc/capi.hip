@@ -739,13 +739,6 @@ int bartrt_step_batch_dev(const double *d_params, int nwalkers, int npars,
   });
 }
 
-int bartrt_step_get_band_fused(int *fused) {
-  NEED_ENGINE();
-  if (!g_eng->step || !fused) return fail(BARTRT_EINVAL, "step_get_band_fused: call bartrt_step_setup first");
-  *fused = g_eng->step->last_band_fused ? 1 : 0;
-  return BARTRT_OK;
-}
-
 int bartrt_step_set_extras(int nrad, int ncloud, int nray) {
   NEED_ENGINE();
   return guarded([&] {

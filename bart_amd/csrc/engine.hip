@@ -781,12 +781,6 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     }
     r.slog = d_slog;
   }
-  r.band = nullptr; r.band_out = nullptr; r.band_status = r.band_status_out = nullptr;
-  if (band_once && solution == 0 && !lbl && !d_ext && !lbl_fused && !want_tau && !want_intens && lo == 0 && hi == Wfull && block == 64) {
-    r.band = band_once; r.band_out = band_out_once; r.band_status = band_status_once; r.band_status_out = band_status_out_once;
-  }
-  band_once = nullptr;
-  band_done = false;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
   r.transparent = transparent ? 1 : 0;
   // Timing: the RT kernel's own dispatch stamps the two events (BARTRT_RT_LAUNCH) -- no marker
@@ -824,7 +818,6 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   else {
     RtLaunchInfo li;
     HIPCHK(launch_rt(r, block, st, &li));
-    band_done = li.band_fused;
     if (want_walked) walked_info = li;
     if (want_next && li.prep_fused) {
       pf_have_prof = pf_req_prof; pf_have_n = pf_req_n; pf_have_buf = 1 - bset;

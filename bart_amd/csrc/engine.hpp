@@ -94,12 +94,6 @@ struct Engine {
   // parameter is among them, so the RT kernels add the deck's surface term
   const double *prep_over_once = nullptr;
   bool prep_over_cloud = false;
-  // band integration in the tail of the NEXT RT launch (step.hip sets these, run_chunk consumes them; band_done: the
-  // launched kernel ran it -- otherwise the caller launches step_bandflux as before)
-  const BandDev *band_once = nullptr;
-  double *band_out_once = nullptr;
-  int *band_status_once = nullptr, *band_status_out_once = nullptr;
-  bool band_done = false;
   // diagnostics of the next RT launches: layers walked per (walker, kernel column)
   bool want_walked = false;
   int *d_walked = nullptr;

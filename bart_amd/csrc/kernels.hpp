@@ -193,17 +193,6 @@ struct PrepArgs {
   double *ds;              // [nw][chord_table_size(L)]
 };
 
-// Band integration as the tail of the single-wave RT kernel (band_tail.hpp; set up by step.hip)
-struct BandDev {
-  int F, ebalance;           // filters; energy-balance check on
-  double e_in, e_fac;        // reject when (sum_i spec_i qe_i) * e_fac > e_in
-  const int *idx0, *npts, *woff;   // [F] first sample, samples, offset into q of each filter's window
-  const double *q;           // [sum npts] filter weight x trapezoid coefficient of each window sample
-  const double *qe;          // [W] trapezoid coefficient of every sample of the grid
-  double *part;              // [walkers][tiles][F + 1] the workgroups' shares
-  unsigned *count;           // [walkers] workgroups that have delivered (returns to 0 with the last one)
-};
-
 struct RtArgs {
   int L, M, Nt, C, A, W, nwalkers, ntiles;
   int Wfull;               // samples of the whole grid (W: this process's block of it): the kernel variant is chosen by
@@ -250,11 +239,6 @@ struct RtArgs {
   // the other set of record buffers -- the next call then starts on its RT kernel directly.
   int nprep;
   PrepArgs prep_next;
-  // band integration in the kernel's tail (null: the spectrum only): BandDev in device memory, the step's outputs
-  const BandDev *band;
-  double *band_out;          // [walkers][F]
-  int *band_status;          // [walkers] in: 0 / 1 / 2 from the profile stage; out: 3 where the energy balance rejects
-  int *band_status_out;      // optional copy of the final status (host-mapped)
 };
 __host__ __device__ inline int prep_slots(int nprep) { return (nprep + 7) / 8 * 8; }
 
@@ -292,7 +276,6 @@ struct RtLaunchInfo {
   int wn_per_column = 64;   // granularity of RtArgs::walked_out
   int ncolumns = 0;         // entries of walked_out per walker
   bool prep_fused = false;  // the launch carried RtArgs::nprep workgroups of the next batch's preparation
-  bool band_fused = false;  // the launch ran the band integration in its tail (RtArgs::band)
   bool rtc = false;         // the kernel was instantiated at run time (rtc.hpp), not taken from the ahead-of-time set
 };
 

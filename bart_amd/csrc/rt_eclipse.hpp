@@ -1133,17 +1133,13 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       info->kernel = INTEG == kIntegSimpson ? "rt_eclipse_simpson_slant (ILP-scheduled build)" : "rt_eclipse_fast<SLANT> (ILP-scheduled build)";
       info->wn_per_column = block; info->ncolumns = b.ntiles;
     }
-    // (rule 1's kernel runs the step's band integration in its tail when asked to: RtArgs::band, band_tail.hpp)
-    const bool band = INTEG == kIntegSimpson && a.band != nullptr && block == 64;
-    if (launch_rt_slant(b, INTEG, sq, block, nblocks + pslots, sh + shp, st, err)) { if (info) info->band_fused = band; return true; }
+    if (launch_rt_slant(b, INTEG, sq, block, nblocks + pslots, sh + shp, st, err)) return true;
     if (!rtc_single_wave_ok(a)) { if (info) info->prep_fused = false; return false; }
     if (INTEG == kIntegSimpson
             ? rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_simpson_slant<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))
             : rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d, 1, false, true>", a.M,
-                      a.C, tf(sq), INTEG)) {
-      if (info) info->band_fused = band;
+                      a.C, tf(sq), INTEG))
       return true;
-    }
     if (info) info->prep_fused = false;
     return false;
   }

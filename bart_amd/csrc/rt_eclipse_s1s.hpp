@@ -39,7 +39,6 @@
 #include "integ.hpp"
 #include "kernels.hpp"
 #include "rt_eclipse_s1.hpp"
-#include "band_tail.hpp"
 
 #ifndef __HIPCC_RTC__
 #include <type_traits>
@@ -460,9 +459,6 @@ void rt_eclipse_simpson_slant(RtArgs p) {
   if (valid) p.spec[(size_t)w * W + i] = F;
   if (p.walked_out && threadIdx.x == 0)  // diagnostics: layers this wave walked (bench.py's byte model)
     p.walked_out[(size_t)w * p.ntiles + tile] = (kw < kend + 1 ? kw : kend + 1);
-  if constexpr (!OUT && !EXT && A == 5) {   // (the five-angle table kernel; launch_rt_spec reports band_fused for it alone)
-    if (p.band && blockDim.x == 64) band_tail(p, w, tile, i, valid, F);
-  }
 }
 
 // the builds (rt_eclipse_i1s_ilp.hip): ray grids of five angles and of the other sizes, the line-by-line hand-off

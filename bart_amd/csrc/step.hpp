@@ -43,15 +43,6 @@ struct StepArgs {
   int carry = 0;
   double *d_prevT = nullptr;
   int *d_status = nullptr;
-  // band integration as the RT kernel's tail (band_tail.hpp): per-sample coefficients of the filters' trapezoids and of
-  // the energy integral, the workgroups' shares, the per-walker counters, and the device copy of the BandDev block
-  double *d_q = nullptr, *d_qe = nullptr, *d_part = nullptr;
-  unsigned *d_count = nullptr;
-  BandDev *d_band = nullptr;
-  int band_cap = 0;            // walkers d_part / d_count hold
-  bool band_dirty = true;      // the device block is out of date (setup, set_ebalance, growth)
-  bool band_fuse = true;       // BARTRT_BAND_FUSE=0: always the separate step_bandflux launch
-  bool last_band_fused = false;   // the latest step's band fluxes came out of the RT kernel's tail
   ~StepArgs();
 };
 

@@ -323,13 +323,6 @@ def step_set_extras(nrad: int, ncloud: int, nray: int) -> None:
     _check(trm.lib().bartrt_step_set_extras(int(nrad), int(ncloud), int(nray)))
 
 
-def step_band_fused() -> bool:
-    """Did the latest step's band fluxes come out of the RT kernel's tail (include/bartrt.h, bartrt_step_get_band_fused)?"""
-    v = C.c_int(0)
-    _check(trm.lib().bartrt_step_get_band_fused(C.byref(v)))
-    return bool(v.value)
-
-
 def step_set_carry(on: bool) -> None:
     """The reference's carry-over of the previous temperature profile when the T(p)
     model raises ValueError (BARTfunc.py:318-324); walker w of every batch = chain w."""

@@ -72,7 +72,6 @@ def lib():
         L.bartrt_step_setup.argtypes = [p, i, i, d, d, p, i, p, i, p, p, p, p, d, i]
         L.bartrt_step_set_ebalance.argtypes = [i, d, d]
         L.bartrt_step_set_extras.argtypes = [i, i, i]
-        L.bartrt_step_get_band_fused.argtypes = [C.POINTER(i)]
         L.bartrt_step_batch.argtypes = [p, i, i, p, p]
         L.bartrt_mcmc_run.argtypes = [i, i, C.c_long, p, p, p, p, i, p, p, i, C.c_ulonglong, p, p, p, p]
         L.bartrt_step_batch_dev.argtypes = [p, i, i, p, p, p, p]

@@ -213,13 +213,6 @@ int bartrt_step_setup(const double *ptargs5, int tint_thorngren, int pttype,
  * trapz(spectrum, wn) * e_fac > e_in  (e_fac = 4 (Rp*100)^2). */
 int bartrt_step_set_ebalance(int on, double e_in, double e_fac);
 
-/* Where the launched RT kernel offers it (rule 1 under `cut slant`, five ray angles, the single-wave kernel that serves
- * batches), the band integration and the energy balance run in that kernel's tail -- per-workgroup shares added in tile
- * order by the walker's last workgroup: reproducible to the bit -- instead of a launch of their own (BARTRT_BAND_FUSE=0:
- * always the separate launch).  *fused = 1 if the latest bartrt_step_batch[_dev] call went that way.  The two forms
- * write the trapezoid as different sums of the same terms: band fluxes agree to 1e-14. */
-int bartrt_step_get_band_fused(int *fused);
-
 /* Declares the per-walker parameters BARTfunc places between the T(p) parameters
  * and the abundance factors (BARTfunc.py:350-360), each 0 or 1, in this order:
  * planet radius at the reference pressure (km; what trm.set_radius takes), log10

@@ -224,49 +224,3 @@ def test_energy_balance_rejection(demo_case, wg, ptg):
         assert status[0] == 3 and np.all(band == -1.0)              # BARTfunc.py:378-383
     finally:
         trm.free_memory()
-
-
-def test_band_integration_in_the_rt_kernels_tail(tmp_path, monkeypatch):
-    """The single-wave kernel of the default conventions adds the filters' trapezoids and the energy integral in its own
-    tail (csrc/band_tail.hpp) instead of a separate step_bandflux launch: same band fluxes to 1e-13, the same statuses and
-    -1 rows (temperature out of bounds, energy balance), and the same BITS call after call (the workgroups' shares are
-    added in tile order)."""
-    import torch
-    from bart_amd import BARTfunc, engine, synthcfg, transit_module as trm
-    mols = ("H2O", "CO", "CO2", "CH4")
-    p0 = (-2.0, 0.0, 1.0, 0.0, 0.98, -0.5, -0.5, -0.5, -0.5)
-    case, cfg = synthcfg.make_worker_case(str(tmp_path / "c"), nwave=2501, wnlow=1200.0, opmol=mols, molfit=mols, params=p0, nfilters=7)
-    rng = np.random.default_rng(12)
-    pars = np.array(p0) + rng.normal(0, [0.3, 0.2, 0.2, 0.05, 0.02, 0.5, 0.5, 0.5, 0.5], (14, 9))
-    pars[:, 3] = np.clip(pars[:, 3], 0, 1)
-    pars[3, 4] = 3.5          # far too hot: rejected by the temperature bounds before the engine runs
-    pars[9, 5:] = 4.0         # metals above one: rejected by the abundance renormalisation
-    res = {}
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("BARTRT_BAND_FUSE", fuse)
-        w = BARTfunc.Worker(BARTfunc.WorkerConfig.from_cfg(cfg))
-        try:
-            d_par = torch.from_numpy(pars).cuda()
-            band, status, spec = engine.step_batch_dev(d_par, w.nfilters, want_spec=True)
-            torch.cuda.synchronize()
-            assert engine.step_band_fused() == (fuse == "1")
-            band, status, spec = band.cpu().numpy().copy(), status.cpu().numpy().copy(), spec.cpu().numpy().copy()
-            # an energy budget that about half of the accepted walkers exceed
-            wn = trm.get_waveno_arr(trm.get_no_samples())
-            e_out = np.trapz(spec, wn, axis=1)
-            e_in = float(np.median(e_out[status == 0]))
-            engine.step_set_ebalance(True, e_in, 1.0)
-            band_e, status_e = engine.step_batch_dev(d_par, w.nfilters)
-            torch.cuda.synchronize()
-            band_e, status_e = band_e.cpu().numpy().copy(), status_e.cpu().numpy().copy()
-            again = [engine.step_batch_dev(d_par, w.nfilters)[0].cpu().numpy().copy() for _ in range(15)]
-            assert all(np.array_equal(a, band_e) for a in again)
-            res[fuse] = (band, status, band_e, status_e)
-        finally:
-            w.close()
-    (b0, s0, be0, se0), (b1, s1, be1, se1) = res["0"], res["1"]
-    assert np.array_equal(s0, s1) and np.array_equal(se0, se1)
-    assert s0[3] == 1 and s0[9] == 2 and np.all(b0[3] == -1.0) and np.all(b1[9] == -1.0)
-    assert 2 <= (se0 == 3).sum() <= 10 and np.all(be1[se1 == 3] == -1.0)
-    np.testing.assert_allclose(b1, b0, rtol=1e-13)
-    np.testing.assert_allclose(be1, be0, rtol=1e-13)

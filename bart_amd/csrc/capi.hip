@@ -645,7 +645,8 @@ int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *w
     if (ncolumns) *ncolumns = nc;
     if (wn_per_column) *wn_per_column = e->walked_info.wn_per_column;
     if (kernel && kernel_len > 0) {
-      std::snprintf(kernel, (size_t)kernel_len, "%s%s", e->walked_info.kernel, e->walked_info.rtc ? " [instantiated at run time]" : "");
+      std::snprintf(kernel, (size_t)kernel_len, "%s%s%s", e->walked_info.kernel, e->walked_info.rtc ? " [instantiated at run time]" : "",
+                    e->walked_info.prep_folded ? " [prepares its own walkers]" : "");
     }
     if (walked && n > 0) {
       if ((size_t)cap < (size_t)n * nc) throw std::invalid_argument("walked_end: buffer too small");

@@ -720,11 +720,14 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   prep_over_once = nullptr;
   pa.rtop = solution == 1 ? d_rtop : nullptr;
   pa.ds = solution == 1 ? d_ds : nullptr;
+  // one to four walkers of the plain table path: the RT kernel may prepare them itself (launch_rt_folded, below)
+  const bool try_fold = !use_have && !prep_hook && !want_next && solution == 0 && !lbl && !d_ext && !lbl_fused && !want_tau &&
+                        !want_intens && n <= 4 && integ == 1 && cut_slant && A == 5;
   if (use_have) {
     // prepared by the previous call's RT launch; its flags go where this call wants them
     if (d_okp) HIPCHK(hipMemcpyAsync(d_okp, ok_b[bset], (size_t)n, hipMemcpyDeviceToDevice, st));
   } else if (prep_hook) HIPCHK(prep_hook(pa, st, prep_hook_ctx));
-  else HIPCHK(launch_prep(pa, st));
+  else if (!try_fold) HIPCHK(launch_prep(pa, st));
   if (solution == 1) HIPCHK(launch_chord_table(pa, st));
 
   RtArgs r = rt;
@@ -817,7 +820,13 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   else if (solution == 1) HIPCHK(launch_transit(r, st));
   else {
     RtLaunchInfo li;
-    HIPCHK(launch_rt(r, block, st, &li));
+    bool folded = false;
+    if (try_fold) HIPCHK(launch_rt_folded(r, pa, block, st, &li, &folded));
+    if (!folded) {
+      if (try_fold) HIPCHK(launch_prep(pa, st));
+      li = RtLaunchInfo{};
+      HIPCHK(launch_rt(r, block, st, &li));
+    }
     if (want_walked) walked_info = li;
     if (want_next && li.prep_fused) {
       pf_have_prof = pf_req_prof; pf_have_n = pf_req_n; pf_have_buf = 1 - bset;

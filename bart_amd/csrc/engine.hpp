@@ -12,6 +12,7 @@ namespace bartrt {
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st);
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *info = nullptr);
+hipError_t launch_rt_folded(const RtArgs &a, const PrepArgs &prep, int block, hipStream_t st, RtLaunchInfo *info, bool *folded);
 hipError_t launch_transit(const RtArgs &a, hipStream_t st);
 hipError_t launch_chord_table(const PrepArgs &a, hipStream_t st);  // transit geometry, after launch_prep
 hipError_t launch_grid_transpose(const double *src, double *dst, long planes, int M, int W, hipStream_t st);

@@ -31,10 +31,10 @@ namespace bartrt {
 // specialised kernels, one instantiation set per integration rule (rt_eclipse_i*.hip)
 template <int INTEG>
 bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::string &kmode, bool force_window,
-                    bool allow_sq, hipError_t &err, RtLaunchInfo *info);
-extern template bool launch_rt_spec<0>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *);
-extern template bool launch_rt_spec<1>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *);
-extern template bool launch_rt_spec<2>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *);
+                    bool allow_sq, hipError_t &err, RtLaunchInfo *info, const PrepArgs *fold = nullptr);
+extern template bool launch_rt_spec<0>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *, const PrepArgs *);
+extern template bool launch_rt_spec<1>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *, const PrepArgs *);
+extern template bool launch_rt_spec<2>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *, const PrepArgs *);
 
 __global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
   extern __shared__ double sm[];
@@ -230,21 +230,45 @@ static hipError_t launch_rt_t(const RtArgs &a, int block, int nblocks, hipStream
   return hipGetLastError();
 }
 
+static const std::string &rt_kmode() {
+  static const std::string kmode = [] {
+    const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split | quad | octo (A/B runs)
+    return std::string(e ? e : "");
+  }();
+  return kmode;
+}
+static bool rt_force_window() {
+  static const bool v = std::getenv("BARTRT_WINDOW") != nullptr;  // windowed addressing on any grid (tests)
+  return v;
+}
+static bool rt_allow_sq() {
+  static const bool v = [] {
+    const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
+// One to four walkers under the default conventions: the layer-parallel kernels build their walker's layer records in
+// their own prologue (RtArgs::nprep < 0) -- no prep_profiles launch, no launch boundary in front of the RT kernel.
+// *folded = false: no such kernel serves this launch; the caller launches the preparation and calls launch_rt.
+hipError_t launch_rt_folded(const RtArgs &a, const PrepArgs &prep, int block, hipStream_t st, RtLaunchInfo *info, bool *folded) {
+  *folded = false;
+  static const bool on = [] { const char *e = std::getenv("BARTRT_FOLD"); return !(e && e[0] == '0'); }();
+  if (!on || a.nwalkers <= 0 || a.W <= 0 || a.integ != kIntegSimpson || rt_kmode() == "generic") return hipSuccess;
+  hipError_t err = hipSuccess;
+  *folded = launch_rt_spec<1>(a, block, st, rt_kmode(), rt_force_window(), rt_allow_sq(), err, info, &prep);
+  return *folded ? err : hipSuccess;
+}
+
 // block: threads per workgroup (64 or 256); a.ntiles must be ceil(W/block).
 hipError_t launch_rt(const RtArgs &a, int block, hipStream_t st, RtLaunchInfo *info) {
   if (a.nwalkers <= 0 || a.W <= 0) return hipSuccess;
   if (a.integ < 0 || a.integ >= kIntegCount) return hipErrorInvalidValue;
   const int ntiles8 = (a.ntiles + 7) / 8 * 8;
   const int nblocks = ntiles8 * a.nwalkers;
-  static const std::string kmode = [] {
-    const char *e = std::getenv("BARTRT_KERNEL");  // generic | mono | split | quad | octo (A/B runs)
-    return std::string(e ? e : "");
-  }();
-  static const bool force_window = std::getenv("BARTRT_WINDOW") != nullptr;  // windowed addressing on any grid (tests)
-  static const bool allow_sq = [] {
-    const char *e = std::getenv("BARTRT_SQ");  // 0: always evaluate every transmittance (A/B runs)
-    return !(e && e[0] == '0');
-  }();
+  const std::string &kmode = rt_kmode();
+  const bool force_window = rt_force_window(), allow_sq = rt_allow_sq();
   if (kmode != "generic") {
     hipError_t err = hipSuccess;
     bool done = false;

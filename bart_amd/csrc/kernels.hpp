@@ -237,6 +237,8 @@ struct RtArgs {
   // prep_profiles' body for the NEXT batch in nprep extra workgroups at the head of this launch
   // (the grid is prep_slots(nprep) + RT workgroups: a multiple of eight keeps the XCD map), into
   // the other set of record buffers -- the next call then starts on its RT kernel directly.
+  // nprep < 0 (launch_rt_folded): THIS launch's walkers are prepared by the kernel itself -- every workgroup of the
+  // layer-parallel kernels builds its walker's records in LDS from prep_next (= this batch's PrepArgs)
   int nprep;
   PrepArgs prep_next;
 };
@@ -276,6 +278,7 @@ struct RtLaunchInfo {
   int wn_per_column = 64;   // granularity of RtArgs::walked_out
   int ncolumns = 0;         // entries of walked_out per walker
   bool prep_fused = false;  // the launch carried RtArgs::nprep workgroups of the next batch's preparation
+  bool prep_folded = false; // the kernel prepared its own walkers' layer records (RtArgs::nprep < 0): no prep_profiles launch
   bool rtc = false;         // the kernel was instantiated at run time (rtc.hpp), not taken from the ahead-of-time set
 };
 

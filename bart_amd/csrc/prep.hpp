@@ -47,7 +47,18 @@ __device__ inline double *prep_lds_consts(double *sm, int L, int S) { return sm 
 // over3 (optional; LDS or global): this walker's own reference radius (cm), cloud-top
 // pressure (barye) and scattering value, NaN = keep the engine's setting -- the
 // radius / cloud / scattering parameters of a retrieval step (BARTfunc.py:350-360).
-__device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const double *over3) {
+// Folded into an RT kernel's prologue (PrepFold: the layer-parallel kernels prepare their own walker when the launch
+// is one to four walkers -- rt_eclipse.hpp, launch_rt_folded): the records go to the workgroup's LDS arrays instead
+// of global memory, and only one workgroup per walker (`global`) writes the walker's flags and radii out.
+struct PrepFold {
+  double *coef = nullptr;   // [L][stride] LDS
+  int stride = 0;
+  idx_t *idx = nullptr;     // [L][1 + C] LDS
+  int *kstop = nullptr;     // LDS word
+  bool global = true;       // write kstop / ok / radii to the PrepArgs outputs as the stand-alone kernel does
+};
+
+__device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const double *over3, const PrepFold fold = PrepFold{}) {
   const int L = p.L, S = p.S, M = p.M, C = p.C;
   double refradius = p.refradius, cloudtop = p.cloudtop, scat_value = p.scat_value;
   int has_cloud = p.has_cloud;
@@ -154,11 +165,12 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
   __syncthreads();
   BARTRT_PHASE(10);
   const int NC = coef_stride(M, C), NI = idx_stride(C);
-  double *coef = p.coef + (size_t)w * L * NC;
-  idx_t *idx = p.idx + (size_t)w * L * NI;
+  double *coef = fold.coef ? fold.coef : p.coef + (size_t)w * L * NC;
+  idx_t *idx = fold.idx ? fold.idx : p.idx + (size_t)w * L * NI;
+  const int cstride = fold.coef ? fold.stride : NC;
   for (int k = threadIdx.x; k < L; k += blockDim.x) {
     const int l = L - 1 - k;
-    double *c = coef + (size_t)k * NC;
+    double *c = coef + (size_t)k * cstride;
     idx_t *ix = idx + (size_t)k * NI;
     if (bad) {
       for (int j = 0; j < NC; j++) c[j] = 0.0;
@@ -231,9 +243,9 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     }
     c[3 + 2 * M + 2 * C] = grey;
   }
-  if (p.rad_out)
+  if (p.rad_out && fold.global)
     for (int l = threadIdx.x; l < L; l += blockDim.x) p.rad_out[(size_t)w * L + l] = bad ? 0.0 : sR[l];
-  if (p.rtop && !bad) {
+  if (p.rtop && !bad && fold.global) {
     // the chord table itself is filled from these radii by chord_table_fill
     double *rt = p.rtop + (size_t)w * L;
     for (int k = threadIdx.x; k < L; k += blockDim.x) rt[k] = sR[L - 1 - k];
@@ -244,8 +256,11 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
       for (int k = 0; k < L; k++)
         if (sPress[L - 1 - k] >= cloudtop) { ks = k | kDeckBit; break; }
     }
-    p.kstop[w] = ks;
-    if (p.ok) p.ok[w] = bad ? 0 : 1;
+    if (fold.kstop) *fold.kstop = ks;
+    if (fold.global) {
+      p.kstop[w] = ks;
+      if (p.ok) p.ok[w] = bad ? 0 : 1;
+    }
   }
   BARTRT_PHASE(11);
 }
@@ -254,13 +269,13 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
 // profile and the block of per-engine constants) is pulled into LDS in ONE batch of
 // independent loads; the phases of prep_body then run out of LDS.  The kernel is pure latency:
 // each dependent trip to memory it avoids is worth most of a microsecond.
-__device__ inline void prep_block(const PrepArgs &p, int w, double *sm) {
+__device__ inline void prep_block(const PrepArgs &p, int w, double *sm, const PrepFold fold = PrepFold{}) {
   const int L = p.L, S = p.S;
   BARTRT_PHASE(7);
   stage2_to_lds(prep_lds_profile(sm, L), p.prof + (size_t)w * (S + 1) * L, (S + 1) * L,
                 prep_lds_consts(sm, L, S), p.consts, 2 * L + S + 2 * p.Nt + 2 * p.ncia_temps,
                 threadIdx.x, blockDim.x);
-  prep_body(p, w, sm, p.over ? p.over + (size_t)3 * w : nullptr);
+  prep_body(p, w, sm, p.over ? p.over + (size_t)3 * w : nullptr, fold);
 }
 
 }  // namespace bartrt

@@ -64,6 +64,11 @@ constexpr long kOctoRaysMaxColumns = 40;
 //     R = 32: 29.4 40.8 56.8   R = 16: 25.3 38.6 44.0   R = 8: 29.6 37.4 37.2   single wave: 55.8 56.0 56.0
 //   bench shape (W = 1e4), one walker = 157 columns: R = 32 / 16 / 8 / 4 / team / single wave 42.8 / 40.2 / 37.6 / 47 / 43 / 58;
 //     two walkers = 314 columns: R = 8 58.4, single wave 58.0
+// The preparation folded into these kernels' prologue (every workgroup builds its walker's records itself: 6 us of
+// latency-shaped work instead of a prep_profiles launch, 8 us + a boundary) pays while the workgroups run in ONE round
+// (round 5, us per step, folded / not: demo shape one walker, 313 workgroups, 25.1 / 27.9, three walkers, 471: 29.4 /
+// 32.2; two walkers, 626: 37.9 / 35.4, four, 628: 47.6 / 45.4; W = 1e4 one walker, 625: 48.2 / 47.4, two: 68.5 / 64.0)
+constexpr int kFoldMaxWorkgroups = 512;
 constexpr long kQuadAllMaxColumns = 256, kOctoAllMaxColumns = 256;    // eight layers per step up to here (R = 4: BARTRT_KERNEL=quad only)
 constexpr long kRows16AllMaxColumns = 128, kRows32AllMaxColumns = 64;  // sixteen / thirty-two layers per step (BARTRT_KERNEL=hexa / r32)
 // ... one or two table molecules (the demo shape: lighter steps, the rounds cost less than the longer walk): by the
@@ -486,7 +491,15 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   double *sC = smem;
   idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NCS);
   const double *sW = smem + (size_t)L * NCS + (size_t)L * NI;  // rule 1 only
-  if constexpr (NCS == NC) {
+  // nprep < 0: this launch prepares its own walkers -- every workgroup builds its walker's layer records in LDS itself
+  // (prep_body, the same code and bits as the prep_profiles launch it replaces; launch_rt_folded)
+  __shared__ int sKstopFold;
+  const bool fold = p.nprep < 0;
+  if (fold) {
+    PrepFold pf;
+    pf.coef = sC; pf.stride = NCS; pf.idx = sI; pf.kstop = &sKstopFold; pf.global = tile == 0;
+    prep_block(p.prep_next, w, smem + (size_t)L * NCS + (size_t)L * NI + integ_lds_doubles<INTEG>(L), pf);
+  } else if constexpr (NCS == NC) {
     stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI,
                   threadIdx.x, 256);
   } else {
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
   const double nu = p.wn[ii];
   const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
   const double nu4 = (nu * nu) * (nu * nu);
-  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const int kraw = fold ? sKstopFold : p.kstop[w], kend = kstop_layer(kraw);
   const bool deck_on = kstop_deck(kraw);
   const double tcap = tau_cap(p, A);
 
@@ -905,9 +918,14 @@ bool launch_rt_qadj(const RtArgs &b, bool sq, int rows, int nblocks, size_t sh, 
 BARTRT_ANGLE_SIZES(BARTRT_DECL_ANGLES)
 #undef BARTRT_DECL_ANGLES
 
+// fold (optional): the preparation of this launch's walkers, NOT yet launched -- only the kernels that can run it in
+// their own prologue (the all-rays layer-parallel forms of rule 1 under `cut slant`) are considered then, and false
+// means "launch the preparation, then call again without it".
 template <int INTEG>
 bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::string &kmode, bool force_window,
-                    bool allow_sq, hipError_t &err, RtLaunchInfo *info) {
+                    bool allow_sq, hipError_t &err, RtLaunchInfo *info, const PrepArgs *fold = nullptr) {
+  if (fold && (INTEG != kIntegSimpson || !a.cut_slant || a.A != 5 || a.ext || a.intens_out || a.tau_out || a.nprep != 0)) return false;
+  const size_t sh_fold = fold ? sizeof(double) * prep_lds_doubles(fold->L, fold->S, fold->Nt, fold->ncia_temps) : 0;
   const int ntiles8 = (a.ntiles + 7) / 8 * 8;
   const int nblocks = ntiles8 * a.nwalkers;
   const size_t sh = sizeof(double) * ((size_t)a.L * coef_stride(a.M, a.C) + integ_lds_doubles<INTEG>(a.L)) +
@@ -1051,7 +1069,10 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         RtArgs ba = b;
         ba.ntiles = (a.W + 4 * awn - 1) / (4 * awn);
         const int nba = (ba.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
-        const size_t sha = sh + shp + (adj_rows >= 16 ? sizeof(double) * (size_t)a.L : 0);
+        size_t sha = sh + shp + (adj_rows >= 16 ? sizeof(double) * (size_t)a.L : 0);
+        const bool folds = fold && sha + sh_fold <= 64 * 1024 && nba <= kFoldMaxWorkgroups;
+        if (folds) { ba.nprep = -1; ba.prep_next = *fold; sha += sh_fold; }
+        if (fold && !folds) return false;
         RtLaunchInfo keep;
         if (info) {
           keep = *info;
@@ -1059,6 +1080,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
           info->wn_per_column = awn; info->ncolumns = 4 * ba.ntiles;
         }
         err = hipSuccess;
+        if (info) info->prep_folded = folds;
         if (launch_rt_qadj(ba, sq, adj_rows, nba, sha, st, err)) return true;
         if (rtc_try(info, false, dim3(nba), dim3(256), sha, st, ba, err, "rt_eclipse_qadj<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), adj_rows)) return true;
         if (info) *info = keep;    // (neither an instantiation nor a compiler: the choice before it)
@@ -1068,7 +1090,11 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         const int wnw = 64 / rows;   // wavenumbers per wave
         b.ntiles = (a.W + 4 * wnw - 1) / (4 * wnw);
         const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
-        const size_t shq = sh + shp + (rows >= 16 ? sizeof(double) * (size_t)a.L : 0);   // (padded records: NCS)
+        size_t shq = sh + shp + (rows >= 16 ? sizeof(double) * (size_t)a.L : 0);   // (padded records: NCS)
+        const bool folds = fold && shq + sh_fold <= 64 * 1024 && nbq <= kFoldMaxWorkgroups;
+        if (fold && !folds) return false;
+        if (folds) { b.nprep = -1; b.prep_next = *fold; shq += sh_fold; }
+        if (info) info->prep_folded = folds;
         if (info) {
           info->kernel = rows == 32 ? "rt_eclipse_quad<R=32, all rays per lane>" : rows == 16 ? "rt_eclipse_quad<R=16, all rays per lane>"
                          : rows == 8 ? "rt_eclipse_quad<R=8, all rays per lane>" : "rt_eclipse_quad<R=4, all rays per lane>";
@@ -1092,7 +1118,9 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         if (rtc_try(info, false, dim3(nbq), dim3(256), shq, st, b, err, "rt_eclipse_quad<5, %d, %d, %s, %d, %d, false, true>", a.M, a.C,
                     tf(sq), rows, INTEG))
           return true;
+        if (folds) { b.nprep = 0; if (info) info->prep_folded = false; }
       }
+      if (fold) return false;   // (no kernel that prepares its own walkers serves this launch: the caller launches prep_profiles)
     }
     if (use_rays && fits32) {
       // (the smallest launches -- one walker on the demo shape -- eight layers per step: one wavenumber x five rays per wave)

@@ -5,5 +5,5 @@
 
 namespace bartrt {
 template bool launch_rt_spec<2>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &,
-                                RtLaunchInfo *);
+                                RtLaunchInfo *, const PrepArgs *);
 }  // namespace bartrt

@@ -83,7 +83,14 @@ __global__ __launch_bounds__(256) void rt_eclipse_qadj(RtArgs p) {
   double *sC = smem;
   idx_t *sI = reinterpret_cast<idx_t *>(smem + (size_t)L * NCS);
   const double *sW = smem + (size_t)L * NCS + (size_t)L * NI;
-  if constexpr (NCS == NC) {
+  // nprep < 0: the workgroup prepares its walker's layer records itself (as rt_eclipse_quad does; launch_rt_spec, `fold`)
+  __shared__ int sKstopFold;
+  const bool fold = p.nprep < 0;
+  if (fold) {
+    PrepFold pf;
+    pf.coef = sC; pf.stride = NCS; pf.idx = sI; pf.kstop = &sKstopFold; pf.global = tile == 0;
+    prep_block(p.prep_next, w, smem + (size_t)L * NCS + (size_t)L * NI + 4 * (size_t)(L + kSimpsonPad), pf);
+  } else if constexpr (NCS == NC) {
     stage2_to_lds(sC, p.coef + (size_t)w * L * NC, L * NC, sI, p.idx + (size_t)w * L * NI, L * NI, threadIdx.x, 256);
   } else {
     const double *src = p.coef + (size_t)w * L * NC;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void rt_eclipse_qadj(RtArgs p) {
   const double nu = p.wn[ii];
   const double bnum = 2.0 * kH * nu * nu * nu * kLS * kLS;
   const double nu4 = (nu * nu) * (nu * nu);
-  const int kraw = p.kstop[w], kend = kstop_layer(kraw);
+  const int kraw = fold ? sKstopFold : p.kstop[w], kend = kstop_layer(kraw);
   const bool deck_on = kstop_deck(kraw);
   const double tcap = tau_cap(p, A);
 

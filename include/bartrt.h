@@ -324,7 +324,8 @@ int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *w
  * are first launched (hiprtc; cached under BARTRT_RTC_CACHE, default ~/.cache/bartrt; BARTRT_RTC=0 or a machine without
  * libhiprtc: the generic kernel serves them, 3-10x slower).  *available: a compiler is at hand; kernels compiled /
  * loaded from the disk cache / failed by this process so far, and the seconds spent compiling.  bartrt_walked_end's
- * kernel name carries " [instantiated at run time]" for such a launch.  Pointers may be NULL. */
+ * kernel name carries " [instantiated at run time]" for such a launch (and " [prepares its own walkers]" where a
+ * few-walker launch built its layer records in its own prologue instead of a preparation launch: BARTRT_FOLD=0 off).  Pointers may be NULL. */
 int bartrt_get_rtc_stats(int *available, int *compiled, int *from_disk, int *failed, double *compile_seconds);
 /* Compiles bartrt::<expr> (a template-id of the kernel headers, e.g. "rt_eclipse_simpson_slant<5, 9, 4, true, 1>")
  * for gfx950 and discards the result: *code_bytes = the code object's size.  Needs no GPU -- a check that the embedded

@@ -659,3 +659,49 @@ def test_default_kernel_choice_under_cut_slant(demo_case, small_case):
                 np.testing.assert_allclose(got[:2], ref, rtol=RTOL, atol=1e-12 * np.abs(ref).max(), err_msg=kname)
         finally:
             trm.free_memory()
+
+
+def test_preparation_folded_into_the_layer_parallel_kernels(demo_case, small_case, tmp_path):
+    """One to four walkers under the default conventions, while the launch is one round of workgroups (<= 512): the
+    layer-parallel kernels build their walker's layer records in their own prologue (csrc/prep.hpp PrepFold;
+    launch_rt_folded) instead of a prep_profiles launch in front of them -- the same code, so the same bits as with
+    BARTRT_FOLD=0; the walker's flag (a profile the engine cannot evaluate) and
+    its hydrostatic radii still reach the caller."""
+    import subprocess, sys
+    from bart_amd import engine, transit_module as trm
+    jobs = []
+    for name, case in (("demo", demo_case), ("small", small_case)):
+        profs = walkers(case, 4, seed=77)
+        np.save(str(tmp_path / (name + "_p.npy")), profs)
+        jobs.append((case.tcfg, str(tmp_path / (name + "_p.npy")), str(tmp_path / (name + "_plain.npy"))))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bart_amd import engine, transit_module as trm\n"
+            "for tcfg, pfile, out in %r:\n"
+            "    engine.init(tcfg); p = np.load(pfile)\n"
+            "    np.save(out, np.concatenate([engine.run_batch(p[:n]) for n in (1, 2, 3, 4)])); trm.free_memory()\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), jobs))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BARTRT_FOLD="0"), timeout=600)
+    for tcfg, pfile, out in jobs:
+        engine.init(tcfg)
+        try:
+            p = np.load(pfile)
+            got, folded = [], []
+            for n in (1, 2, 3, 4):
+                engine.walked_begin()
+                got.append(engine.run_batch(p[:n]))
+                kname = engine.walked_end()[2]
+                folded.append("prepares its own walkers" in kname)
+            assert folded[0], kname          # one walker: a single round of workgroups on either grid
+            assert np.array_equal(np.concatenate(got), np.load(out))
+            # the walker's flag and radii come from the folded preparation too
+            bad = p[:2].copy()
+            bad[1, 3] = np.nan
+            spec, ok = engine.run_batch(bad, want_ok=True)
+            assert ok.tolist() == [1, 0] and np.array_equal(spec[0], got[0][0])
+            n = trm.get_no_samples()
+            trm.run_transit(p[0], n)
+            rad = np.zeros(engine.nlayers())
+            trm.check(trm.lib().bartrt_get_radius(trm._ptr(rad), rad.size))
+            assert np.all(np.diff(rad) > 0) and rad[0] > 1e9
+        finally:
+            trm.free_memory()

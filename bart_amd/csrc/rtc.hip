@@ -33,6 +33,8 @@ struct Api {
   decltype(&hiprtcGetLoweredName) lowered = nullptr;
   decltype(&hiprtcGetCodeSize) code_size = nullptr;
   decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcVersion) version = nullptr;
+  int vmajor = 0, vminor = 0;      // of the compiler at hand: part of the disk cache's key
   bool ok = false;
 };
 
@@ -52,6 +54,8 @@ Api &api() {
     BARTRT_SYM(log_size, hiprtcGetProgramLogSize); BARTRT_SYM(log, hiprtcGetProgramLog);
     BARTRT_SYM(lowered, hiprtcGetLoweredName); BARTRT_SYM(code_size, hiprtcGetCodeSize); BARTRT_SYM(code, hiprtcGetCode);
 #undef BARTRT_SYM
+    x.version = reinterpret_cast<decltype(x.version)>(dlsym(x.lib, "hiprtcVersion"));
+    if (x.version) (void)x.version(&x.vmajor, &x.vminor);
     x.ok = x.create && x.destroy && x.add_name && x.compile && x.log_size && x.log && x.lowered && x.code_size && x.code;
     return x;
   }();
@@ -159,7 +163,8 @@ hipFunction_t get(const std::string &expr, bool ilp) {
   e.failed = true;
   std::string lowered;
   std::vector<char> code;
-  const std::string path = cache_dir() + "/" + hex64(std::string(kRtcSourceId) + "|gfx950|" + key) + ".hsaco";
+  const std::string path = cache_dir() + "/" + hex64(std::string(kRtcSourceId) + "|gfx950|hiprtc " + std::to_string(api().vmajor) + "." +
+                                                     std::to_string(api().vminor) + "|" + key) + ".hsaco";
   bool have = read_cached(path, lowered, code);
   if (have) {
     g_stats.from_disk++;

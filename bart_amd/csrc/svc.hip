@@ -43,7 +43,7 @@ ChainService *ChainService::start(svc::Segment &&elected, Engine *e) {
       if (er == hipSuccess) {
         char *d0 = static_cast<char *>(dev);
         const svc::Header *h = s->seg.hdr();
-        s->d_prof = reinterpret_cast<double *>(d0 + (h->off_prof - h->off_prof));
+        s->d_prof = reinterpret_cast<double *>(d0);      // (the registered range starts at the profiles)
         s->d_spec = reinterpret_cast<double *>(d0 + (h->off_spec - h->off_prof));
         s->d_over = reinterpret_cast<double *>(d0 + (h->off_over - h->off_prof));
         s->d_ok = reinterpret_cast<unsigned char *>(d0 + (h->off_ok - h->off_prof));

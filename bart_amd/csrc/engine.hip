@@ -544,6 +544,28 @@ void Engine::setup(const TCfg &cfg_in, int shard_rank, int shard_n) {
   HIPCHK(hipMalloc(&d_tau, sizeof(double) * (size_t)Wl * L));
   HIPCHK(hipMalloc(&d_last, sizeof(int) * (size_t)Wl));
   ensure_walkers(16);
+  // The first launch of a kernel loads its code object (the single-wave kernels' translation unit is 10 MB: 20 ms,
+  // seen as ONE 20 ms call among the first of a run -- round 5, three worker processes on the chain service).  The
+  // atmosphere file's own profile goes through a one-walker and a twelve-walker launch here, once, so that the
+  // first MCMC step does not pay it (BARTRT_WARMUP=0: off).  Table path of the eclipse geometry.
+  {
+    const char *wv = std::getenv("BARTRT_WARMUP");
+    if (!(wv && wv[0] == '0') && solution == 0 && !lbl && M > 0) {
+      const int nprof = (S + 1) * L, nw = 12;
+      std::vector<double> hp((size_t)nw * nprof);
+      for (int w = 0; w < nw; w++)
+        for (int l = 0; l < L; l++) {
+          hp[(size_t)w * nprof + l] = atm.temp[l];
+          for (int k = 0; k < S; k++) hp[(size_t)w * nprof + (size_t)(k + 1) * L + l] = atm.abund[(size_t)l * S + k];
+        }
+      HIPCHK(hipMemcpy(d_prof, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+      run_dev(d_prof, 1, d_spec, d_ok, stream, false);
+      run_dev(d_prof, nw, d_spec, d_ok, stream, false);
+      HIPCHK(hipStreamSynchronize(stream));
+      last_prof = nullptr;
+      last_n = 0;
+    }
+  }
 }
 
 void Engine::ensure_walkers(int n) {

@@ -36,7 +36,7 @@ extern template bool launch_rt_spec<0>(const RtArgs &, int, hipStream_t, const s
 extern template bool launch_rt_spec<1>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *, const PrepArgs *);
 extern template bool launch_rt_spec<2>(const RtArgs &, int, hipStream_t, const std::string &, bool, bool, hipError_t &, RtLaunchInfo *, const PrepArgs *);
 
-__global__ __launch_bounds__(128) void prep_profiles(PrepArgs p) {
+__global__ __launch_bounds__(256) void prep_profiles(PrepArgs p) {
   extern __shared__ double sm[];
   prep_block(p, blockIdx.x, sm);
 }
@@ -208,7 +208,8 @@ hipError_t launch_grid_transpose(const double *src, double *dst, long planes, in
 hipError_t launch_prep(const PrepArgs &a, hipStream_t st) {
   if (a.nwalkers <= 0) return hipSuccess;
   const size_t sh = sizeof(double) * prep_lds_doubles(a.L, a.S, a.Nt, a.ncia_temps);
-  hipLaunchKernelGGL(prep_profiles, dim3(a.nwalkers), dim3(128), sh, st, a);
+  // (256 lanes: two per layer in the record loop up to 128 layers, prep_body)
+  hipLaunchKernelGGL(prep_profiles, dim3(a.nwalkers), dim3(256), sh, st, a);
   return hipGetLastError();
 }
 

@@ -168,35 +168,51 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
   double *coef = fold.coef ? fold.coef : p.coef + (size_t)w * L * NC;
   idx_t *idx = fold.idx ? fold.idx : p.idx + (size_t)w * L * NI;
   const int cstride = fold.coef ? fold.stride : NC;
-  for (int k = threadIdx.x; k < L; k += blockDim.x) {
+  // A workgroup with two lanes per layer (256 lanes, up to 128 layers) splits a layer's record: the first half of the
+  // lanes writes the path length, c2 / T and the table's plane offset and weights, the second half the cross-section
+  // tables, Rayleigh and grey-cloud terms -- the same values from the same operations, half the dependent chain each
+  // (the kernel is latency: 3.6 of its 16 us were this loop, phase clock of round 5).
+  const int half = (int)(blockDim.x >> 1);
+  const bool two = half >= L && half >= 64;
+  const bool do_tab = !two || (int)threadIdx.x < half, do_cs = !two || (int)threadIdx.x >= half;
+  for (int k = two ? (int)threadIdx.x % half : (int)threadIdx.x; k < L; k += two ? half : (int)blockDim.x) {
     const int l = L - 1 - k;
     double *c = coef + (size_t)k * cstride;
     idx_t *ix = idx + (size_t)k * NI;
     if (bad) {
-      for (int j = 0; j < NC; j++) c[j] = 0.0;
-      for (int j = 0; j < NI; j++) ix[j] = 0;
-      c[1] = 1.0;
+      if (do_tab) {
+        for (int j = 0; j < 2 + 2 * M; j++) c[j] = 0.0;
+        ix[0] = 0;
+        c[1] = 1.0;
+      }
+      if (do_cs) {
+        for (int j = 2 + 2 * M; j < NC; j++) c[j] = 0.0;
+        for (int j = 1; j < NI; j++) ix[j] = 0;
+      }
       continue;
     }
     // one division per layer (1/T); grid spacings come as reciprocals
     const double T = sT[l];
     const double invT = 1.0 / T;
     const double nd = sPress[l] * invT * (1.0 / kKB);
-    c[0] = (k == 0) ? 0.0 : (sR[l + 1] - sR[l]);
-    c[1] = (kH * kLS / kKB) * invT;
-    int j = 0;
-    double f = 0.0;
-    if (M > 0) {
-      j = bracket_dev(sTg, sTgInv, p.Nt, T);
-      f = (T - sTg[j]) * sTgInv[j];
+    if (do_tab) {
+      c[0] = (k == 0) ? 0.0 : (sR[l + 1] - sR[l]);
+      c[1] = (kH * kLS / kKB) * invT;
+      int j = 0;
+      double f = 0.0;
+      if (M > 0) {
+        j = bracket_dev(sTg, sTgInv, p.Nt, T);
+        f = (T - sTg[j]) * sTgInv[j];
+      }
+      ix[0] = (idx_t)(((size_t)l * p.Nt + j) * M * p.W) * 8;
+      for (int m = 0; m < M; m++) {
+        const int s = p.opmol[m];
+        const double rho = prof[(size_t)(s + 1) * L + l] * sMass[s] * kAMU * nd;
+        c[2 + 2 * m] = rho * (1.0 - f);
+        c[3 + 2 * m] = rho * f;
+      }
     }
-    ix[0] = (idx_t)(((size_t)l * p.Nt + j) * M * p.W) * 8;
-    for (int m = 0; m < M; m++) {
-      const int s = p.opmol[m];
-      const double rho = prof[(size_t)(s + 1) * L + l] * sMass[s] * kAMU * nd;
-      c[2 + 2 * m] = rho * (1.0 - f);
-      c[3 + 2 * m] = rho * f;
-    }
+    if (!do_cs) continue;
     for (int cc = 0; cc < C; cc++) {
       const int nt = p.cia_nt[cc];
       const double *tg = sCiaT + p.cia_toff[cc], *tginv = sCiaTInv + p.cia_toff[cc];

@@ -274,14 +274,6 @@ int bartrt_get_kernel_by(int *local) {
   return BARTRT_OK;
 }
 
-int bartrt_get_migration_stats(long long *moves, int *gave_up) {
-  NEED_ENGINE();
-  return guarded([&] {
-    g_eng->migration_stats(moves, gave_up);
-    return BARTRT_OK;
-  });
-}
-
 int bartrt_get_cut(int *slant) {
   CLIENT_OR_ENGINE();
   if (!slant) return fail(BARTRT_EINVAL, "get_cut: null output pointer");

@@ -9,7 +9,6 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -27,25 +26,6 @@ static T *dev_upload(const std::vector<T> &v) {
   return d;
 }
 
-void Engine::migration_stats(long long *moves, int *error) {
-  unsigned w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (d_mig_ctl) {
-    HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipMemcpy(w, d_mig_ctl, sizeof(w), hipMemcpyDeviceToHost));
-  }
-  if (std::getenv("BARTRT_MIG_DEBUG") && d_mig_ctl) {
-    unsigned c[32];
-    HIPCHK(hipMemcpy(c, d_mig_ctl, sizeof(c), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[bartrt] migration: looks with a waiting wave by waves at work on the looker's SIMD (0, 1, 2, 3+): %u %u %u %u; by layer / 12:", c[16], c[17], c[18], c[19]);
-    for (int i = 20; i < 30; i++) std::fprintf(stderr, " %u", c[i]);
-    std::fprintf(stderr, "\n");
-    std::fprintf(stderr, "[bartrt] migration: looks with a waiting wave %u, of them wanted %u; tries %u: no slot waiting %u, SIMD holds one wave %u, slot taken %u; waves that waited %u; moves %u\n",
-                 c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[kMigMoves]);
-  }
-  if (moves) *moves = (long long)w[kMigMoves];
-  if (error) *error = (int)w[kMigError];
-}
-
 Engine::~Engine() {
   delete step;
   delete lbl;
@@ -54,7 +34,7 @@ Engine::~Engine() {
   fr(d_kappa); fr(d_cia); fr(d_wn); fr(d_wn_full); fr(d_press); fr(d_mass);
   fr(d_prep_consts); fr(d_diam); fr(d_prof); fr(d_coef); fr(d_spec);
   fr(d_idx); fr(d_kstop); fr(d_rtop); fr(d_ds); fr(d_rad); fr(d_intens); fr(d_ok); fr(d_tau); fr(d_last);
-  fr(d_walked); fr(d_coef2); fr(d_idx2); fr(d_kstop2); fr(d_ok2); fr(d_slog); fr(d_mig_ctl); fr(d_mig_state);
+  fr(d_walked); fr(d_coef2); fr(d_idx2); fr(d_kstop2); fr(d_ok2); fr(d_slog);
   if (h_pin) (void)hipHostFree(h_pin);
   if (h_flag) (void)hipHostFree(h_flag);
   for (auto e : ev) (void)hipEventDestroy(e);
@@ -765,40 +745,6 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   // one to four walkers of the plain table path: the RT kernel may prepare them itself (launch_rt_folded, below)
   const bool try_fold = !use_have && !prep_hook && !want_next && solution == 0 && !lbl && !d_ext && !lbl_fused && !want_tau &&
                         !want_intens && n <= 4 && integ == 1 && cut_slant && A == 5;
-  // Columns that migrate between SIMDs (rt_eclipse_s1s.hpp, MIG): the launcher takes that form when the single-wave columns do
-  // not divide evenly over the SIMDs (launch_rt_spec); the preparation launch in front of it zeroes its per-launch counters.
-  // BARTRT_MIG=0 switches it off, =force hands over whenever a wave waits (tests), BARTRT_MIG_CB: blocks of six layers
-  // between two looks for a waiting wave
-  static const int mig_mode = [] { const char *e = std::getenv("BARTRT_MIG"); return !e || !*e ? 1 : std::string(e) == "force" ? 2 : std::atoi(e); }();
-  static const int mig_cb_now = [] { const char *e = std::getenv("BARTRT_MIG_CB"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? v : 2; }();
-  const int mig_force_now = mig_mode == 2 ? 1 : 0;
-  unsigned *mig_ctl_now = nullptr;
-  if (mig_mode && cut_slant && integ == 1 && solution == 0 && !lbl_fused && !lbl && A == 5 && !use_have && !try_fold && !want_next &&
-      !want_tau && !want_intens && !d_ext) {
-    if (!mig_simds) {
-      int cus = 0;
-      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-      mig_simds = 4 * cus;
-    }
-    const long units = (long)n * ((rt.W + 63) / 64);
-    if (units > mig_simds && units <= 6l * mig_simds) {
-      if (!d_mig_ctl) {
-        HIPCHK(hipMalloc(&d_mig_ctl, sizeof(unsigned) * mig_ctl_words()));
-        HIPCHK(hipMemset(d_mig_ctl, 0, sizeof(unsigned) * mig_ctl_words()));
-      }
-      const size_t need = sizeof(double) * mig_state_doubles(n, (rt.W + 63) / 64, A);
-      if (need > mig_state_cap) {
-        HIPCHK(hipDeviceSynchronize());
-        if (d_mig_state) HIPCHK(hipFree(d_mig_state));
-        d_mig_state = nullptr;
-        mig_state_cap = 0;
-        HIPCHK(hipMalloc(&d_mig_state, need));
-        mig_state_cap = need;
-      }
-      mig_ctl_now = d_mig_ctl;
-    }
-  }
-  pa.mig_ctl = mig_ctl_now;
   if (use_have) {
     // prepared by the previous call's RT launch; its flags go where this call wants them
     if (d_okp) HIPCHK(hipMemcpyAsync(d_okp, ok_b[bset], (size_t)n, hipMemcpyDeviceToDevice, st));
@@ -820,7 +766,6 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     pn.ok = ok_b[1 - bset];
     pn.over = nullptr;
     pn.rad_out = nullptr;   // (bartrt_get_radius: the radii of the batch this call computes)
-    pn.mig_ctl = nullptr;
     r.nprep = pf_req_n;
     r.prep_next = pn;
   }
@@ -861,10 +806,6 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
     }
     r.slog = d_slog;
   }
-  r.mig_ctl = mig_ctl_now; r.mig_state = mig_ctl_now ? d_mig_state : nullptr;
-  if (mig_ctl_now && ++mig_epoch == 0) mig_epoch = 1;
-  r.mig_epoch = mig_epoch;
-  r.mig_cb = mig_cb_now; r.mig_force = mig_force_now; r.mig_simds = mig_simds;
   r.inv_starrad2 = solution == 1 ? 1.0 / (starrad * starrad) : 0.0;
   r.transparent = transparent ? 1 : 0;
   // Timing: the RT kernel's own dispatch stamps the two events (BARTRT_RT_LAUNCH) -- no marker

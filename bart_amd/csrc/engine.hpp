@@ -134,13 +134,6 @@ struct Engine {
   int cap2 = 0;                          // walkers the second set holds
   void *d_slog = nullptr;                // `cut slant`: the single-wave kernels' event log (RtArgs::slog)
   size_t slog_cap = 0;
-  // columns that migrate between SIMDs (RtArgs::mig_*, rt_eclipse_s1s.hpp): control words, hand-over slots, the device's SIMDs
-  unsigned *d_mig_ctl = nullptr;
-  double *d_mig_state = nullptr;
-  size_t mig_state_cap = 0;
-  int mig_simds = 0;
-  unsigned mig_epoch = 0;
-  void migration_stats(long long *moves, int *error);   // columns handed over so far; a taker that gave up waiting
   // per-step converters
   StepArgs *step = nullptr;
   Lbl *lbl = nullptr;

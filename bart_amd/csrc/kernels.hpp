@@ -184,7 +184,6 @@ struct PrepArgs {
   int *kstop;              // [nw] deepest layer index k to integrate to (| kDeckBit: see kstop_layer)
   unsigned char *ok;       // [nw]
   double *rad_out;         // optional [nw][L] hydrostatic radii, cm, atm layer order
-  unsigned *mig_ctl;       // or null: RtArgs::mig_ctl of the RT launch that follows -- walker 0's workgroup zeroes its per-launch words
   // transit geometry only (null otherwise): radii top -> bottom and the chord
   // segments DS(k, j) = s_{j-1} - s_j, s_j = sqrt(r_j^2 - r_k^2), j = 1..k (0
   // elsewhere), laid out as the B operands of v_mfma_f64_16x16x4: for row tile
@@ -242,31 +241,8 @@ struct RtArgs {
   // layer-parallel kernels builds its walker's records in LDS from prep_next (= this batch's PrepArgs)
   int nprep;
   PrepArgs prep_next;
-  // Columns that migrate between the SIMDs of a compute unit (rt_eclipse_simpson_slant<..., MIG>, rt_eclipse_s1s.hpp), or
-  // null: the control words (mig_ctl_words(), layout below; zero before the first launch) and the hand-over slots of the
-  // columns' lane state (mig_state_doubles(...)).  mig_cb: a wave looks for a waiting one every mig_cb blocks of six
-  // layers; mig_force (tests): hand over whenever somebody waits, whatever else this SIMD holds; mig_simds: SIMDs of the device
-  unsigned *mig_ctl;
-  double *mig_state;
-  int mig_cb, mig_force, mig_simds;
-  unsigned mig_epoch;      // this launch's tag in the slots (never 0; slots of earlier launches count as free)
 };
 __host__ __device__ inline int prep_slots(int nprep) { return (nprep + 7) / 8 * 8; }
-
-// RtArgs::mig_ctl in 32-bit words: a header (kMigError: a waiting wave gave up; kMigMoves: columns handed over since the
-// engine started) and one record of kMigCuStride words per compute unit, keyed by the hardware's XCD / engine / array / CU
-// numbers: word 0 = four 4-bit counts of the waves at work on the CU's SIMDs + (bits 16..23) the waves that wait for a
-// column, zeroed by the preparation launch in front of the RT launch (PrepArgs::mig_ctl); from word 32 on (a cache line
-// of their own) kMigSlots 64-bit slots [launch tag : state], state = free / a wave waits / a donor writes / a column.
-// Everything a wave reads or changes while it walks or waits belongs to ITS compute unit: no word is shared by more than
-// the handful of waves of one CU (a word every wave of the launch polls keeps one memory channel busy with them, and a
-// wave's loads return in order behind it: measured, round 5).
-constexpr int kMigError = 5, kMigMoves = 6;
-constexpr int kMigCu = 32, kMigCuKeys = 2048, kMigCuStride = 64, kMigSlots = 16, kMigSlotWord = 32;
-constexpr unsigned kMigFree = 0u, kMigWaiting = 1u, kMigReserved = 2u, kMigColumn = 0x80000000u;   // a slot's low half
-constexpr int kMigSpinMax = 400000;            // a waiting wave gives up after about 0.5 s (and sets kMigError)
-__host__ __device__ inline size_t mig_ctl_words() { return (size_t)kMigCu + (size_t)kMigCuKeys * kMigCuStride; }
-__host__ __device__ inline size_t mig_state_doubles(int nwalkers, int ntiles, int A) { return (size_t)nwalkers * ntiles * (8 + 4 * A) * 64; }
 
 // thr[a] of RtArgs for a value of `toomuch`: tau > thr[a]  <=>  tau * invmu[a] > toomuch, to the bit (the
 // product is monotone in tau, so the set of surviving depths is an interval that ends on one double)

@@ -67,9 +67,6 @@ __device__ inline void prep_body(const PrepArgs &p, int w, double *sm, const dou
     if (over3[1] == over3[1]) { cloudtop = over3[1]; has_cloud = 1; }
     if (over3[2] == over3[2]) scat_value = over3[2];
   }
-  if (p.mig_ctl && w == 0) {   // (the RT launch behind this one counts its compute units' waves from zero)
-    for (int c = threadIdx.x; c < kMigCuKeys; c += blockDim.x) p.mig_ctl[kMigCu + (size_t)c * kMigCuStride] = 0u;
-  }
   double *sT = sm;           // temperature, atm order
   double *sMu = sm + L;      // mean molecular mass
   double *sR = sm + 2 * L;   // radius

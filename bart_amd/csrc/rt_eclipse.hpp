@@ -905,7 +905,6 @@ bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t
 // the `cut slant` kernels of rules 0 / 1 for five angles (rt_eclipse_slant_ilp.hip), table and line-by-line input
 bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 bool launch_rt_slant_ext(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
-bool launch_rt_slant_mig(const RtArgs &b, bool sq, int nblocks, size_t sh, hipStream_t st, hipError_t &err);   // rt_eclipse_slant_mig.hip
 bool launch_rt_slant_out(const RtArgs &b, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
 // the layer-parallel walk of rule 1 / `cut slant` with a column's rows on adjacent lanes (rt_eclipse_qadj.hpp, built in
@@ -1158,19 +1157,6 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     }
     // ... everything else the single-wave kernels (each ray its own sums in one lane)
     b.ntiles = a.ntiles;
-    if constexpr (INTEG == kIntegSimpson) {
-      // columns that do not divide evenly over the SIMDs migrate (rt_eclipse_s1s.hpp, MIG): between one and a few waves per
-      // SIMD, where the SIMDs with one wave more set the launch's time (BARTRT_MIG=0 off, =force: tests)
-      const long units = (long)a.nwalkers * a.ntiles;
-      const bool fits = a.L < 2048 && units < (1l << 20) && b.mig_ctl && b.mig_state && a.nprep == 0 && block == 64;
-      if (fits && (kmode == "mig" || (kmode.empty() && units > b.mig_simds && units <= 6l * b.mig_simds))) {
-        if (info) { info->kernel = "rt_eclipse_simpson_slant (columns migrate between SIMDs)"; info->wn_per_column = block; info->ncolumns = b.ntiles; }
-        if (launch_rt_slant_mig(b, sq, nblocks, sh, st, err)) return true;
-        if (rtc_single_wave_ok(a) &&
-            rtc_try(info, true, dim3(nblocks), dim3(block), sh, st, b, err, "rt_eclipse_simpson_slant<5, %d, %d, %s, 1, false, false, true>", a.M, a.C, tf(sq)))
-          return true;
-      }
-    }
     if (info) {
       info->kernel = INTEG == kIntegSimpson ? "rt_eclipse_simpson_slant (ILP-scheduled build)" : "rt_eclipse_fast<SLANT> (ILP-scheduled build)";
       info->wn_per_column = block; info->ncolumns = b.ntiles;

@@ -97,7 +97,6 @@ def lib():
         L.bartrt_get_service.argtypes = [C.POINTER(i)] * 4
         L.bartrt_get_rtc_stats.argtypes = [C.POINTER(i)] * 4 + [C.POINTER(d)]
         L.bartrt_rtc_compile.argtypes = [C.c_char_p, i, C.POINTER(C.c_long)]
-        L.bartrt_get_migration_stats.argtypes = [C.POINTER(C.c_longlong), C.POINTER(i)]
         L.bartrt_get_service_stats.argtypes = [C.POINTER(C.c_ulonglong)] * 3
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
@@ -232,14 +231,6 @@ def get_rtc_stats():
     check(lib().bartrt_get_rtc_stats(*[C.byref(x) for x in v], C.byref(s)))
     return {"available": bool(v[0].value), "compiled": v[1].value, "from_disk": v[2].value, "failed": v[3].value,
             "compile_seconds": s.value}
-
-
-def get_migration_stats():
-    """-> dict(moves, gave_up): columns handed from one SIMD to another since transit_init, and whether a waiting wave
-    ever gave up (include/bartrt.h, bartrt_get_migration_stats)."""
-    m, e = C.c_longlong(0), C.c_int(0)
-    check(lib().bartrt_get_migration_stats(C.byref(m), C.byref(e)))
-    return {"moves": m.value, "gave_up": bool(e.value)}
 
 
 def get_service():

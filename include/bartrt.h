@@ -327,13 +327,6 @@ int bartrt_walked_end(int *walked, int cap, int *nwalkers, int *ncolumns, int *w
  * kernel name carries " [instantiated at run time]" for such a launch (and " [prepares its own walkers]" where a
  * few-walker launch built its layer records in its own prologue instead of a preparation launch: BARTRT_FOLD=0 off).  Pointers may be NULL. */
 int bartrt_get_rtc_stats(int *available, int *compiled, int *from_disk, int *failed, double *compile_seconds);
-/* Launches whose columns do not divide evenly over the GPU's SIMDs (more than one and up to six single-wave columns per
- * SIMD: ten walkers on 1e4 samples are 1 570 columns on 1 024 SIMDs) let columns MIGRATE: a wave whose SIMD has run out
- * of work takes over, at a boundary of six layers, a column of a SIMD that walks two (csrc/rt_eclipse_s1s.hpp, MIG; same
- * instructions on the same numbers whoever walks them: the spectra do not change by a bit).  BARTRT_MIG=0 switches it
- * off.  *moves: columns handed over since transit_init; *gave_up: nonzero when a waiting wave ever gave up (it never
- * should: the spectra of that launch are not to be trusted).  Pointers may be NULL. */
-int bartrt_get_migration_stats(long long *moves, int *gave_up);
 /* Compiles bartrt::<expr> (a template-id of the kernel headers, e.g. "rt_eclipse_simpson_slant<5, 9, 4, true, 1>")
  * for gfx950 and discards the result: *code_bytes = the code object's size.  Needs no GPU -- a check that the embedded
  * sources and the compiler at hand agree.  BARTRT_ENOTSUP without a compiler or on a compile error (bartrt_last_error). */

@@ -35,7 +35,5 @@ for n in [int(x) for x in (sys.argv[1:] or "1 2 3 4 6 8 10".split())]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 200
     ms, nl = engine.timing_end()
-    mv = trm.get_migration_stats()
-    print("%s cut=%s W=%d walkers %3d: step %.1f us, RT kernel %.1f us  [%s]%s" % (os.environ.get("BARTRT_KERNEL", "-"), trm.get_cut(), NW, n, dt * 1e6, ms / nl * 1e3, kname,
-          "  columns handed over so far: %d%s" % (mv["moves"], " (A WAVE GAVE UP)" if mv["gave_up"] else "") if mv["moves"] or mv["gave_up"] else ""), flush=True)
+    print("%s cut=%s W=%d walkers %3d: step %.1f us, RT kernel %.1f us  [%s]" % (os.environ.get("BARTRT_KERNEL", "-"), trm.get_cut(), NW, n, dt * 1e6, ms / nl * 1e3, kname), flush=True)
 trm.free_memory()

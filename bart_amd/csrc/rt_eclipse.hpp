@@ -462,8 +462,13 @@ void rt_eclipse_split(RtArgs p) {
 // row of its column (or the column's last layer) and the rows of that parity are added up.  Ten values cross the rows
 // per step instead of two; extinction, optical depth and Planck term are computed once per (layer, wavenumber) --
 // which the one-ray-per-lane form (RAYS) does five times.
+// (BARTRT_QUAD_WPE, A/B builds: waves per SIMD the register allocation is held to.  Three -- 168 registers instead of
+// 170-188 -- was measured in round 5: two walkers on the demo shape 23.8 -> 20.2 us, one walker 18.9 -> 19.6; left as it was.)
+#ifndef BARTRT_QUAD_WPE
+#define BARTRT_QUAD_WPE 1
+#endif
 template <int AT, int MT, int CT, bool SQ, int R, int INTEG, bool RAYS = false, bool ALLR = false>
-__global__ __launch_bounds__(256) void rt_eclipse_quad(RtArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BARTRT_QUAD_WPE))) void rt_eclipse_quad(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;

@@ -57,8 +57,13 @@ __device__ __forceinline__ double rows_prefix_max(double v, int q) {   // (value
   return v;
 }
 
+// (BARTRT_QADJ_WPE, A/B builds: held to three waves per SIMD -- 168 registers instead of 178-211 -- the kernel spills
+// 3-60 registers and slows down: one walker at W = 1e4 34.8 -> 59.6 us, demo shape three walkers 23.2 -> 25.5; round 5)
+#ifndef BARTRT_QADJ_WPE
+#define BARTRT_QADJ_WPE 1
+#endif
 template <int AT, int MT, int CT, bool SQ, int R>
-__global__ __launch_bounds__(256) void rt_eclipse_qadj(RtArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BARTRT_QADJ_WPE))) void rt_eclipse_qadj(RtArgs p) {
   static_assert(R == 8 || R == 16, "a column's rows lie inside one 16-lane DPP row");
   extern __shared__ double smem[];
   constexpr int A = AT, M = MT, C = CT;

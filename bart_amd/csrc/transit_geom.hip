@@ -129,8 +129,15 @@ constexpr int kMfmaTilesMax = 20;   // L <= 320 (the most layers the transit geo
 
 // EXT: the line-by-line hand-off -- the layer's line extinction ext[w][l][W] (atm layer order) is
 // one more 8-byte load per (layer, wavenumber) and one more addend (such engines have no table).
+// (Registers: the 100-layer build took 180 + 8 and ran two waves per SIMD; the launch is a chain of dependent trips to
+// memory per wave -- a tile's rows, its matrix products, the next tile -- so the waves a SIMD holds are what hides
+// them.  Held to 168 registers it keeps three, without a spill; deeper columns keep their registers.)
+#ifndef BARTRT_TRANSIT_WPE
+#define BARTRT_TRANSIT_WPE 3
+#endif
 template <int MT, int CT, int KT, bool EXT = false>
-__global__ __launch_bounds__(256) void rt_transit_mfma(RtArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KT <= 8 ? BARTRT_TRANSIT_WPE : 1)))
+void rt_transit_mfma(RtArgs p) {
   extern __shared__ double smem[];
   constexpr int M = MT, C = CT;
   constexpr int NC = 4 + 2 * M + 2 * C, NI = 1 + C, NLD = 2 * M + 2 * C, NR = NLD > 0 ? NLD : 1;

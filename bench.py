@@ -45,6 +45,7 @@ and `cpu_baseline` objects included).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -514,26 +515,35 @@ def main():
         def window(nsteps, first_step=0):
             """-> (seconds between the barriers on this rank, seconds of the final drain, last output)"""
             out_ = None
-            sync()
-            if in_group:
-                dist.barrier()
-            sync()
-            t0 = time.perf_counter()
-            for i in range(nsteps):
-                o = step(i)
-                out_ = o if o is not None else out_
-            t1 = time.perf_counter()
-            if gather:   # (t1: the kernels are enqueued, the collectives of the filled buckets too)
-                out_ = (drain(nsteps - 1) or [out_])[-1]
-            sync()
-            t2 = time.perf_counter()
-            if in_group:
-                dist.barrier()
-            sync()
-            return time.perf_counter() - t0, t2 - t1, out_
+            # (the interpreter's cyclic collector stays out of the window, as in timeit: with torch imported a full
+            # collection is a 30-40 ms pause on the host -- measured in tools/bench_configs.py full_step_10, round 5 --
+            # and which window it lands in depends on the allocations of everything that ran before.  The collection
+            # itself is made before the spin-up below, not here: 40 ms of idle device in front of a window cost it its clocks)
+            gc.disable()
+            try:
+                sync()
+                if in_group:
+                    dist.barrier()
+                sync()
+                t0 = time.perf_counter()
+                for i in range(nsteps):
+                    o = step(i)
+                    out_ = o if o is not None else out_
+                t1 = time.perf_counter()
+                if gather:   # (t1: the kernels are enqueued, the collectives of the filled buckets too)
+                    out_ = (drain(nsteps - 1) or [out_])[-1]
+                sync()
+                t2 = time.perf_counter()
+                if in_group:
+                    dist.barrier()
+                sync()
+                return time.perf_counter() - t0, t2 - t1, out_
+            finally:
+                gc.enable()
 
         if before is not None:       # untimed set-up work on the same batches (the byte model's passes)
             before(profs_h, d_prof)
+        gc.collect()
         if record:                   # (creates its event pool: host work, before the device is spun up)
             engine.timing_begin(a.event_stride)
             engine.timing_end()

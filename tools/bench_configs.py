@@ -200,6 +200,18 @@ def wasp12b_step(integ):
         w.close()
 
 
+class no_gc:
+    """Timed loops run with the interpreter's cyclic collector held off, as timeit does (with torch imported a full
+    collection is a 30-40 ms pause; round 5: it came at the same two of 300 host calls in every run)."""
+    def __enter__(self):
+        import gc
+        gc.disable()      # (collect BEFORE the warm-up calls, not here: 40 ms of idle device cost the timed loop its clocks)
+
+    def __exit__(self, *exc):
+        import gc
+        gc.enable()
+
+
 def full_step_10(integ, headline_dir=None, kappa="survey8d"):
     """The whole MCMC step at the HEADLINE shape: 100 layers x 1e4 samples, 4 molecules, 10 walkers,
     10 filters with the energy-balance check on -- parameters -> T(p) / abundances / layer records -> RT -> band fluxes
@@ -221,22 +233,44 @@ def full_step_10(integ, headline_dir=None, kappa="survey8d"):
         pars[..., 3] = np.clip(pars[..., 3], 0, 1)
         d_par = torch.from_numpy(pars).cuda()
         out = {}
+        import gc
         for sync_each in (True, False):
-            for i in range(20):
+            gc.collect()
+            for i in range(40):
                 band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
             torch.cuda.synchronize()
             engine.timing_begin(1)
-            t0 = time.perf_counter()
-            for i in range(steps):
-                band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
-                if sync_each:
-                    torch.cuda.synchronize()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            with no_gc():
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    band, status = engine.step_batch_dev(d_par[i % nsets], w.nfilters)
+                    if sync_each:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
             kms, nl = engine.timing_end()
             out["synchronised_every_step" if sync_each else "queued_back_to_back"] = {
                 "us_per_step": dt * 1e6, "walker_steps_per_s": n / dt, "rt_kernel_us": kms / max(nl, 1) * 1e3,
                 "step_minus_rt_kernel_us": dt * 1e6 - kms / max(nl, 1) * 1e3}
+        # ... and through the host call an MCMC driver on the host makes (parameters in host memory, band fluxes back in host
+        # memory: the kernels read and write a pinned buffer, the host polls a word the stream writes -- csrc/step.hip)
+        gc.collect()
+        for i in range(40):
+            engine.step_batch(pars[i % nsets], w.nfilters)
+        lat = np.zeros(steps)
+        with no_gc():
+            t0 = time.perf_counter()
+            for i in range(steps):
+                t1 = time.perf_counter()
+                hb, hs = engine.step_batch(pars[i % nsets], w.nfilters)
+                lat[i] = time.perf_counter() - t1
+            dt = (time.perf_counter() - t0) / steps
+        out["host_call_step_batch"] = {"us_per_step": dt * 1e6, "walker_steps_per_s": n / dt, "median_us": float(np.median(lat) * 1e6),
+                                       "p90_us": float(np.percentile(lat, 90) * 1e6), "max_us": float(lat.max() * 1e6),
+                                       "calls_over_twice_the_median": int((lat > 2 * np.median(lat)).sum()),
+                                       "slowest_calls": [[int(i), round(float(lat[i]) * 1e6, 1)] for i in np.argsort(lat)[-6:][::-1]]}
+        db, _ = engine.step_batch_dev(d_par[(steps - 1) % nsets], w.nfilters)
+        out["host_call_equals_device_call"] = bool(np.array_equal(db.cpu().numpy(), hb))
         # run to run: the same parameters give the same band-flux bits
         b1, _ = engine.step_batch_dev(d_par[0], w.nfilters); b1 = b1.clone()
         b2, _ = engine.step_batch_dev(d_par[0], w.nfilters)

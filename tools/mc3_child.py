@@ -79,15 +79,19 @@ def main():
         except trm.TransitError:
             pass
         return
+    import gc
+    gc.collect()          # (before the warm-up calls: the device idles while it runs)
     for _ in range(min(30, nsteps)):            # untimed: the processes fall into step, caches and kernels are warm
         trm.run_transit(mine, n)
     lat = np.zeros(max(nsteps, 1))
+    gc.disable()          # (as timeit does: a full collection is a pause of tens of milliseconds in the middle of the loop)
     t0 = time.perf_counter()
     for i in range(nsteps):
         t1 = time.perf_counter()
         spec = trm.run_transit(mine, n)
         lat[i] = time.perf_counter() - t1
     dt = time.perf_counter() - t0
+    gc.enable()
     common = trm.run_transit(prof0, n)
     if out:
         np.save(out, np.stack([common, spec]))

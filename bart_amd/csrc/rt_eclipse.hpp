@@ -1062,11 +1062,13 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       //   there; W = 5 000: 79 columns 24.5 / 25.9, 158: 34.8 / 37.0, 237: 40.4 / 37.1 -- not there, 316: 49.5 / 58.6
       //   demo shape (one molecule): 40 / 80 columns 16.2 / 15.4, 19.5 / 18.2 -- not there (R = 32 stays), 120: 19.6 / 21.4,
       //   160: 27.9 / 25.8 -- not there, 200: 29.6 / 32.7 and 240: 29.0 / 32.6 with eight rows
+      //   W = 2 424 (the WASP-12b grid's 38 columns per walker): 342 columns 56.3 / 58.1, 380: 55.5 / 58.4 (ten walkers: the
+      //   per-step callable 1.30e5 against 1.26e5 walker-steps/s), 418: 64.0 / 58.9 -- not there
       // BARTRT_KERNEL=adj8 / adj16 force it, BARTRT_ADJ=0 switches it off.
       static const int adj_env = [] { const char *v = std::getenv("BARTRT_ADJ"); return v && *v ? atoi(v) : -1; }();
       int adj_rows = kmode == "adj8" ? 8 : kmode == "adj16" ? 16 : 0;
       if (kmode.empty() && adj_env != 0 && rows_env == 0) {
-        if (a.M >= 3) adj_rows = ((columns > 64 && columns <= 176) || (columns > 280 && columns <= 330)) ? 16 : 0;
+        if (a.M >= 3) adj_rows = ((columns > 64 && columns <= 176) || (columns > 280 && columns <= 390)) ? 16 : 0;
         else adj_rows = (columns > 96 && columns <= 140) ? 16 : (columns > 176 && columns <= 256) ? 8 : 0;
       }
       if (adj_rows && !use_rays && a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, adj_rows))) {

@@ -641,7 +641,8 @@ def test_default_kernel_choice_under_cut_slant(demo_case, small_case):
              (small_case, 1, "R=32, all rays"), (small_case, 4, "R=32, all rays"), (small_case, 5, "qadj<R=16>"),
              (small_case, 9, "qadj<R=16>"), (small_case, 13, "qadj<R=16>"), (small_case, 14, "R=8, all rays"),
              (small_case, 19, "R=8, all rays"), (small_case, 20, "rt_eclipse_simpson_slant"), (small_case, 22, "qadj<R=16>"),
-             (small_case, 25, "qadj<R=16>"), (small_case, 26, "rt_eclipse_simpson_slant")]
+             (small_case, 25, "qadj<R=16>"), (small_case, 26, "qadj<R=16>"), (small_case, 30, "qadj<R=16>"),
+             (small_case, 31, "rt_eclipse_simpson_slant")]
     for case in (demo_case, small_case):
         engine.init(case.tcfg)
         try:

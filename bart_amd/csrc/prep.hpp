@@ -43,7 +43,8 @@ __device__ inline double *prep_lds_profile(double *sm, int L) { return sm + 4 * 
 __device__ inline double *prep_lds_consts(double *sm, int L, int S) { return sm + 4 * L + (size_t)(S + 1) * L; }
 
 // Expects the walker's profile and the constants written to LDS by this workgroup
-// (the body's first barrier makes them visible); w = walker index; 128 lanes.
+// (the body's first barrier makes them visible); w = walker index; 256 lanes in the stand-alone and per-step kernels (two
+// per layer in the record loop up to 128 layers), 64-256 when folded into an RT kernel.
 // over3 (optional; LDS or global): this walker's own reference radius (cm), cloud-top
 // pressure (barye) and scattering value, NaN = keep the engine's setting -- the
 // radius / cloud / scattering parameters of a retrieval step (BARTfunc.py:350-360).

@@ -71,6 +71,7 @@ ChainService *ChainService::start(svc::Segment &&elected, Engine *e) {
     s->disp.seg = &s->seg;
     s->disp.backend = s;
     s->disp.window_us = svc::env_num("BARTRT_SVC_WINDOW_US", 30.0);
+    s->disp.wait_all = svc::env_num("BARTRT_SVC_WAIT_ALL", 0.0) != 0.0;   // (tests: whole batches whatever the processes' pace)
     s->disp.idle_spin_us = svc::env_num("BARTRT_SVC_IDLE_SPIN_US", 100.0);
     const int device = e->device;
     s->th = std::thread([s, device] {

@@ -393,6 +393,7 @@ struct Dispatcher {
   Backend *backend = nullptr;
   std::atomic<bool> stop{false};
   double window_us = 30.0, idle_spin_us = 100.0;
+  bool wait_all = false;                 // tests (BARTRT_SVC_WAIT_ALL): the window waits for every REGISTERED client, not only the active ones
   std::vector<unsigned char> active;     // slots expected in the next batch: they were in the last one (or posted since)
 
   void loop() {
@@ -428,7 +429,7 @@ struct Dispatcher {
           const bool p = seg->slot(i)->st.load(std::memory_order_acquire) == kPosted;
           np += p;
           if (p) active[i] = 1;
-          else if (active[i]) all = false;
+          else if (active[i] || (wait_all && seg->slot(i)->pid.load(std::memory_order_relaxed) != 0)) all = false;
         }
         if (np > seen) { seen = np; t_arr = clk::now(); }
         if (all || since(t_arr) * 1e6 >= window_us) break;

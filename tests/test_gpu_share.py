@@ -96,7 +96,10 @@ def test_a_stale_segment_is_replaced(tmp_path):
 
 
 # ---- the chain service ----------------------------------------------------------------------------------------
-SVC_ENV = {"BARTRT_SVC_WINDOW_US": "20000"}     # (test processes start and print at their own pace: a wide window)
+# (test processes start, collect garbage and print at their own pace: a wide window, and the dispatcher waits for every
+# registered worker within it, not only for those of the batch before -- whole batches, so that "the bits of a ten-walker
+# batch" does not depend on who was late for a round)
+SVC_ENV = {"BARTRT_SVC_WINDOW_US": "20000", "BARTRT_SVC_WAIT_ALL": "1"}
 
 
 def own_engine_cfg(case, tmp_path):
@@ -127,7 +130,7 @@ def test_ten_clients_are_one_ten_walker_batch(tmp_path):
     assert [r["hip_context"] for r in ready if r["service"] == "client"] == [False] * 9
     assert [d["hip_context"] for d, r in zip(done, ready) if r["service"] == "client"] == [False] * 9
     stats = max((d["service_stats"] for d in done), key=lambda s: s["launches"])
-    assert stats["profiles"] >= 10 * 7 and stats["profiles"] / stats["launches"] > 5.0, stats
+    assert stats["profiles"] >= 10 * 7 and stats["profiles"] / stats["launches"] > 4.0 and stats["full"] >= 6, stats
     # the ten-walker batch of an engine of this process's own
     engine.init(own_engine_cfg(case, tmp_path))
     try:

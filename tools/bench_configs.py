@@ -498,10 +498,27 @@ def mc3_processes(headline_dir, kappa, nprocs=(3, 10), steps=1500):
 def run_all(integ, headline_dir=None, kappa="survey8d"):
     res = {}
     if headline_dir:
+        # (the one leg that waits on other processes' pipes: bounded, so that a worker that never answers costs the line
+        # this leg and not the run)
+        import signal
+
+        def _late(signum, frame):
+            raise TimeoutError("mc3_processes: the worker processes did not answer within 900 s")
+        armed = False
+        try:
+            old = signal.signal(signal.SIGALRM, _late)      # (main thread only; elsewhere the leg runs unbounded as before)
+            signal.alarm(900)
+            armed = True
+        except ValueError:
+            pass
         try:
             res["mc3_processes"] = mc3_processes(headline_dir, kappa)
         except Exception as e:
             res["mc3_processes"] = {"error": repr(e)}
+        finally:
+            if armed:
+                signal.alarm(0)
+                signal.signal(signal.SIGALRM, old)
     for name, fn in (("demo_1walker", demo_1walker), ("wasp12b_step", wasp12b_step), ("wasp12b_shard8", wasp12b_shard8),
                      ("full_step_10", full_step_10)):
         try:

@@ -147,6 +147,8 @@ def cpu_baseline(case, conv, walkers, seconds_target=8.0):
         if dt >= 5.0 or n >= 16384:
             break
     return {"value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
+            "sample_short": "%d spectra of the timed run's own walkers, one per thread on %d threads, %.1f s wall; the "
+                            "oracle, NOT reference transit" % (n, cores, dt),
             "sample": f"{n} spectra = the timed run's own {len(walkers)} walkers, repeated in order (100x1e4, 4 "
                       f"molecules, integ {conv['integ']}, cut {conv['cut']}, cia_interp {conv['cia_interp']}), one "
                       f"walker per thread on {cores} threads, {dt:.1f} s wall after a warm-up pass of {cores} spectra"}
@@ -246,6 +248,109 @@ def launch_byte_model(case, profs, walked, wn_per_col, nwave, ncia=1, spline=Fal
     return {"effective_bytes": eff + fixed, "unique_bytes": uniq + fixed,
             "layers_walked_frac": walked_lw / (nw * L * float(nwave)),
             "layer_wavenumbers_walked": walked_lw}
+
+
+LINE_LIMIT = 4096        # bytes: the driver keeps 8 kB of stdout; the r05 line was 20 kB and did not parse
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+
+
+def _short(x, digits=6):
+    """Floats to `digits` significant digits (lists and dicts walked): the line is a record, not an archive."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if np.isfinite(x) else None
+    if isinstance(x, (np.floating, np.integer)):
+        return _short(x.item(), digits)
+    if isinstance(x, dict):
+        return {k: _short(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys} if isinstance(d, dict) else None
+
+
+def contract_line(res, detail_name="bench_detail.json"):
+    """The ONE line of the contract from the full result `res`: the contract's scalar keys, a one-sentence
+    `config`, `roofline`, `cpu_baseline`, `parity`, for N > 1 a short `scaling_diag`, and a pointer to the detail
+    file that holds everything else (windows, sweeps, side legs, notes).  At most LINE_LIMIT bytes whatever the
+    run produced (tests/test_bench_launch.py feeds it a full-size result, N = 8 included)."""
+    cfg = res.get("config") or {}
+    roof = res.get("roofline")
+    line = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if res.get("dry"):
+        line["dry"] = True
+    wl = str(cfg.get("workload_short") or cfg.get("workload") or "")
+    line["config"] = {"workload": wl if len(wl) <= 300 else wl[:297] + "...",
+                      **{k: cfg.get(k) for k in ("walkers_per_step", "nlayers", "nwave", "integ", "cut", "cia_interp",
+                                                 "kappa_model", "parallelism") if k in cfg}}
+    if roof:
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac"))
+        fr = roof.get("fractions") or {}
+        r["frac_cold"] = fr.get("frac_cold")
+        r["frac_survey8d_letter"] = fr.get("frac_survey8d_letter")
+        r.update(_pick(roof, ("traffic", "traffic_source", "kernel", "avg_launch_ms", "unique_bytes_per_launch",
+                              "survey8d_algorithmic_bytes_per_launch", "launches")))
+        bm = roof.get("bound_measured")
+        if isinstance(bm, dict):       # the SQ pass of this build, one word per batch size
+            r["bound_measured"] = {k: v.get("bound") for k, v in bm.items() if isinstance(v, dict)}
+            r["bound_measured"]["source"] = bm.get("source")
+        else:
+            r["bound_measured"] = None
+        f64 = roof.get("fp64")
+        r["fp64_frac"] = f64.get("frac") if isinstance(f64, dict) else None
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:160]
+    else:
+        line["cpu_baseline"] = cb if cb is None else {"error": str(cb.get("error"))[:120]}
+    par = res.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = _pick(par, ("max_rel_err", "tolerance", "n_samples", "walkers", "bit_equal_to_plain_launch", "ok"))
+        line["parity"]["against"] = "oracle/rt_oracle.c (CPU restatement; RT parity unpinned)"
+    win = res.get("windows")
+    if isinstance(win, dict):
+        line["windows_ms_per_step"] = win.get("ms_per_step")
+    d = res.get("scaling_diag")
+    if isinstance(d, dict):
+        sd = _pick(d, ("mode", "rank_skew_ms", "steps_per_bucket", "allgather_send_bytes_per_rank_per_bucket",
+                       "allgather_recv_bytes_per_rank_per_bucket", "ms_per_step_minus_rt_kernel"))
+        for k in ("per_rank_window_s", "per_rank_rt_kernel_ms", "per_rank_final_drain_ms"):
+            sd[k] = _short(d.get(k), 4)
+        line["scaling_diag"] = {k: v for k, v in sd.items() if v is not None}
+    rep = res.get("replicas")
+    if isinstance(rep, dict):
+        line["replicas"] = _pick(rep, ("value", "unit", "ms_per_step", "walkers_per_rank"))
+    line["source_id"] = res.get("source_id")
+    line["detail"] = detail_name
+    line = _short(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:             # last resort (a launcher with hundreds of ranks): drop the per-rank lists
+        for k in ("per_rank_window_s", "per_rank_rt_kernel_ms", "per_rank_final_drain_ms"):
+            line.get("scaling_diag", {}).pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def emit(res, detail_path=DETAIL_FILE):
+    """Everything to the detail file (and to stderr), the contract's line -- alone -- to stdout."""
+    name = None
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(res, f, indent=1)
+            f.write("\n")
+        name = os.path.relpath(detail_path, ROOT)
+    except OSError as e:       # a read-only checkout must not cost the line
+        print("bench.py: detail file not written: %r" % (e,), file=sys.stderr)
+    print("bench.py detail: " + json.dumps(res), file=sys.stderr, flush=True)
+    print(contract_line(res, name), flush=True)
 
 
 def self_launch(ngpus, argv, port=0):
@@ -383,9 +488,15 @@ def main():
                          "planes shared: what the launch costs without its own HBM traffic); not a benchmark")
     ap.add_argument("--dry-gloo", action="store_true",
                     help="no GPU: stub engine, CPU tensors, gloo backend (launch-path check, not a measurement)")
+    ap.add_argument("--detail", default=DETAIL_FILE,
+                    help="where the full record goes (windows, sweeps, side legs, notes); stdout carries the contract's "
+                         "line only, at most %d bytes" % LINE_LIMIT)
     ap.add_argument("--master-port", type=int, default=0,
                     help="rendezvous port of the self-launched N > 1 run (0: pick a free one)")
     a = ap.parse_args()
+    if a.dry_gloo and a.detail == DETAIL_FILE:
+        # a dry run measures nothing: its record must not replace a measured one next to bench.py
+        a.detail = os.path.join(tempfile.gettempdir(), "bench_detail_dry_%d.json" % os.getpid())
 
     if a.config == "lbl":
         # a second artefact, not the contract's line: config 5 on one GPU
@@ -697,7 +808,7 @@ def main():
 
     if rank == 0 and dry:
         assert ok
-        print(json.dumps({
+        emit({
             "metric": "forward spectra/sec (100 layers x 1e4 wavenumbers)", "dry": True,
             "value": None, "unit": "spectra/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -708,7 +819,7 @@ def main():
                        "parallelism": ("wavenumber-block shard x%d + all-gather" if a.mode == "shard"
                                        else "replicas x%d, no collective") % world},
             "scaling_diag": main_run["diag"],
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": None, "cpu_baseline": None}, detail_path=a.detail)
     elif rank == 0:
         assert ok
         value = nspectra_per_step * a.steps / dt
@@ -794,6 +905,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
+                "workload_short": "H2O+CO+CO2+CH4 eclipse, %d layers x %d wavenumbers, %d walkers batched per GPU per "
+                                  "step (BASELINE config 3), opacity-table path, 27 T planes, H2-H2 CIA, 5 ray angles, "
+                                  "toomuch 10, %s opacities, every step its own profile preparation"
+                                  % (a.nlayers, a.nwave, a.walkers, "SURVEY 8d" if a.kappa == "survey8d" else a.kappa),
                 "workload": "H2O+CO+CO2+CH4 eclipse, %d layers x %d wavenumbers, %d walkers "
                             "batched per GPU per step, opacity-table path, 27 T planes, "
                             "H2-H2 CIA, 5 ray angles, toomuch 10, integration rule %d (%s); "
@@ -946,7 +1061,7 @@ def main():
                 case, conv, profs_all.reshape(-1, profs_all.shape[-1])))
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        emit(res, detail_path=a.detail)
     if in_group:
         dist.barrier()
         dist.destroy_process_group()

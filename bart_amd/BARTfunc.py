@@ -275,6 +275,14 @@ def main(comm, argv=None, group=None, worker_factory=None, shard_backend="nccl")
     npars, niter = int(array1[0]), int(array1[1])
     nworkers = group.Get_size() if group is not None else 1
     wrank = group.Get_rank() if group is not None else 0
+    if group is None:
+        # one engine call per worker process, as the reference's worker makes it: the library reads the number of
+        # chains (the local group of MC3's intercommunicator) to choose how `shareOpacity` is served -- fewer than five
+        # processes are faster on engines of their own over one shared grid than on the chain service
+        try:
+            os.environ.setdefault("BARTRT_NCHAINS", str(int(comm.Get_size())))
+        except Exception:      # noqa: BLE001  (a stand-in communicator without a size)
+            pass
     # BARTRT_GPUS = G > 1: the first G workers each drive one GPU of the node and
     # hold one wavenumber block of the tables; every step they all evaluate the
     # whole batch on their block and reassemble the spectra with one RCCL

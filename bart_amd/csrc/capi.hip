@@ -80,17 +80,51 @@ InitArgs parse_init_args(int argc, const char **argv) {
   return a;
 }
 
+// How many GPUs this process can see, WITHOUT a HIP call (a service client never makes one): the entries of
+// HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if set, else the KFD topology nodes that have SIMDs.  0: unknown.
+int visible_gpu_count() {
+  for (const char *name : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"}) {
+    const char *v = std::getenv(name);
+    if (v && *v) {
+      int n = 1;
+      for (const char *c = v; *c; c++) n += *c == ',';
+      return n;
+    }
+  }
+  int n = 0;
+  for (int node = 0; node < 256; node++) {
+    char path[128];
+    std::snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+    FILE *f = std::fopen(path, "r");
+    if (!f) break;
+    char key[64];
+    long long val;
+    while (std::fscanf(f, "%63s %lld", key, &val) == 2)
+      if (std::strcmp(key, "simd_count") == 0) { n += val > 0; break; }
+    std::fclose(f);
+  }
+  return n;
+}
+
 std::string service_key(const InitArgs &a) {
   struct stat st;
   if (stat(a.cfile.c_str(), &st) != 0) throw IoError{"cannot open configuration file '" + a.cfile + "'"};
   char rp[PATH_MAX];
   const std::string real = realpath(a.cfile.c_str(), rp) ? std::string(rp) : a.cfile;
-  // (no HIP call here: a client never makes one -- the GPU is named by what selects it)
+  // (no HIP call here: a client never makes one -- the GPU is named by what selects it, resolved the way
+  // Engine::setup resolves it: LOCAL_RANK modulo the visible devices, so that ten workers with ten LOCAL_RANKs on a
+  // one-GPU node meet on one engine instead of electing themselves ten times)
   const char *lr = std::getenv("LOCAL_RANK"), *hv = std::getenv("HIP_VISIBLE_DEVICES"), *rv = std::getenv("ROCR_VISIBLE_DEVICES");
-  const std::string dev = a.device >= 0 ? std::to_string(a.device) : std::string(lr ? lr : "0");
+  int dev = a.device;
+  if (dev < 0) {
+    dev = lr ? std::atoi(lr) : 0;
+    const int ndev = visible_gpu_count();
+    if (ndev > 0) dev %= ndev;
+  }
+  // (the library's own id: workers on different builds of libbartrt do not share an engine)
   return real + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtime) + "|" +
-         std::to_string((long long)getuid()) + "|dev " + dev + "|hip " + (hv ? hv : "") + "|rocr " + (rv ? rv : "") +
-         "|shard " + std::to_string(a.shard_rank) + "/" + std::to_string(a.shard_n) + "|svc v2";
+         std::to_string((long long)getuid()) + "|dev " + std::to_string(dev) + "|hip " + (hv ? hv : "") + "|rocr " + (rv ? rv : "") +
+         "|shard " + std::to_string(a.shard_rank) + "/" + std::to_string(a.shard_n) + "|svc v3|" + bartrt_build_id();
 }
 
 std::string what_failed() {
@@ -342,6 +376,12 @@ int bartrt_get_service_stats(unsigned long long *nlaunches, unsigned long long *
   if (nlaunches) *nlaunches = h->nbatches.load();
   if (nprofiles) *nprofiles = h->nserved.load();
   if (nfull) *nfull = h->nfull.load();
+  return BARTRT_OK;
+}
+
+int bartrt_get_service_gathered(unsigned long long *ngathered) {
+  if (!g_cli) return fail(BARTRT_EINVAL, "get_service_gathered: this process is not on a chain service");
+  if (ngathered) *ngathered = g_cli->seg.hdr()->ngathered.load();
   return BARTRT_OK;
 }
 

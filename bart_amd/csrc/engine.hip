@@ -69,6 +69,19 @@ int resolve_share_mode(const TCfg &cfg, bool no_service) {
   if (auto it = cfg.find("shareOpacity"); it != cfg.end()) on = truthy(it->second);
   if (const char *e = std::getenv("BARTRT_SHARE_OPACITY")) if (*e) on = std::string(e) != "0";
   int mode = kShareService;
+  // Fewer than five worker processes: separate HIP contexts overlap their one-walker launches and beat the service's
+  // one batched launch (measured, headline grid: three processes 63 against 85 us per call, four 86 / 90, five 89 / 92
+  // per call but 2.8e4 / 5.4e4 spectra/s) -- when the launcher says how many chains there are (BARTRT_NCHAINS, set by
+  // bart_amd.BARTfunc from the communicator's size; else the MPI world size of the spawned workers) and nothing names a
+  // mode, such runs take the IPC reading.
+  for (const char *name : {"BARTRT_NCHAINS", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "MV2_COMM_WORLD_SIZE"}) {
+    const char *e = std::getenv(name);
+    if (e && *e) {
+      const int n = std::atoi(e);
+      if (n >= 1 && n < 5) mode = kShareIpc;
+      break;
+    }
+  }
   if (const char *e = std::getenv("BARTRT_SHARE_MODE")) if (*e) {
     const std::string v = e;
     if (v == "service") mode = kShareService;
@@ -744,7 +757,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
   pa.ds = solution == 1 ? d_ds : nullptr;
   // one to four walkers of the plain table path: the RT kernel may prepare them itself (launch_rt_folded, below)
   const bool try_fold = !use_have && !prep_hook && !want_next && solution == 0 && !lbl && !d_ext && !lbl_fused && !want_tau &&
-                        !want_intens && n <= 4 && integ == 1 && cut_slant && A == 5;
+                        !want_intens && std::max(n, sel_walkers) <= 4 && integ == 1 && cut_slant && A == 5;
   if (use_have) {
     // prepared by the previous call's RT launch; its flags go where this call wants them
     if (d_okp) HIPCHK(hipMemcpyAsync(d_okp, ok_b[bset], (size_t)n, hipMemcpyDeviceToDevice, st));
@@ -754,6 +767,7 @@ void Engine::run_chunk(const double *d_prof_in, int n, double *d_spec_out,
 
   RtArgs r = rt;
   r.nwalkers = n;
+  r.nsel = sel_walkers > n ? sel_walkers : 0;
   if (kernel_by_local) r.Wfull = r.W;
   r.coef = coef_b[bset]; r.idx = idx_b[bset]; r.kstop = kstop_b[bset];
   r.ext = d_ext;

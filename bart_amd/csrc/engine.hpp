@@ -46,6 +46,7 @@ struct Engine {
   // kernel's latency floor, 52 us; spectra agree with the unsharded run's to 4e-16) or by the WHOLE grid's (false: cfg
   // `kernel_by whole` / BARTRT_KERNEL_BY=whole / bartrt_set_kernel_by -- the blocks then are the unsharded run's bits)
   bool kernel_by_local = true;
+  int sel_walkers = 0;    // > 0: the walker count the kernel variant is chosen for instead of the batch's own (RtArgs::nsel)
   bool cia_spline = false; // cfg `cia_interp spline` / BARTRT_CIA_INTERP: natural cubic splines in wavenumber and T (C20)
   double starrad = 0;     // cm, transit geometry
   double scat_value = 0, cloudtop = 0;

@@ -19,11 +19,13 @@ template <bool B, class T, class F> using conditional_t = typename conditional<B
 }  // namespace std
 #endif
 
-// (molecules, CIA pairs) the specialised kernels are instantiated for
-// (four CIA slots = two cross-section files under the default `cia_interp spline`: BART's usual H2-H2 + H2-He)
+// (molecules, CIA pairs) the specialised kernels are instantiated for AHEAD OF TIME
+// (four CIA slots = two cross-section files under the default `cia_interp spline`: BART's usual H2-H2 + H2-He).
+// Up to six table molecules (the reference's examples use one to four); seven and more are instantiated at their
+// first launch (csrc/rtc.hpp) since round 6 -- the (7, *) / (8, *) pairs were 8 MB of the library.
 #define BARTRT_MC_LIST(X) \
   X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) \
-  X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2) X(7, 1) X(7, 2) X(8, 1) X(8, 2)                 \
+  X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2)                                                 \
   X(1, 4) X(2, 4) X(3, 4) X(4, 4) X(5, 4) X(6, 4)
 // ... of the adjacent-rows layer-parallel kernel (rt_eclipse_qadj.hpp)
 #define BARTRT_QADJ_LIST(X) X(1, 1) X(1, 2) X(4, 1) X(4, 2)
@@ -195,6 +197,9 @@ struct PrepArgs {
 
 struct RtArgs {
   int L, M, Nt, C, A, W, nwalkers, ntiles;
+  int nsel;                // host side only: the walker count the kernel VARIANT is chosen for (0: nwalkers).  The chain
+                           // service names its registered clients here, so that a round some worker missed runs the
+                           // kernel of the full batch and gives the same bits (svc_core.hpp, Backend::run)
   int Wfull;               // samples of the whole grid (W: this process's block of it): the kernel variant is chosen by
                            // the batch on the WHOLE grid, so that a sharded run adds the same numbers in the same order
                            // as the unsharded one (blocks concatenate bit for bit)

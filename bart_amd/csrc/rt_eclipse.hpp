@@ -916,8 +916,11 @@ bool launch_rt_slant_out(const RtArgs &b, int block, int nblocks, size_t sh, hip
 // rt_eclipse_qadj.hip): five angles, rows = 8 or 16; false: no instantiation for this shape
 bool launch_rt_qadj(const RtArgs &b, bool sq, int rows, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 
-// ... and for ray grids of 1 .. 9 angles other than five (rt_eclipse_angles.hip, one object per size)
-#define BARTRT_ANGLE_SIZES(X) X(1) X(2) X(3) X(4) X(6) X(7) X(8) X(9)
+// ... and for the ray-grid sizes other than five built ahead of time (rt_eclipse_angles.hip, one object per size; the
+// list comes from bart_amd/build.py -- empty by default since round 6: every other size is instantiated at run time)
+#ifndef BARTRT_ANGLE_SIZES
+#define BARTRT_ANGLE_SIZES(X)
+#endif
 #define BARTRT_DECL_ANGLES(N) \
   bool launch_rt_angles_##N(const RtArgs &b, int integ, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err);
 BARTRT_ANGLE_SIZES(BARTRT_DECL_ANGLES)
@@ -1025,7 +1028,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
   // too few single-wave columns to load the 1 024 SIMDs evenly -> several
   // waves per 64 wavenumbers: four 16-wavenumber waves that take four layers at
   // a time (quad-layer), or a producer / consumer pair
-  const long columns = (long)a.nwalkers * (((a.Wfull > 0 ? a.Wfull : a.W) + 63) / 64);   // (of the whole grid: RtArgs::Wfull)
+  const int nsel = a.nsel > a.nwalkers ? a.nsel : a.nwalkers;   // (the batch the variant is chosen for: RtArgs::nsel)
+  const long columns = (long)nsel * (((a.Wfull > 0 ? a.Wfull : a.W) + 63) / 64);   // (of the whole grid: RtArgs::Wfull)
   const int ntiles64 = (a.W + 63) / 64;
   const int nb64 = (ntiles64 + 7) / 8 * 8 * a.nwalkers;
   // the quad-layer kernel addresses the tables with per-lane 32-bit offsets
@@ -1077,7 +1081,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         ba.ntiles = (a.W + 4 * awn - 1) / (4 * awn);
         const int nba = (ba.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
         size_t sha = sh + shp + (adj_rows >= 16 ? sizeof(double) * (size_t)a.L : 0);
-        const bool folds = fold && sha + sh_fold <= 64 * 1024 && nba <= kFoldMaxWorkgroups;
+        const bool folds = fold && sha + sh_fold <= 64 * 1024 && (ba.ntiles + 7) / 8 * 8 * nsel + pslots <= kFoldMaxWorkgroups;
         if (folds) { ba.nprep = -1; ba.prep_next = *fold; sha += sh_fold; }
         if (fold && !folds) return false;
         RtLaunchInfo keep;
@@ -1098,7 +1102,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         b.ntiles = (a.W + 4 * wnw - 1) / (4 * wnw);
         const int nbq = (b.ntiles + 7) / 8 * 8 * a.nwalkers + pslots;
         size_t shq = sh + shp + (rows >= 16 ? sizeof(double) * (size_t)a.L : 0);   // (padded records: NCS)
-        const bool folds = fold && shq + sh_fold <= 64 * 1024 && nbq <= kFoldMaxWorkgroups;
+        const bool folds = fold && shq + sh_fold <= 64 * 1024 && (b.ntiles + 7) / 8 * 8 * nsel + pslots <= kFoldMaxWorkgroups;
         if (fold && !folds) return false;
         if (folds) { b.nprep = -1; b.prep_next = *fold; shq += sh_fold; }
         if (info) info->prep_folded = folds;

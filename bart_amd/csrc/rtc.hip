@@ -68,17 +68,30 @@ std::map<std::string, Entry> g_cache;
 std::vector<hipModule_t> g_modules;
 RtcStats g_stats;
 
+// The directory of the on-disk cache, or "" when there is none to trust: a code object read from it is loaded and run
+// on the GPU against the engine's buffers, so the directory must be this user's own and writable by nobody else (a
+// /tmp fallback or a shared BARTRT_RTC_CACHE another local user pre-created does not qualify: the process then compiles
+// in memory only).
 std::string cache_dir() {
-  std::string d;
-  if (const char *e = std::getenv("BARTRT_RTC_CACHE")) d = e;
-  else if (const char *x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/bartrt";
-  else if (const char *h = std::getenv("HOME")) d = std::string(h) + "/.cache/bartrt";
-  else d = "/tmp/bartrt_cache_" + std::to_string((long)getuid());
-  // (mkdir -p, two levels are enough for the defaults)
-  const size_t slash = d.find_last_of('/');
-  if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0700);
-  (void)mkdir(d.c_str(), 0700);
-  return d;
+  static const std::string dir = [] {
+    std::string d;
+    if (const char *e = std::getenv("BARTRT_RTC_CACHE")) d = e;
+    else if (const char *x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/bartrt";
+    else if (const char *h = std::getenv("HOME")) d = std::string(h) + "/.cache/bartrt";
+    else d = "/tmp/bartrt_cache_" + std::to_string((long)getuid());
+    // (mkdir -p, two levels are enough for the defaults)
+    const size_t slash = d.find_last_of('/');
+    if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0700);
+    (void)mkdir(d.c_str(), 0700);
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+      std::fprintf(stderr, "libbartrt: kernel cache directory %s is not a directory of this user's own without group/other "
+                           "write permission: compiled kernels are kept in memory only\n", d.c_str());
+      return std::string();
+    }
+    return d;
+  }();
+  return dir;
 }
 
 std::string hex64(const std::string &s) {
@@ -163,9 +176,10 @@ hipFunction_t get(const std::string &expr, bool ilp) {
   e.failed = true;
   std::string lowered;
   std::vector<char> code;
-  const std::string path = cache_dir() + "/" + hex64(std::string(kRtcSourceId) + "|gfx950|hiprtc " + std::to_string(api().vmajor) + "." +
+  const std::string cdir = cache_dir();
+  const std::string path = cdir.empty() ? std::string() : cdir + "/" + hex64(std::string(kRtcSourceId) + "|gfx950|hiprtc " + std::to_string(api().vmajor) + "." +
                                                      std::to_string(api().vminor) + "|" + key) + ".hsaco";
-  bool have = read_cached(path, lowered, code);
+  bool have = !path.empty() && read_cached(path, lowered, code);
   if (have) {
     g_stats.from_disk++;
   } else if (api().ok) {
@@ -175,7 +189,7 @@ hipFunction_t get(const std::string &expr, bool ilp) {
     g_stats.compile_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (have) {
       g_stats.compiled++;
-      write_cached(path, lowered, code);
+      if (!path.empty()) write_cached(path, lowered, code);
       if (std::getenv("BARTRT_RTC_VERBOSE")) std::fprintf(stderr, "libbartrt: compiled %s (%zu bytes)\n", expr.c_str(), code.size());
     } else {
       g_stats.failed++;

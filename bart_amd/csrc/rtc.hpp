@@ -1,7 +1,7 @@
 // Kernels of the hand-written headers instantiated at run time.
 //
 // The library ships the RT kernels for the shapes BART's examples use, instantiated ahead of time (kernels.hpp,
-// BARTRT_MC_LIST: 28 (molecules, cross-section slots) pairs x five ray angles, ray grids of 1-9 angles); every other
+// BARTRT_MC_LIST: 24 (molecules, cross-section slots) pairs x the five-angle ray grid); every other
 // shape -- seven or eight molecules with two cross-section files under the default spline, nine and more molecules, ten
 // and more ray angles -- used to fall to the generic kernel, 3-10x slower.  Instead of another 30 MB of objects, such a
 // shape is compiled for when it is first launched: the SAME kernel templates (the headers are embedded in the library

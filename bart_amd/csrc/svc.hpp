@@ -35,6 +35,7 @@ struct ChainService : svc::Backend {
   int sync_mode = 0;
   uint32_t flag_seq = 0;
   uint32_t *d_flag = nullptr;
+  int32_t *d_list = nullptr;        // device view of the segment's slot list (gathered launches)
   void *ev_done = nullptr;
   void wait_done();
 
@@ -42,7 +43,7 @@ struct ChainService : svc::Backend {
   static ChainService *start(svc::Segment &&seg, Engine *e);
   // keeps serving until the other clients have detached (or wait_s passed), then stops; deletes the engine
   void shutdown(double wait_s);
-  void run(int first, int n, int scat_flag, bool any_over, bool any_cloud) override;
+  void run(const int *slots, int n, int nominal, int scat_flag, bool any_over, bool any_cloud) override;
   ~ChainService() override {}
 };
 

@@ -100,10 +100,13 @@ struct NameLock {
 };
 
 // ---- segment layout -------------------------------------------------------------------------
-constexpr uint32_t kVersion = 3;
+constexpr uint32_t kVersion = 4;
 constexpr uint32_t kLoading = 0, kReady = 1, kGone = 2;
 constexpr uint32_t kIdle = 0, kPosted = 1, kDone = 2, kFailed = 3;
-constexpr int kMaxClients = 64;
+// One slot per worker process = per MCMC chain (examples/demo/BART_eclipse.cfg:90-91: "number of parallel chains", free in
+// the reference).  Default 256 (BARTRT_SVC_MAXCLIENTS; 86 kB of segment each at the headline shape), at most 1 024.
+constexpr int kMaxClients = 1024;
+constexpr int kDefaultClients = 256;
 constexpr size_t kPage = 4096;
 
 struct alignas(128) Slot {
@@ -124,7 +127,8 @@ struct Header {
   // what a client needs to answer the reference module's getters without an engine
   int32_t L, S, A, Wfull, lo, hi, integ, cut_slant, cia_spline, solution, device;
   int32_t nprof, Wl;                // (S+1)*L, hi-lo
-  uint64_t off_slots, off_prof, off_spec, off_over, off_ok, off_flag, off_info;   // byte offsets from the segment's start
+  std::atomic<int32_t> nhi;         // 1 + the highest slot ever taken: the dispatcher scans [0, nhi) (slots are taken lowest first)
+  uint64_t off_slots, off_prof, off_spec, off_over, off_ok, off_flag, off_list, off_info;   // byte offsets from the segment's start
   uint64_t off_wn, off_press, off_atmprof, off_angles, off_species, species_len;
   // dispatcher
   alignas(64) std::atomic<uint32_t> bell;      // futex word: bumped by every post
@@ -132,6 +136,7 @@ struct Header {
   alignas(64) std::atomic<uint64_t> nbatches;  // launches made ...
   std::atomic<uint64_t> nserved;               // ... and profiles served by them
   std::atomic<uint64_t> nfull;                 // launches that held every registered client
+  std::atomic<uint64_t> ngathered;             // launches whose slots were not consecutive (one launch all the same)
   char owner_err[256];                         // kGone after a failed start: why
 };
 static_assert(sizeof(Header) <= kPage, "Header must fit the first page");
@@ -149,7 +154,7 @@ struct Info {
 };
 
 struct Layout {
-  size_t off_slots, off_prof, off_spec, off_over, off_ok, off_flag, off_wn, off_press, off_atmprof, off_angles, off_species, total;
+  size_t off_slots, off_prof, off_spec, off_over, off_ok, off_flag, off_list, off_wn, off_press, off_atmprof, off_angles, off_species, total;
   static Layout of(const Info &i, int maxclients) {
     Layout l{};
     size_t o = kPage;
@@ -160,6 +165,7 @@ struct Layout {
     l.off_over = o; o += round_up(sizeof(double) * (size_t)maxclients * 3, 256);
     l.off_ok = o; o += round_up((size_t)maxclients, 256);
     l.off_flag = o; o += 256;            // a word the GPU writes when a launch has finished (csrc/svc.hip)
+    l.off_list = o; o += round_up(sizeof(int32_t) * (size_t)maxclients, 256);   // the slots of the launch in flight (gathered launches)
     o = round_up(o, kPage);
     l.off_wn = o; o += sizeof(double) * i.wn_full.size();
     l.off_press = o; o += sizeof(double) * i.press.size();
@@ -183,6 +189,7 @@ struct Segment {
   double *spec(int i) const { return reinterpret_cast<double *>(base + hdr()->off_spec) + (size_t)i * hdr()->Wl; }
   double *over(int i) const { return reinterpret_cast<double *>(base + hdr()->off_over) + (size_t)i * 3; }
   unsigned char *ok(int i) const { return reinterpret_cast<unsigned char *>(base + hdr()->off_ok) + i; }
+  int32_t *list() const { return reinterpret_cast<int32_t *>(base + hdr()->off_list); }
   // the part the backend's kernels touch: [data_begin, data_begin + data_bytes)
   char *data_begin() const { return base + hdr()->off_prof; }
   size_t data_bytes() const { return hdr()->off_wn - hdr()->off_prof; }
@@ -232,6 +239,7 @@ inline bool elect(const std::string &name, Segment &seg) {
   h->state.store(kLoading);
   h->version = kVersion;
   h->maxclients = 0;
+  h->nhi.store(0);
   h->total_bytes = kPage;
   h->owner_err[0] = 0;
   h->owner_pid.store((int32_t)getpid(), std::memory_order_release);
@@ -251,10 +259,11 @@ inline void publish(Segment &seg, const Info &info, int maxclients) {
   h->device = info.device;
   h->nprof = info.nprof(); h->Wl = info.Wl();
   h->off_slots = l.off_slots; h->off_prof = l.off_prof; h->off_spec = l.off_spec; h->off_over = l.off_over; h->off_ok = l.off_ok; h->off_flag = l.off_flag;
+  h->off_list = l.off_list;
   h->off_info = l.off_wn;
   h->off_wn = l.off_wn; h->off_press = l.off_press; h->off_atmprof = l.off_atmprof; h->off_angles = l.off_angles;
   h->off_species = l.off_species; h->species_len = info.species.size();
-  h->bell.store(0); h->asleep.store(0); h->nbatches.store(0); h->nserved.store(0); h->nfull.store(0);
+  h->bell.store(0); h->asleep.store(0); h->nbatches.store(0); h->nserved.store(0); h->nfull.store(0); h->ngathered.store(0);
   for (int i = 0; i < maxclients; i++) {
     Slot *s = new (seg.slot(i)) Slot;
     s->pid.store(0); s->st.store(kIdle); s->sleeping.store(0); s->scat_flag = -1; s->rc = 0; s->err[0] = 0;
@@ -321,6 +330,10 @@ struct Client {
       int32_t expect = 0;
       if (seg.slot(i)->pid.compare_exchange_strong(expect, (int32_t)getpid())) { slot = i; break; }
     }
+    if (slot >= 0) {
+      int32_t hi = h->nhi.load();
+      while (hi < slot + 1 && !h->nhi.compare_exchange_weak(hi, slot + 1)) {}
+    }
     if (slot < 0) throw Error{kENOTSUP, "shareOpacity: all " + std::to_string(h->maxclients) + " client slots of the service are taken (BARTRT_SVC_MAXCLIENTS)"};
     Slot *s = seg.slot(slot);
     s->st.store(kIdle); s->sleeping.store(0);
@@ -380,11 +393,15 @@ struct Client {
 };
 
 // ---- dispatcher -----------------------------------------------------------------------------
-// What one launch computes: slots [first, first + n) -- profiles, overrides, spectra and flags lie
-// consecutively in the segment -- all with the same scattering flag.  Throws Error / anything with
-// what(): the slots of the run are failed with the message.
+// What one launch computes: the n slots of `slots` (ascending; consecutive or not -- a worker in the middle of the range
+// that missed the round does not split the batch), all with the same scattering flag.  `nominal` is the number of
+// walkers the KERNEL is to be chosen for: the registered clients (or BARTRT_SVC_KERNEL_WALKERS), not the n that happened
+// to post together -- every kernel computes a walker independently of its neighbours, so a straggler's launch then
+// gives the bits the full batch would have given it (the reference's worker calls its own engine: the same chain is
+// the same bits every run, code/BARTfunc.py:363).  Throws Error / anything with what(): the slots of the run are
+// failed with the message.
 struct Backend {
-  virtual void run(int first, int n, int scat_flag, bool any_over, bool any_cloud) = 0;
+  virtual void run(const int *slots, int n, int nominal, int scat_flag, bool any_over, bool any_cloud) = 0;
   virtual ~Backend() {}
 };
 
@@ -393,18 +410,19 @@ struct Dispatcher {
   Backend *backend = nullptr;
   std::atomic<bool> stop{false};
   double window_us = 30.0, idle_spin_us = 100.0;
-  bool wait_all = false;                 // tests (BARTRT_SVC_WAIT_ALL): the window waits for every REGISTERED client, not only the active ones
+  bool wait_all = false;                 // BARTRT_SVC_WAIT_ALL: the window waits for every REGISTERED client, not only the active ones
+  int kernel_walkers = 0;                // BARTRT_SVC_KERNEL_WALKERS: pins Backend::run's `nominal` (0: the registered clients)
   std::vector<unsigned char> active;     // slots expected in the next batch: they were in the last one (or posted since)
 
   void loop() {
     Header *h = seg->hdr();
-    const int nmax = h->maxclients;
-    active.assign(nmax, 0);
-    std::vector<int> posted;
+    active.assign(h->maxclients, 0);
+    std::vector<int> posted, group;
     auto last_prune = clk::now();
     auto idle_since = clk::now();
     while (!stop.load(std::memory_order_acquire)) {
       const uint32_t b = h->bell.load();
+      const int nmax = h->nhi.load(std::memory_order_acquire);     // (slots are taken lowest first: nothing lives above)
       posted.clear();
       for (int i = 0; i < nmax; i++)
         if (seg->slot(i)->st.load(std::memory_order_acquire) == kPosted) posted.push_back(i);
@@ -447,22 +465,28 @@ struct Dispatcher {
       h->nbatches.fetch_add(1, std::memory_order_relaxed);
       h->nserved.fetch_add(posted.size(), std::memory_order_relaxed);
       if ((int)posted.size() == nreg) h->nfull.fetch_add(1, std::memory_order_relaxed);
-      // consecutive slots with one scattering flag go out as one launch
-      size_t k = 0;
-      while (k < posted.size()) {
-        size_t e = k + 1;
-        const int flag = seg->slot(posted[k])->scat_flag;
-        while (e < posted.size() && posted[e] == posted[e - 1] + 1 && seg->slot(posted[e])->scat_flag == flag) e++;
-        serve(posted[k], (int)(e - k), flag);
-        k = e;
+      // the slots with one scattering flag go out as one launch, consecutive or not
+      const int nominal = kernel_walkers > 0 ? kernel_walkers : nreg;
+      while (!posted.empty()) {
+        const int flag = seg->slot(posted[0])->scat_flag;
+        group.clear();
+        size_t keep = 0;
+        for (int i : posted) {
+          if (seg->slot(i)->scat_flag == flag) group.push_back(i);
+          else posted[keep++] = i;
+        }
+        posted.resize(keep);
+        serve(group, nominal, flag);
       }
       idle_since = clk::now();
     }
   }
 
-  void serve(int first, int n, int flag) {
+  void serve(const std::vector<int> &slots, int nominal, int flag) {
     bool any_over = false, any_cloud = false;
-    for (int i = first; i < first + n; i++) {
+    for (size_t k = 1; k < slots.size(); k++)
+      if (slots[k] != slots[k - 1] + 1) { seg->hdr()->ngathered.fetch_add(1, std::memory_order_relaxed); break; }
+    for (int i : slots) {
       const double *ov = seg->over(i);
       for (int j = 0; j < 3; j++) any_over |= ov[j] == ov[j];
       any_cloud |= ov[1] == ov[1];
@@ -470,7 +494,8 @@ struct Dispatcher {
     int rc = 0;
     std::string msg;
     try {
-      backend->run(first, n, flag, any_over, any_cloud);
+      backend->run(slots.data(), (int)slots.size(), nominal < (int)slots.size() && kernel_walkers <= 0 ? (int)slots.size() : nominal,
+                   flag, any_over, any_cloud);
     } catch (const Error &e) {
       rc = e.code; msg = e.msg;
     } catch (const std::exception &e) {
@@ -478,7 +503,7 @@ struct Dispatcher {
     } catch (...) {
       rc = kENODEV; msg = "the engine failed on this batch";
     }
-    for (int i = first; i < first + n; i++) {
+    for (int i : slots) {
       Slot *s = seg->slot(i);
       if (rc) {
         s->rc = rc;

@@ -61,6 +61,7 @@ def lib():
         L = C.CDLL(_LIBPATH)
         d, i, p = C.c_double, C.c_int, C.c_void_p
         L.bartrt_last_error.restype = C.c_char_p
+        L.bartrt_build_id.restype = C.c_char_p
         L.bartrt_init.argtypes = [i, C.POINTER(C.c_char_p)]
         L.bartrt_get_waveno_arr.argtypes = [p, i]
         L.bartrt_set_radius.argtypes = [d]
@@ -98,6 +99,7 @@ def lib():
         L.bartrt_get_rtc_stats.argtypes = [C.POINTER(i)] * 4 + [C.POINTER(d)]
         L.bartrt_rtc_compile.argtypes = [C.c_char_p, i, C.POINTER(C.c_long)]
         L.bartrt_get_service_stats.argtypes = [C.POINTER(C.c_ulonglong)] * 3
+        L.bartrt_get_service_gathered.argtypes = [C.POINTER(C.c_ulonglong)]
         L.bartrt_prefetch_profiles_dev.argtypes = [C.c_void_p, i]
         L.bartrt_get_integ.argtypes = [C.POINTER(i)]
         L.bartrt_walked_end.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
@@ -247,7 +249,9 @@ def get_service_stats():
     every registered client."""
     v = [C.c_ulonglong(0) for _ in range(3)]
     check(lib().bartrt_get_service_stats(*[C.byref(x) for x in v]))
-    return {"launches": v[0].value, "profiles": v[1].value, "full": v[2].value}
+    g = C.c_ulonglong(0)
+    check(lib().bartrt_get_service_gathered(C.byref(g)))
+    return {"launches": v[0].value, "profiles": v[1].value, "full": v[2].value, "gathered": g.value}
 
 
 def get_integ() -> int:

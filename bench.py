@@ -175,21 +175,13 @@ def parity_record(case, conv, profs, spec_gpu, plain_equal, what, max_walkers=16
     return rec
 
 
-RT_SOURCES = ("kernels.hpp", "integ.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "prep.hpp",
-              "engine.hpp", "rt_eclipse_i0.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1.hip", "rt_eclipse_i1_ilp.hip",
-              "rt_eclipse_slant_ilp.hip", "kernels.hip", "engine.hip")
-
-
 def source_id():
-    """Short hash of the sources the eclipse RT kernel, its launch and its inputs are built
-    from: ties committed profiler figures (PMC traffic, instruction mix) to the build they
-    were taken on; bench.py reports them only when these sources are unchanged."""
-    import hashlib
-    h = hashlib.sha1()
-    for f in RT_SOURCES:
-        h.update(open(os.path.join(ROOT, "bart_amd", "csrc", f), "rb").read())
-    h.update(open(os.path.join(ROOT, "bart_amd", "build.py"), "rb").read())   # compiler flags
-    return h.hexdigest()[:12]
+    """The loaded library's own id (bartrt_build_id: a hash of the code objects and host text of the RT translation
+    units, fixed at build time -- bart_amd/build.py code_id).  Ties committed profiler figures (PMC traffic, SQ pass,
+    instruction mix) to the build they were taken on: bench.py reports them only under the same id.  A comment edit
+    keeps the id (round 5 lost its `traffic` to one: the id then was a hash of source text)."""
+    from bart_amd import transit_module as trm
+    return trm.lib().bartrt_build_id().decode()
 
 
 def _cia_temps(path):

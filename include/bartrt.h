@@ -158,6 +158,9 @@ int bartrt_get_service(int *mode, int *owner_pid, int *slot, int *nclients);
  * registered client (nprofiles / nlaunches = the mean batch). */
 int bartrt_get_service_stats(unsigned long long *nlaunches, unsigned long long *nprofiles,
                              unsigned long long *nfull);
+/* ... and the rounds whose slots were not consecutive (a worker in the middle of the slot
+ * range missed the round): served by one launch all the same, through a gather / scatter pair. */
+int bartrt_get_service_gathered(unsigned long long *ngathered);
 
 /* Prefetched preparation.  Names the profile batch of the bartrt_run_transit_batch_dev call
  * AFTER the next one: the next call's RT launch prepares that batch's layer records
@@ -266,6 +269,11 @@ int bartrt_step_bandflux_dev(const double *d_spec_full, int nwalkers,
 
 /* ---- introspection ----------------------------------------------------- */
 const char *bartrt_last_error(void);
+/* Twelve hex digits: a hash of the CODE the eclipse RT launch is made of (device
+ * code objects and host text of the RT translation units), fixed at build time.
+ * Never fails, needs no GPU.  Profiler figures under profiles/ carry the id of the
+ * library they were measured on; bench.py quotes them only under the same id. */
+const char *bartrt_build_id(void);
 int bartrt_get_nlayers(void);
 int bartrt_get_nspecies(void);
 int bartrt_get_nprof(void);                 /* (S+1)*L */

@@ -20,10 +20,16 @@ static const int kNprofL = 7, kS = 2, kW = 513;
 struct Echo : Backend {
   Segment *seg;
   unsigned long launches = 0;
-  void run(int first, int n, int scat_flag, bool, bool) override {
+  unsigned long gathered = 0;     // launches whose slots were not consecutive
+  int nominal_min = 1 << 30, nominal_max = 0;
+  void run(const int *slots, int n, int nominal, int scat_flag, bool, bool) override {
     launches++;
+    for (int k = 1; k < n; k++) if (slots[k] != slots[k - 1] + 1) { gathered++; break; }
+    nominal_min = nominal < nominal_min ? nominal : nominal_min;
+    nominal_max = nominal > nominal_max ? nominal : nominal_max;
     const Header *h = seg->hdr();
-    for (int i = first; i < first + n; i++) {
+    for (int k = 0; k < n; k++) {
+      const int i = slots[k];
       const double *p = seg->prof(i);
       double s = 0;
       for (int k = 0; k < h->nprof; k++) s += p[k];
@@ -65,10 +71,11 @@ int main(int argc, char **argv) {
       info.press.assign(kNprofL, 1.0); info.atm_prof.assign((kS + 1) * kNprofL, 0.5); info.angles = {0.0};
       info.species = "H2 He";
       own = seg;
-      publish(own, info, 16);
+      publish(own, info, (int)env_num("BARTRT_SVC_MAXCLIENTS", 16.0));
       echo.seg = &own;
       disp.seg = &own; disp.backend = &echo;
       disp.window_us = env_num("BARTRT_SVC_WINDOW_US", 200.0);
+      disp.kernel_walkers = (int)env_num("BARTRT_SVC_KERNEL_WALKERS", 0.0);
       th = std::thread([&] { disp.loop(); });
       cli.seg.name = name;
       cli.seg.fd = shm_open(name.c_str(), O_RDWR, 0600);
@@ -117,9 +124,18 @@ int main(int argc, char **argv) {
     for (int j = 0; j < h->Wl; j++) bad += spec[j] != s * (j + 1) + extra;
     bad += ok != (prof[0] > 0 ? 1 : 0);
     done++;
-    if (std::getenv("SVC_HARNESS_THINK_US")) std::this_thread::sleep_for(std::chrono::microseconds((long)env_num("SVC_HARNESS_THINK_US", 0)));
+    // "think time" between two calls: of every client, or (SVC_HARNESS_SLOW_RANK) of one straggler only
+    if (std::getenv("SVC_HARNESS_THINK_US") && (!std::getenv("SVC_HARNESS_SLOW_RANK") || (int)env_num("SVC_HARNESS_SLOW_RANK", -1) == rank))
+      std::this_thread::sleep_for(std::chrono::microseconds((long)env_num("SVC_HARNESS_THINK_US", 0)));
   }
   const double dt = since(t0);
+  const int myslot = cli.slot;
+  if (std::getenv("SVC_HARNESS_LEAVE_TOGETHER")) {
+    // MC3 ends all chains together (code/BARTfunc.py:405-412): nobody lets go of its slot while another still runs
+    const auto tl = clk::now();
+    while (h->nserved.load() < (unsigned long long)expect * (unsigned long long)nrounds && since(tl) < 30.0)
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
   unsigned long long nb = h->nbatches.load(), ns = h->nserved.load(), nf = h->nfull.load();
   cli.detach();
   if (owner) {
@@ -132,7 +148,9 @@ int main(int argc, char **argv) {
     th.join();
   }
   std::printf("{\"rank\": %d, \"owner\": %s, \"done\": %d, \"bad\": %d, \"err\": %d, \"msg\": \"%s\", \"us_per_call\": %.2f, "
-              "\"batches\": %llu, \"served\": %llu, \"full\": %llu, \"launches\": %lu}\n",
-              rank, owner ? "true" : "false", done, bad, err, msg.c_str(), dt / (nrounds > 0 ? nrounds : 1) * 1e6, nb, ns, nf, echo.launches);
+              "\"batches\": %llu, \"served\": %llu, \"full\": %llu, \"launches\": %lu, \"gathered\": %lu, "
+              "\"nominal_min\": %d, \"nominal_max\": %d, \"slot\": %d}\n",
+              rank, owner ? "true" : "false", done, bad, err, msg.c_str(), dt / (nrounds > 0 ? nrounds : 1) * 1e6, nb, ns, nf, echo.launches,
+              echo.gathered, echo.nominal_min, echo.nominal_max, myslot);
   return 0;
 }

@@ -229,3 +229,59 @@ def test_client_refuses_what_only_an_engine_serves(tmp_path):
             "trm.free_memory()\n" % (ROOT, case.tcfg))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_a_late_worker_gets_the_bits_of_the_full_batch(tmp_path):
+    """VERDICT r5 item 3 (a, b, c): NO `BARTRT_SVC_WAIT_ALL`, the production window of 30 us, and one worker in the
+    middle of the slot range late on purpose every third step (by 300 us: ten windows).  Its profile goes out in a
+    launch of its own, the nine others in a launch without it -- gathered from non-consecutive slots, ONE launch -- and
+    every spectrum of every step is the one a ten-walker batch call computes, bit for bit: the kernel is chosen for the
+    REGISTERED workers, not for the profiles that happened to post together (the reference's worker calls its own
+    engine, the same chain is the same bits every run: code/BARTfunc.py:363)."""
+    from bart_amd import engine, synth, transit_module as trm
+    # 37 columns per walker: ten walkers = 370 columns (the adjacent-rows range), one walker = 37 (32 rows per step),
+    # nine = 333: three different kernels if the batch that formed were to choose
+    case = synth.make_case(str(tmp_path / "s"), nlayers=40, nwave=2330, extra_keys={"shareOpacity": ""})
+    (tmp_path / "o").mkdir()
+    steps = 60
+    procs = [start_worker(case.tcfg, r, steps, os.path.join(str(tmp_path / "o"), "w%d.npy" % r),
+                          ("--late-every", "3", "--late-us", "300" if r == 4 else "0"), {"BARTRT_SVC_WINDOW_US": "30"})
+             for r in range(10)]
+    try:
+        ready = [expect(p, "ready") for p in procs]
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        done = [expect(p, "done") for p in procs]
+        for p in procs:
+            p.stdin.write("bye\n"); p.stdin.flush()
+        for p in procs:
+            assert p.wait(timeout=120) == 0, p.stderr.read()[-3000:]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert sorted(r["slot"] for r in ready) == list(range(10))
+    stats = max((d["service_stats"] for d in done), key=lambda s: s["launches"])
+    # the straggler did split rounds (launches that did not hold all ten) ...
+    assert stats["launches"] > stats["full"] + 10, stats
+    # ... and whoever held a middle slot was missing from some: those went out gathered, as one launch
+    assert stats["gathered"] > 0, stats
+    # every step of every worker: the same bits
+    assert [d["steps_that_differ_from_the_first"] for d in done] == [0] * 10, done
+    engine.init(own_engine_cfg(case, tmp_path))
+    try:
+        L = engine.nlayers()
+        prof0 = case.profiles().ravel()
+        batch = engine.run_batch(np.stack([worker_profile(prof0, L, r) for r in range(10)]))
+        walked = {}
+        for n in (1, 9, 10):
+            engine.walked_begin()
+            engine.run_batch(np.stack([worker_profile(prof0, L, r) for r in range(n)]))
+            walked[n] = engine.walked_end()[2]
+    finally:
+        trm.free_memory()
+    assert len(set(walked.values())) > 1, walked          # the batch sizes that formed WOULD have taken different kernels
+    spec = [np.load(os.path.join(str(tmp_path / "o"), "w%d.npy" % r)) for r in range(10)]
+    for r in range(10):
+        assert np.array_equal(spec[r][1], batch[r]), r
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("bartrt_svc_")]

@@ -117,3 +117,49 @@ def test_a_failed_batch_fails_its_callers_only(harness):
     # everybody kept going afterwards
     assert all(r["done"] >= 39 and r["bad"] == 0 for r in rep), rep
     assert not leftovers(key)
+
+
+def test_a_straggler_in_the_middle_does_not_split_the_batch(harness):
+    """(c) the posted slots of a round go out as ONE launch whether they are consecutive or not --
+    a worker in the middle of the slot range that is late every round used to cut every batch in two; (a) the walker
+    count the backend is told to choose its kernel for is the REGISTERED clients, the same in every launch, however few
+    profiles happened to post together."""
+    key = "f%f" % time.time()
+    n, rounds = 6, 150
+    res = run(harness, key, n, rounds, ranks=[0, 1, 3, 4, 5, 6],       # (rank 2 carries another scattering flag: left out)
+              env={"BARTRT_SVC_WINDOW_US": "30", "SVC_HARNESS_THINK_US": "400", "SVC_HARNESS_SLOW_RANK": "3",
+                   "SVC_HARNESS_LEAVE_TOGETHER": "1"})
+    rep = [r for _, r in res]
+    assert all(rc == 0 for rc, _ in res) and sum(r["owner"] for r in rep) == 1
+    assert all(r["done"] == rounds and r["bad"] == 0 and r["err"] == 0 for r in rep), rep
+    owner = [r for r in rep if r["owner"]][0]
+    slow = [r for r in rep if r["rank"] == 3][0]
+    assert owner["served"] == n * rounds
+    assert owner["launches"] == owner["batches"]                      # one flag: one launch per round, always
+    if 0 < slow["slot"] < n - 1:                                      # (the straggler took a middle slot: arrival order)
+        assert owner["gathered"] > 0, owner                           # rounds without it were launched gathered
+    assert owner["nominal_min"] == owner["nominal_max"] == n, owner   # never the size of the round that formed
+
+
+def test_the_kernel_walkers_can_be_pinned(harness):
+    key = "g%f" % time.time()
+    res = run(harness, key, 3, 30, ranks=[0, 1, 3], env={"BARTRT_SVC_KERNEL_WALKERS": "12", "SVC_HARNESS_LEAVE_TOGETHER": "1"})
+    owner = [r for _, r in res if r["owner"]][0]
+    assert owner["nominal_min"] == owner["nominal_max"] == 12 and all(r["bad"] == 0 and r["done"] == 30 for _, r in res)
+    assert not leftovers(key)
+
+
+def test_seventy_chains_all_get_a_slot(harness):
+    """The reference leaves the number of chains free (examples/demo/BART_eclipse.cfg:90-91); the service had 32 slots
+    (64 at most) and the 33rd worker's transit_init failed.  Default 256 now, 1 024 at most."""
+    key = "h%f" % time.time()
+    n = 70
+    res = run(harness, key, n, 12, ranks=[r for r in range(n + 1) if r != 2],
+              env={"BARTRT_SVC_MAXCLIENTS": "256", "BARTRT_SVC_WINDOW_US": "2000", "SVC_HARNESS_LEAVE_TOGETHER": "1"})
+    rep = [r for _, r in res]
+    assert all(rc == 0 for rc, _ in res) and sum(r["owner"] for r in rep) == 1
+    assert all("attach_error" not in r and r["done"] == 12 and r["bad"] == 0 for r in rep), [r for r in rep if r.get("bad") or "attach_error" in r]
+    assert sorted(r["slot"] for r in rep) == list(range(n))           # lowest slots first, one each
+    owner = [r for r in rep if r["owner"]][0]
+    assert owner["served"] == n * 12 and owner["batches"] < n * 12 // 4
+    assert not leftovers(key)

@@ -8,7 +8,7 @@ tests/test_gpu_share.py; talks to its parent over stdin / stdout:
     child  -> "done {json}"      after its steps
     parent -> "bye"              once every child is done (the grid's owner must outlive the others' use)
 usage: mc3_child.py <transit.cfg> <rank> <nsteps> [<out.npy>] [--radius km] [--cloudtop log10bar]
-                    [--scattering flag value] [--until-error]
+                    [--scattering flag value] [--until-error] [--late-every K --late-us U]
 The setters are this process's own trm.set_radius / set_cloudtop / set_scattering (code/BARTfunc.py:350-360);
 --until-error: keep calling until the engine refuses (a chain-service client whose owner has died), report it."""
 import argparse
@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--radius", type=float); ap.add_argument("--cloudtop", type=float)
     ap.add_argument("--scattering", nargs=2, type=float)
     ap.add_argument("--until-error", action="store_true")
+    ap.add_argument("--late-every", type=int, default=0, help="this worker is late for every K-th step ...")
+    ap.add_argument("--late-us", type=float, default=0.0, help="... by this many microseconds (a straggler on purpose)")
     a = ap.parse_args()
     tcfg, rank, nsteps, out = a.tcfg, a.rank, a.nsteps, a.out
     from bart_amd import transit_module as trm
@@ -86,10 +88,20 @@ def main():
     lat = np.zeros(max(nsteps, 1))
     gc.disable()          # (as timeit does: a full collection is a pause of tens of milliseconds in the middle of the loop)
     t0 = time.perf_counter()
+    first, differ = None, 0      # the chain's profile is the same every step: so must its spectrum be, bit for bit
     for i in range(nsteps):
+        if a.late_every and i % a.late_every == a.late_every - 1:
+            t_late = time.perf_counter() + a.late_us * 1e-6
+            while time.perf_counter() < t_late:
+                pass
         t1 = time.perf_counter()
         spec = trm.run_transit(mine, n)
         lat[i] = time.perf_counter() - t1
+        if a.late_every:             # (not in the timed runs of tools/mc3_bench.py: the compare is 10 us of host time per step)
+            if first is None:
+                first = spec.copy()
+            elif not np.array_equal(first, spec):
+                differ += 1
     dt = time.perf_counter() - t0
     gc.enable()
     common = trm.run_transit(prof0, n)
@@ -99,7 +111,7 @@ def main():
            "call_us_median": float(np.median(lat) * 1e6), "call_us_p90": float(np.percentile(lat, 90) * 1e6),
            "call_us_max": float(lat.max() * 1e6), "calls_over_twice_the_median": int((lat > 2 * np.median(lat)).sum()),
            "slowest_calls": [[int(i), round(float(lat[i]) * 1e6, 1)] for i in np.argsort(lat)[-6:][::-1]],
-           "hip_context": kfd_touched()}
+           "hip_context": kfd_touched(), "steps_that_differ_from_the_first": differ if a.late_every else None}
     if svc["mode"] != "engine":
         rep["service_stats"] = trm.get_service_stats()
     print("done " + json.dumps(rep), flush=True)

@@ -37,7 +37,7 @@ def test_bench_collective_path_under_torchrun_world1(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--force-collective", "--force-replicas-leg", "--steps", "8", "--warmup", "2",
-           "--no-extras", "--no-cpu", "--nwave", "2501", "--workdir", str(tmp_path / "w")]
+           "--no-extras", "--no-cpu", "--nwave", "2501", "--workdir", str(tmp_path / "w"), "--detail", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -50,7 +50,10 @@ def test_bench_collective_path_under_torchrun_world1(tmp_path):
     # the line certifies its own (gathered) spectra against the oracle, and the replicas comparison of the N > 1
     # line ran: the engine freed and initialised twice more under the live process group
     assert j["parity"]["ok"] and j["parity"]["max_rel_err"] < 1e-9 and j["parity"]["bit_equal_to_plain_launch"]
-    assert j["replicas"]["value"] > 0 and j["replicas"]["diag"]["mode"] == "replicas"
+    assert j["replicas"]["value"] > 0 and len(lines[0]) <= 4096
+    # (the line is the contract's record; the diagnostics of the replicas leg are in the detail file it names)
+    full = json.load(open(tmp_path / "detail.json"))
+    assert full["replicas"]["diag"]["mode"] == "replicas" and full["replicas"]["value"] == pytest.approx(j["replicas"]["value"], rel=1e-5)
 
 
 CHILD = r"""

@@ -54,6 +54,11 @@ def test_shapes_outside_the_aot_set_are_instantiated_and_match_the_oracle(tmp_pa
               ("m9c2", dict(cia=1, **many_molecules(9)), None, None),
               ("m4c6", dict(cia=3), None, None),                                 # three CS files
               ("a12", dict(raygrid=(0, 8, 16, 24, 32, 40, 48, 56, 64, 72, 78, 84)), None, None),
+              # since round 6 NO ray grid other than the five-angle one, and no shape of seven or eight molecules, is
+              # built ahead of time (the library went from 101 to 54 MB): the sizes that used to be are instantiated too
+              ("a3", dict(raygrid=(0, 35, 70)), None, None),
+              ("a7v", dict(raygrid=(0, 12, 25, 38, 51, 64, 77)), 0, "vertical"),
+              ("m7c2", dict(cia=1, **many_molecules(7)), None, None),
               ("m9v0", dict(cia=1, **many_molecules(9)), 0, "vertical"),         # another rule, the other cut
               ("m7c4i2", dict(cia=2, **many_molecules(7)), 2, None)]
     jobs, cases = [], {}
@@ -65,7 +70,7 @@ def test_shapes_outside_the_aot_set_are_instantiated_and_match_the_oracle(tmp_pa
         jobs.append((c.tcfg, os.path.join(c.dir, "p.npy"), os.path.join(c.dir, "s.npy"), nws, integ, cut))
         cases[name] = (c, integ, cut)
     rep = run_child(jobs, {"BARTRT_RTC_CACHE": cache})
-    assert rep["rtc"]["available"] and rep["rtc"]["compiled"] >= 8 and rep["rtc"]["failed"] == 0, rep["rtc"]
+    assert rep["rtc"]["available"] and rep["rtc"]["compiled"] >= 11 and rep["rtc"]["failed"] == 0, rep["rtc"]
     wide = ("m7c4", "m8c4", "m9c2", "m7c4i2")       # more than 20 loads per layer, single-wave kernel at 400 columns (m9v0: rule 0 + vertical cut keeps the layer-parallel kernel to 640)
     for key, kname in rep["names"].items():
         shape = os.path.basename(os.path.dirname(key.split("|")[0]))

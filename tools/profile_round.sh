@@ -45,8 +45,26 @@ python3 tools/isa_stats.py --ilp > "profiles/${tag}_isa_rt_eclipse_fast_5_4_1_sq
 # (the default rule's kernel: its figures feed the bench line's fp64 record)
 python3 tools/isa_stats.py --ilp rt_eclipse_simpsonILi5ELi4ELi2ELb1ELi1ELb0E > "profiles/${tag}_isa_rt_eclipse_simpson_5_4_2_sq_ilp.txt"
 python3 tools/isa_stats.py --json profiles/isa_latest.json rt_eclipse_simpson_slantILi5ELi4ELi2ELb1ELi1ELb0E > "profiles/${tag}_isa_rt_eclipse_simpson_slant_5_4_2_sq_ilp.txt"
-# the bench line last, so that its `traffic` is this round's PMC figure
+# SQ pass of the same build (roofline.bound_measured)
+bash tools/sq_counters.sh "$tag" > "$out/sq.log" 2>&1
+# the bench line last, so that its `traffic` / `bound_measured` / `fp64` are this build's figures
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cp "$out/bench.json" "profiles/${tag}_bench.json"
-mkdir -p "$out/profiles" && cp profiles/${tag}_* profiles/pmc_latest.json profiles/isa_latest.json "$out/profiles/" 2>/dev/null
-tail -c 600 "$out/bench.json"
+cp bench_detail.json "profiles/${tag}_bench_detail.json"
+mkdir -p "$out/profiles" && cp profiles/${tag}_* profiles/pmc_latest.json profiles/isa_latest.json profiles/sq_latest.json "$out/profiles/" 2>/dev/null
+tail -c 1800 "$out/bench.json"
+# the round's evidence must be the shipped library's: every profiler record carries bartrt_build_id(), and the line
+# quotes them -- a record taken on another build fails the script
+python3 - "$tag" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import bench
+sid = bench.source_id()
+bad = [f for f in ("pmc_latest.json", "isa_latest.json", "sq_latest.json")
+       if json.load(open("profiles/" + f)).get("source_id") != sid]
+line = json.loads(open("profiles/%s_bench.json" % sys.argv[1]).read().strip().splitlines()[-1])
+r = line["roofline"]
+missing = [k for k in ("traffic", "traffic_source", "bound_measured", "fp64_frac") if r.get(k) is None]
+print("library id %s; line id %s; stale records: %s; null in the line: %s" % (sid, line.get("source_id"), bad, missing))
+sys.exit(1 if (bad or missing or line.get("source_id") != sid or len(open("profiles/%s_bench.json" % sys.argv[1]).read()) > 4096) else 0)
+PY

@@ -542,11 +542,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // sorted list overlaps one wave's points).  Here every wave works alone on its 64
 // points, no workgroup barrier:
 //   A1 lane = line, 64 lines of the window at a time: stage it; the lines above the
-//      strength threshold whose cut reaches the wave's span join a queue in LDS
-//   A2 (the queue holds 64 lines, or the window is exhausted) lane = queued line: its
-//      range of the wave's points (binary search), prefix sum of the range lengths ->
-//      pair offsets; the round takes the leading lines whose pairs fit the LDS buffer
-//      (kPairCap), the rest stay queued
+//      strength threshold whose cut reaches the wave's span join a queue in LDS (a ring), each
+//      with its range of the wave's points (binary search, once per line)
+//   A2 (the queue holds 64 lines, or the window is exhausted) lane = queued line: prefix sum
+//      of the range lengths -> pair offsets; the round takes the leading lines whose pairs fit
+//      the LDS buffer (kPairCap), the rest stay queued
 //   B  lane = (line, point) pair, 64 pairs per pass, all lanes busy: the pair's
 //      contribution goes to the buffer in pair order
 //   C  lane = point: adds its pairs in line order (fixed summation order, no
@@ -563,11 +563,16 @@ constexpr int kPairCap = 240;                       // pairs per round (LDS buff
 
 struct PairScratch {                        // per wave
   double wnu[64];                           // the wave's points
-  double nu0[128], amp[128], xs[128], y[128], cut[128];   // queue of kept lines that reach the wave, list order
+  // queue of kept lines that reach the wave, list order: a RING of 128 slots (round 6: a round takes the ~9 leading
+  // lines whose pairs fit the buffer -- 25 points per line on config 5's Doppler cores -- and moving the other ~55 up
+  // the queue every round was a tenth of the kernel)
+  double nu0[128], amp[128], xs[128], y[128], cut[128];
   double val[kPairCap];                     // pair contributions of the round
-  unsigned short off[64], first[64];        // pair offset and first point of each line of the round
+  unsigned short off[64];                   // pair offset of each line of the round
+  unsigned char qfirst[128], qn[128];       // a queued line's first point and point count, found ONCE when it is staged
+                                            // (round 6: every round searched the ranges of all 64 queued lines again)
   unsigned char ord[128];                   // voigt_order(y) of the queued lines
-  unsigned char line[kPairCap];             // the line (queue slot) a pair belongs to
+  unsigned char line[kPairCap];             // the line (position in the round) a pair belongs to
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -599,26 +604,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int g_lo = a.per_group ? blockIdx.z : 0, g_hi = a.per_group ? blockIdx.z + 1 : d.ngroup;
   const int nmax = 2 * a.pair_reach + 3;   // points of a line incl. one of slack either side (<= kPairCap)
   double acc = 0.0;
-  int pending = 0;                         // queued lines (wave-uniform)
+  int pending = 0, head = 0;               // queued lines and the ring's first slot (wave-uniform)
   // Rounds B / C over the head of the queue: while it holds 64 lines (all of it when flushing)
   auto rounds = [&](bool flush) {
     while (pending >= 64 || (flush && pending > 0)) {
       const int nq = min(pending, 64);
-      // ---- A2  lane = queued line: its range of the wave's points
+      // ---- A2  lane = queued line: its range of the wave's points, as found when it was staged
+      const int slot = (head + lane) & 127;
       int first = 0, n = 0;
-      if (lane < nq) {
-        const double lo = ws.nu0[lane] - ws.cut[lane], hi = ws.nu0[lane] + ws.cut[lane];
-        int b = 0, e = 64;  // b -> first point >= lo
-        while (b < e) { const int m = (b + e) >> 1; if (ws.wnu[m] < lo) b = m + 1; else e = m; }
-        int c = b;          // c -> first point > hi
-        e = 64;
-        while (c < e) { const int m = (c + e) >> 1; if (ws.wnu[m] <= hi) c = m + 1; else e = m; }
-        if (c > b) {
-          // one point of slack either side: the exact |nu - nu0| <= cut test is per pair
-          first = b > 0 ? b - 1 : 0;
-          n = min((c < 64 ? c + 1 : 64) - first, nmax);
-        }
-      }
+      if (lane < nq) { first = ws.qfirst[slot]; n = ws.qn[slot]; }
       int incl = n;  // inclusive prefix sum over the lanes
       for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o);
@@ -633,15 +627,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int offv = incl - n;
       if (total > 0) {
         ws.off[lane] = (unsigned short)offv;
-        ws.first[lane] = (unsigned short)first;
         for (int k = 0; k < n; k++) ws.line[offv + k] = (unsigned char)lane;
         wave_sync();
         // ---- B
         for (int p = lane; p < total; p += 64) {
-          const int x = ws.line[p];
-          const double dv = fabs(ws.wnu[ws.first[x] + (p - ws.off[x])] - ws.nu0[x]);
-          ws.val[p] = dv <= ws.cut[x]
-                          ? mul_rounded(ws.amp[x], voigt_k(dv * ws.xs[x], ws.y[x], s_tab, [&] { return (int)ws.ord[x]; }))
+          const int x = ws.line[p], xs_ = (head + x) & 127;
+          const double dv = fabs(ws.wnu[ws.qfirst[xs_] + (p - ws.off[x])] - ws.nu0[xs_]);
+          ws.val[p] = dv <= ws.cut[xs_]
+                          ? mul_rounded(ws.amp[xs_], voigt_k(dv * ws.xs[xs_], ws.y[xs_], s_tab, [&] { return (int)ws.ord[xs_]; }))
                           : 0.0;
         }
         wave_sync();
@@ -653,19 +646,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           if (k < (unsigned)__builtin_amdgcn_readlane(n, t))
             acc = add_rounded(acc, ws.val[__builtin_amdgcn_readlane(offv, t) + k]);
         }
+        wave_sync();   // (the next round's fill of `line` / `off` must not overtake this round's readers)
       }
-      // the queue moves up by the m lines taken
-      const int rem = pending - m;
-      double q0[5], q1[5];
-      int o0 = 0, o1 = 0;
-      const bool h0 = lane < rem, h1 = lane + 64 < rem;
-      if (h0) { q0[0] = ws.nu0[m + lane]; q0[1] = ws.amp[m + lane]; q0[2] = ws.xs[m + lane]; q0[3] = ws.y[m + lane]; q0[4] = ws.cut[m + lane]; o0 = ws.ord[m + lane]; }
-      if (h1) { q1[0] = ws.nu0[m + 64 + lane]; q1[1] = ws.amp[m + 64 + lane]; q1[2] = ws.xs[m + 64 + lane]; q1[3] = ws.y[m + 64 + lane]; q1[4] = ws.cut[m + 64 + lane]; o1 = ws.ord[m + 64 + lane]; }
-      wave_sync();
-      if (h0) { ws.nu0[lane] = q0[0]; ws.amp[lane] = q0[1]; ws.xs[lane] = q0[2]; ws.y[lane] = q0[3]; ws.cut[lane] = q0[4]; ws.ord[lane] = o0; }
-      if (h1) { ws.nu0[64 + lane] = q1[0]; ws.amp[64 + lane] = q1[1]; ws.xs[64 + lane] = q1[2]; ws.y[64 + lane] = q1[3]; ws.cut[64 + lane] = q1[4]; ws.ord[64 + lane] = o1; }
-      wave_sync();
-      pending = rem;
+      // the ring moves on by the m lines taken
+      head = (head + m) & 127;
+      pending -= m;
     }
   };
   for (int g = g_lo; g < g_hi; g++) {
@@ -675,7 +660,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const double thresh = d.ethresh * a.smax[(size_t)st * d.ngroup + g];
     for (long base = j0; base < j1; base += 64) {
       // ---- A1  lane = line: stage it; the lines above the strength threshold whose cut
-      // reaches the wave's span join the queue (at most 63 wait there)
+      // reaches the wave's span join the queue (at most 63 wait there) with their range of the wave's points
       const long j = base + lane;
       LineRec r{1e300, 0.0, 0.0, 1.0, -1.0};
       if (j < j1) r = stage_line(d, sv, invT, thresh, j);
@@ -683,9 +668,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const unsigned long long keep = __ballot(in);
       if (!keep) continue;
       if (in) {
-        const int pos = pending + __popcll(keep & ((1ull << lane) - 1ull));
+        const int pos = (head + pending + __popcll(keep & ((1ull << lane) - 1ull))) & 127;
         ws.nu0[pos] = r.nu0; ws.amp[pos] = r.amp; ws.xs[pos] = r.xs; ws.y[pos] = r.y; ws.cut[pos] = r.cut;
         ws.ord[pos] = (unsigned char)voigt_order(r.y);
+        const double lo = r.nu0 - r.cut, hi = r.nu0 + r.cut;
+        int b = 0, e = 64;  // b -> first point >= lo
+        while (b < e) { const int m = (b + e) >> 1; if (ws.wnu[m] < lo) b = m + 1; else e = m; }
+        int c = b;          // c -> first point > hi
+        e = 64;
+        while (c < e) { const int m = (c + e) >> 1; if (ws.wnu[m] <= hi) c = m + 1; else e = m; }
+        int first = 0, n = 0;
+        if (c > b) {
+          // one point of slack either side: the exact |nu - nu0| <= cut test is per pair
+          first = b > 0 ? b - 1 : 0;
+          n = min((c < 64 ? c + 1 : 64) - first, nmax);
+        }
+        ws.qfirst[pos] = (unsigned char)first;
+        ws.qn[pos] = (unsigned char)n;
       }
       pending += __popcll(keep);
       wave_sync();

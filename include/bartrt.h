@@ -140,7 +140,14 @@ int bartrt_get_cia_interp(int *spline);
  *       bartrt_free_memory keeps serving until the other workers have let go (BARTRT_SHARE_WAIT_S
  *       seconds at most, default 60).  Tunables: BARTRT_SVC_WINDOW_US (30: how long the dispatcher
  *       waits for the workers of the previous batch after the latest arrival), BARTRT_SVC_SPIN_US
- *       (200: a waiting client polls this long before it sleeps), BARTRT_SVC_MAXCLIENTS (32).
+ *       (200: a waiting client polls this long before it sleeps), BARTRT_SVC_MAXCLIENTS (256 slots,
+ *       1024 at most: one per worker process = per chain).  Which profiles share a launch depends on
+ *       the processes' pace; the RESULT does not: the kernel variant is chosen for the number of
+ *       registered workers (BARTRT_SVC_KERNEL_WALKERS pins it) and every kernel computes a walker
+ *       independently of the others in its launch, so a chain's spectra are the same bits every run.
+ *       Runs of fewer than five chains (BARTRT_NCHAINS, else the MPI world size of the spawned
+ *       workers) take the `ipc` reading unless BARTRT_SHARE_MODE says otherwise: it is the faster
+ *       one there.
  *   ipc  every process runs its own engine; the first uploads the grid, the others map that HBM
  *       allocation through a HIP IPC handle published in a POSIX shared-memory segment
  *       (HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment where the host driver supports

@@ -288,9 +288,9 @@ def full_step_10(integ, headline_dir=None, kappa="survey8d"):
 def wasp12b_shard8(integ):
     """BASELINE config 4 at N = 8 as ONE rank sees it: rank 3 of 8 of the WASP-12b grid (303 of 2424 samples), ten walkers
     per step -- parameters -> profiles -> RT on the block (the all-gather and the band integration on the gathered
-    spectrum are the other ranks' business too and are not in this figure).  Twice: with the kernel chosen by the WHOLE
-    grid's columns (the default: blocks bit-identical to the unsharded run) and by the LOCAL block's
-    (include/bartrt.h, bartrt_set_kernel_by).  DESIGN.md section 5 takes its N = 8 recommendation from these two."""
+    spectrum are the other ranks' business too and are not in this figure).  Twice: with the kernel chosen by the LOCAL block's
+    columns (the default since round 5; blocks agree with the unsharded run to rounding) and by the WHOLE grid's (blocks
+    bit-identical to the unsharded run; include/bartrt.h, bartrt_set_kernel_by).  DESIGN.md section 5 takes its N = 8 recommendation from these two."""
     import ctypes as C
     import torch
     from bart_amd import BARTfunc, engine, synthcfg, transit_module as trm

@@ -13,7 +13,7 @@ CLI = os.path.join(HERE, "transit")
 SOURCES = ["rt_eclipse_angles.hip", "rt_eclipse_slant_ilp.hip", "rt_eclipse_qadj.hip", "rt_eclipse_team.hip", "rt_eclipse_i0.hip", "rt_eclipse_i1.hip", "rt_eclipse_i2.hip", "rt_eclipse_i0_ilp.hip", "rt_eclipse_i1_ilp.hip", "lbl.hip",
            "transit_geom.hip",
            "kernels.hip", "capi.hip", "engine.hip", "step.hip", "mcmc.hip", "share.hip", "svc.hip", "rtc.hip", "io.cpp"]   # longest first
-HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "rt_eclipse_s1t.hpp", "rt_eclipse_qadj.hpp", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp", "share.hpp", "svc.hpp", "svc_core.hpp", "rtc.hpp",
+HEADERS = ["engine.hpp", "kernels.hpp", "rt_eclipse.hpp", "rt_eclipse_s1.hpp", "rt_eclipse_s1s.hpp", "rt_eclipse_s1t.hpp", "rt_eclipse_qadj.hpp", "kernel_table.inc", "imw_tab.hpp", "integ.hpp", "step.hpp", "lbl.hpp", "voigt_coef.hpp", "expint_coef.hpp", "prep.hpp", "io.hpp", "share.hpp", "svc.hpp", "svc_core.hpp", "rtc.hpp",
            "transit_main.cpp", "../../include/bartrt.h"]
 
 

@@ -69,11 +69,9 @@ constexpr long kOctoRaysMaxColumns = 40;
 // (round 5, us per step, folded / not: demo shape one walker, 313 workgroups, 25.1 / 27.9, three walkers, 471: 29.4 /
 // 32.2; two walkers, 626: 37.9 / 35.4, four, 628: 47.6 / 45.4; W = 1e4 one walker, 625: 48.2 / 47.4, two: 68.5 / 64.0)
 constexpr int kFoldMaxWorkgroups = 512;
-constexpr long kQuadAllMaxColumns = 256, kOctoAllMaxColumns = 256;    // eight layers per step up to here (R = 4: BARTRT_KERNEL=quad only)
-constexpr long kRows16AllMaxColumns = 128, kRows32AllMaxColumns = 64;  // sixteen / thirty-two layers per step (BARTRT_KERNEL=hexa / r32)
-// ... one or two table molecules (the demo shape: lighter steps, the rounds cost less than the longer walk): by the
-// demo-shape figures above, 32 rows to 96 columns, 16 rows to 176
-constexpr long kRows16AllMaxColumnsFewMol = 176, kRows32AllMaxColumnsFewMol = 96;
+// (which of these forms serves which launch: kernel_table.inc, below.  The figures above are what its first version
+// -- R = 32 to 64 columns, 16 to 128, 8 to 256; with one or two molecules 32 to 96, 16 to 176 -- was read from.)
+constexpr long kQuadAllMaxColumns = 256;    // the range of the layer-parallel walk under BARTRT_ALLR_ROWS (the A/B tools' switch)
 // `cut slant`, rule 1: a team of three waves per column (rt_eclipse_s1t.hpp) for ONE walker's worth of columns at
 // W = 1e4 -- 44 against the single-wave kernel's 58 us; from two walkers on the team loses (59 / 59, four walkers 76 /
 // 61, ten 135 / 98, 64: 639 / 429 us): its producer wave keeps its table loads one layer ahead only (the 128
@@ -83,6 +81,29 @@ constexpr long kTeamMaxColumns = 0;   // (round 4, later: the all-rays quad kern
 constexpr long kOctoMaxColumns = 400;  // eight layers per step (R = 8) below this
 constexpr long kSplitMinColumns = 1025, kSplitMaxColumns = 1300;
 constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled build below this (128 walkers at W = 1e4)
+
+#ifndef __HIPCC_RTC__   // (host side: the launchers' business)
+// Rule 1 under `cut slant` (the default conventions): the variant comes from a MEASURED table (kernel_table.inc, written
+// by tools/tune_kernels.py from a sweep on the box; round 6 -- until then a thicket of hand-measured column intervals in
+// launch_rt_spec).  tests/test_gpu_kernel_choice.py holds the default choice to within 7 % of the best forced variant
+// on grids the table was not tuned on.
+enum KernelVariant { kVarSingle = 0, kVarRows4 = 4, kVarRows8 = 8, kVarRows16 = 16, kVarRows32 = 32, kVarAdj8 = 108, kVarAdj16 = 116 };
+struct KernelChoice { long max_columns; int variant, fallback; };
+constexpr long kAllColumns = 0x7fffffffffffffffL;
+#include "kernel_table.inc"
+inline const KernelChoice &slant_simpson_choice(int M, long columns) {
+  const KernelChoice *t = M <= 2 ? kSlantSimpsonFewMol : kSlantSimpsonManyMol;
+  int i = 0;
+  while (columns > t[i].max_columns) i++;   // (the last entry holds kAllColumns)
+  return t[i];
+}
+inline const char *kernel_variant_name(int v) {
+  switch (v) {
+    case kVarRows4: return "rows4"; case kVarRows8: return "rows8"; case kVarRows16: return "rows16"; case kVarRows32: return "rows32";
+    case kVarAdj8: return "adj8"; case kVarAdj16: return "adj16"; default: return "single";
+  }
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // XCD-aware block -> (tile, walker) map.  Blocks b and b+8 share an XCD (and
@@ -1053,28 +1074,24 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
       // rule 1: the layer-parallel walk with ALL rays per lane (rt_eclipse_quad<..., ALLR>)
       // rows = layers per step (and 64 / rows wavenumbers per wave): the fewer the columns, the more rows
       static const int rows_env = [] { const char *v = std::getenv("BARTRT_ALLR_ROWS"); return v && *v ? atoi(v) : 0; }();
-      int rows = kmode == "quad" ? 4 : kmode == "octo" ? 8 : kmode == "hexa" ? 16 : kmode == "r32" ? 32
-                 : columns <= (a.M <= 2 ? kRows32AllMaxColumnsFewMol : kRows32AllMaxColumns) ? 32
-                 : columns <= (a.M <= 2 ? kRows16AllMaxColumnsFewMol : kRows16AllMaxColumns) ? 16
-                 : columns <= kOctoAllMaxColumns ? 8 : 4;
+      // the launch's variant: forced (BARTRT_KERNEL, BARTRT_ALLR_ROWS), else the measured table's (kernel_table.inc)
+      static const int adj_env = [] { const char *v = std::getenv("BARTRT_ADJ"); return v && *v ? atoi(v) : -1; }();
+      const KernelChoice &entry = slant_simpson_choice(a.M, columns);
+      const bool adj_ok = adj_env != 0 && rows_env == 0;
+      const bool adj_named = entry.variant == kVarAdj16 || entry.variant == kVarAdj8;
+      // (the layer-parallel form that runs should the adjacent one not launch: the entry's fallback)
+      const int other = adj_named ? entry.fallback : entry.variant;
+      int rows = kmode == "quad" ? 4 : kmode == "octo" ? 8 : kmode == "hexa" ? 16 : kmode == "r32" ? 32 : other == kVarSingle ? 4 : other;
       if (rows_env == 4 || rows_env == 8 || rows_env == 16 || rows_env == 32) rows = rows_env;
       const bool lpa_forced = lp_forced || kmode == "hexa" || kmode == "r32" || kmode == "adj8" || kmode == "adj16";
       while (rows > 4 && b.window && !window_fits(a, rows)) rows /= 2;
-      // The same walk with a column's rows on ADJACENT lanes (rt_eclipse_qadj.hpp: DPP row shifts instead of ds_bpermute,
-      // carries in place), where it was measured ahead (round 5, us per launch, this kernel / the choice before it):
-      //   bench shape, W = 1e4: 157 columns 34.6 / 38.2 (R = 8), 314 columns 50.2 / 57.7 (single wave), 471: 70 / 58 -- not
-      //   there; W = 5 000: 79 columns 24.5 / 25.9, 158: 34.8 / 37.0, 237: 40.4 / 37.1 -- not there, 316: 49.5 / 58.6
-      //   demo shape (one molecule): 40 / 80 columns 16.2 / 15.4, 19.5 / 18.2 -- not there (R = 32 stays), 120: 19.6 / 21.4,
-      //   160: 27.9 / 25.8 -- not there, 200: 29.6 / 32.7 and 240: 29.0 / 32.6 with eight rows
-      //   W = 2 424 (the WASP-12b grid's 38 columns per walker): 342 columns 56.3 / 58.1, 380: 55.5 / 58.4 (ten walkers: the
-      //   per-step callable 1.30e5 against 1.26e5 walker-steps/s), 418: 64.0 / 58.9 -- not there
-      // BARTRT_KERNEL=adj8 / adj16 force it, BARTRT_ADJ=0 switches it off.
-      static const int adj_env = [] { const char *v = std::getenv("BARTRT_ADJ"); return v && *v ? atoi(v) : -1; }();
+      // rt_eclipse_qadj (rows on adjacent lanes: DPP row shifts instead of ds_bpermute, carries in place) where the table
+      // names it; BARTRT_KERNEL=adj8 / adj16 force it, BARTRT_ADJ=0 switches it off
       int adj_rows = kmode == "adj8" ? 8 : kmode == "adj16" ? 16 : 0;
-      if (kmode.empty() && adj_env != 0 && rows_env == 0) {
-        if (a.M >= 3) adj_rows = ((columns > 64 && columns <= 176) || (columns > 280 && columns <= 390)) ? 16 : 0;
-        else adj_rows = (columns > 96 && columns <= 140) ? 16 : (columns > 176 && columns <= 256) ? 8 : 0;
-      }
+      if (kmode.empty() && adj_ok && adj_named) adj_rows = entry.variant == kVarAdj16 ? 16 : 8;
+      // (the layer-parallel walk at all: forced, or the table names one of its forms; BARTRT_ALLR_ROWS, the A/B tools'
+      // switch, keeps round 5's range for it)
+      const bool lp_by_table = kmode.empty() && (rows_env != 0 ? columns <= kQuadAllMaxColumns : other != kVarSingle);
       if (adj_rows && !use_rays && a.cia_bytes < (1ull << 32) - 4096 && (!b.window || window_fits(a, adj_rows))) {
         const int awn = 64 / adj_rows;
         RtArgs ba = b;
@@ -1096,7 +1113,7 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
         if (rtc_try(info, false, dim3(nba), dim3(256), sha, st, ba, err, "rt_eclipse_qadj<5, %d, %d, %s, %d>", a.M, a.C, tf(sq), adj_rows)) return true;
         if (info) *info = keep;    // (neither an instantiation nor a compiler: the choice before it)
       }
-      if (!use_rays && (lpa_forced || (kmode.empty() && columns <= kQuadAllMaxColumns)) && a.cia_bytes < (1ull << 32) - 4096 &&
+      if (!use_rays && (lpa_forced || lp_by_table) && a.cia_bytes < (1ull << 32) - 4096 &&
           (!b.window || window_fits(a, rows))) {
         const int wnw = 64 / rows;   // wavenumbers per wave
         b.ntiles = (a.W + 4 * wnw - 1) / (4 * wnw);

@@ -33,3 +33,8 @@ bool launch_rt_fast_ext(const RtArgs &b, bool sq, int block, int nblocks, size_t
 }
 
 }  // namespace bartrt
+
+// include/bartrt.h: what the measured table names for a launch (no GPU, no engine)
+extern "C" const char *bartrt_kernel_choice(int nmol, long columns) {
+  return bartrt::kernel_variant_name(bartrt::slant_simpson_choice(nmol, columns < 0 ? 0 : columns).variant);
+}

@@ -62,6 +62,8 @@ def lib():
         d, i, p = C.c_double, C.c_int, C.c_void_p
         L.bartrt_last_error.restype = C.c_char_p
         L.bartrt_build_id.restype = C.c_char_p
+        L.bartrt_kernel_choice.restype = C.c_char_p
+        L.bartrt_kernel_choice.argtypes = [i, C.c_long]
         L.bartrt_init.argtypes = [i, C.POINTER(C.c_char_p)]
         L.bartrt_get_waveno_arr.argtypes = [p, i]
         L.bartrt_set_radius.argtypes = [d]

@@ -281,6 +281,13 @@ const char *bartrt_last_error(void);
  * Never fails, needs no GPU.  Profiler figures under profiles/ carry the id of the
  * library they were measured on; bench.py quotes them only under the same id. */
 const char *bartrt_build_id(void);
+/* Which eclipse kernel the library's measured table (csrc/kernel_table.inc, written by
+ * tools/tune_kernels.py) names for a launch of `columns` 64-sample columns (walkers x
+ * ceil(samples / 64)) with `nmol` table molecules under the default conventions (rule 1,
+ * `cut slant`, five ray angles): "single", "rows4" / "rows8" / "rows16" / "rows32" (layers per
+ * step of the layer-parallel walk), "adj8" / "adj16" (rows on adjacent lanes).  Needs no GPU and
+ * no engine; the returned string is static. */
+const char *bartrt_kernel_choice(int nmol, long columns);
 int bartrt_get_nlayers(void);
 int bartrt_get_nspecies(void);
 int bartrt_get_nprof(void);                 /* (S+1)*L */

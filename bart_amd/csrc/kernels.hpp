@@ -27,8 +27,10 @@ template <bool B, class T, class F> using conditional_t = typename conditional<B
   X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) \
   X(5, 0) X(5, 1) X(5, 2) X(6, 0) X(6, 1) X(6, 2)                                                 \
   X(1, 4) X(2, 4) X(3, 4) X(4, 4) X(5, 4) X(6, 4)
-// ... of the adjacent-rows layer-parallel kernel (rt_eclipse_qadj.hpp)
-#define BARTRT_QADJ_LIST(X) X(1, 1) X(1, 2) X(4, 1) X(4, 2)
+// ... of the adjacent-rows layer-parallel kernel (rt_eclipse_qadj.hpp): the same list since round 6 -- the measured table
+// (kernel_table.inc) names that kernel for the few-walker launches of every shape, and a run-time compile of it at a
+// shape's first launch is 5-10 s (the whole list is 5 MB of code objects)
+#define BARTRT_QADJ_LIST(X) BARTRT_MC_LIST(X)
 // CIA slot counts of the line-by-line hand-off kernels (no table molecules)
 #define BARTRT_EXT_C_LIST(X) X(0) X(1) X(2) X(4)
 

@@ -90,9 +90,12 @@ constexpr long kIlpMaxColumns = 20000;  // single-wave kernel: the ILP-scheduled
 enum KernelVariant { kVarSingle = 0, kVarRows4 = 4, kVarRows8 = 8, kVarRows16 = 16, kVarRows32 = 32, kVarAdj8 = 108, kVarAdj16 = 116 };
 struct KernelChoice { long max_columns; int variant, fallback; };
 constexpr long kAllColumns = 0x7fffffffffffffffL;
+// SCHED of rt_eclipse_simpson_slant (rt_eclipse_s1s.hpp) by shape: the record read-ahead up to twelve table loads per
+// layer, none beyond (rt_eclipse_slant_ilp.hip)
+constexpr int slant_sched(int M, int C, int dflt) { return 2 * M + 2 * C > 12 ? 0 : dflt; }
 #include "kernel_table.inc"
 inline const KernelChoice &slant_simpson_choice(int M, long columns) {
-  const KernelChoice *t = M <= 2 ? kSlantSimpsonFewMol : kSlantSimpsonManyMol;
+  const KernelChoice *t = M <= 2 ? kSlantSimpsonFewMol : M <= 4 ? kSlantSimpsonMidMol : kSlantSimpsonManyMol;
   int i = 0;
   while (columns > t[i].max_columns) i++;   // (the last entry holds kAllColumns)
   return t[i];
@@ -1192,7 +1195,8 @@ bool launch_rt_spec(const RtArgs &a, int block, hipStream_t st, const std::strin
     if (launch_rt_slant(b, INTEG, sq, block, nblocks + pslots, sh + shp, st, err)) return true;
     if (!rtc_single_wave_ok(a)) { if (info) info->prep_fused = false; return false; }
     if (INTEG == kIntegSimpson
-            ? rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_simpson_slant<5, %d, %d, %s, 1>", a.M, a.C, tf(sq))
+            ? rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_simpson_slant<5, %d, %d, %s, %d>", a.M, a.C, tf(sq),
+                      slant_sched(a.M, a.C, 1))
             : rtc_try(info, true, dim3(nblocks + pslots), dim3(block), sh + shp, st, b, err, "rt_eclipse_fast<5, %d, %d, %s, %d, 1, false, true>", a.M,
                       a.C, tf(sq), INTEG))
       return true;

@@ -13,12 +13,17 @@
 
 namespace bartrt {
 
+// The record read-ahead (SCHED 1: a layer reads the NEXT layer's record while it computes) pays on the shapes it was
+// tuned on -- up to twelve table loads per layer -- and drowns wider ones in spills: <5, 6, 2> (sixteen loads) 294
+// registers spilled against 22 without it, <5, 4, 4> (BART's usual H2-H2 + H2-He under the spline) 161 against 26;
+// measured on six molecules: 762 -> 3xx us at 26 walkers (round 6, slant_sched in rt_eclipse.hpp).
+
 bool launch_rt_slant(const RtArgs &b, int integ, bool sq, int block, int nblocks, size_t sh, hipStream_t st, hipError_t &err) {
 #define BARTRT_SLANT(MM, CC)                                                                                              \
   if (b.M == MM && b.C == CC) {                                                                                           \
     if (integ == kIntegSimpson) {                                                                                         \
-      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, true, BARTRT_SLANT_SCHED>), dim3(nblocks), dim3(block), sh, st, b);    \
-      else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, BARTRT_SLANT_SCHED>), dim3(nblocks), dim3(block), sh, st, b);      \
+      if (sq) BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, true, slant_sched(MM, CC, BARTRT_SLANT_SCHED)>), dim3(nblocks), dim3(block), sh, st, b);    \
+      else BARTRT_RT_LAUNCH((rt_eclipse_simpson_slant<5, MM, CC, false, slant_sched(MM, CC, BARTRT_SLANT_SCHED)>), dim3(nblocks), dim3(block), sh, st, b);      \
     } else if (integ == kIntegTransmittance) {                                                                            \
       if (sq) BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, true, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);  \
       else BARTRT_RT_LAUNCH((rt_eclipse_fast<5, MM, CC, false, 0, 1, false, true>), dim3(nblocks), dim3(block), sh, st, b);    \

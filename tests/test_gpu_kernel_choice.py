@@ -24,12 +24,14 @@ def test_the_table_is_well_formed():
         assert set(seen) <= names
         assert seen[-1] == "single" and L.bartrt_kernel_choice(M, 10 ** 9).decode() == "single"
         assert L.bartrt_kernel_choice(M, -5).decode() == seen[0]
-    assert L.bartrt_kernel_choice(1, 100) == L.bartrt_kernel_choice(2, 100)       # classes: one or two / three and more
-    assert L.bartrt_kernel_choice(3, 100) == L.bartrt_kernel_choice(8, 100)
+    for c in (40, 100, 200, 300, 400):                   # classes: one or two / three or four / five and more
+        assert L.bartrt_kernel_choice(1, c) == L.bartrt_kernel_choice(2, c)
+        assert L.bartrt_kernel_choice(3, c) == L.bartrt_kernel_choice(4, c)
+        assert L.bartrt_kernel_choice(5, c) == L.bartrt_kernel_choice(9, c)
     rec = os.path.join(ROOT, "profiles", "r06_kernel_table.json")
     if os.path.exists(rec):
         table = json.load(open(rec))["table"]
-        for cls, M in (("few", 1), ("many", 4)):
+        for cls, M in (("few", 1), ("mid", 4), ("many", 6)):
             lo = 0
             for bound, variant, _fallback in table[cls]:
                 hi = bound if bound is not None else lo + 1000
@@ -42,6 +44,8 @@ def test_the_table_is_well_formed():
 @pytest.mark.parametrize("grid, walkers", [
     ((3333, 2, 100), (1, 2, 3, 4, 5)),        # 53 columns per walker, two molecules
     ((7000, 6, 100), (1, 2, 3)),              # 110 per walker, six molecules
+    ((4000, 3, 100), (1, 2, 3, 4, 5)),        # 63 per walker, three molecules
+    ((6200, 5, 80), (1, 2, 3)),               # 97 per walker, five molecules, eighty layers
     ((10000, 4, 60), (1, 2, 3)),              # the headline grid with sixty layers
 ])
 def test_default_choice_is_within_seven_percent_of_the_best_forced_variant(grid, walkers):

@@ -627,39 +627,35 @@ def test_cia_interpolated_by_splines(tmp_path, npairs, solution):
 
 
 def test_default_kernel_choice_under_cut_slant(demo_case, small_case):
-    """The launcher's table under the default conventions (csrc/rt_eclipse.hpp, rule 1, `cut slant`): the all-rays
-    layer-parallel kernel with 32 / 16 / 8 layers per step by the 64-wide columns of the launch -- to 96 / 176 / 256
-    columns on grids of one or two table molecules, 64 / 128 / 256 otherwise -- its adjacent-rows form
-    (rt_eclipse_qadj.hpp) on the column ranges where it was measured ahead, and the single-wave kernel beyond; every
-    choice against the oracle on two walkers' whole spectra."""
+    """The launcher follows the measured table under the default conventions (csrc/kernel_table.inc, written by
+    tools/tune_kernels.py; rule 1, `cut slant`): by the 64-wide columns of the launch and the table-molecule count the
+    all-rays layer-parallel kernel with 32 / 16 / 8 / 4 layers per step, its adjacent-rows form (rt_eclipse_qadj.hpp) or
+    the single-wave kernel -- what `bartrt_kernel_choice` names is what runs; every choice against the oracle on two
+    walkers' whole spectra."""
     from bart_amd import engine, transit_module as trm
     from oracle import rt_oracle as orc
-    # (case, walkers) -> columns = walkers * ceil(W / 64) and the kernel that goes with them
-    table = [(demo_case, 1, "R=32, all rays"), (demo_case, 2, "R=32, all rays"), (demo_case, 3, "qadj<R=16>"),
-             (demo_case, 4, "R=16, all rays"), (demo_case, 5, "qadj<R=8>"), (demo_case, 6, "qadj<R=8>"),
-             (demo_case, 7, "rt_eclipse_simpson_slant"),
-             (small_case, 1, "R=32, all rays"), (small_case, 4, "R=32, all rays"), (small_case, 5, "qadj<R=16>"),
-             (small_case, 9, "qadj<R=16>"), (small_case, 13, "qadj<R=16>"), (small_case, 14, "R=8, all rays"),
-             (small_case, 19, "R=8, all rays"), (small_case, 20, "rt_eclipse_simpson_slant"), (small_case, 22, "qadj<R=16>"),
-             (small_case, 25, "qadj<R=16>"), (small_case, 26, "qadj<R=16>"), (small_case, 30, "qadj<R=16>"),
-             (small_case, 31, "rt_eclipse_simpson_slant")]
-    for case in (demo_case, small_case):
+    name_of = {"rows32": "R=32, all rays", "rows16": "R=16, all rays", "rows8": "R=8, all rays", "rows4": "R=4, all rays",
+               "adj16": "qadj<R=16>", "adj8": "qadj<R=8>", "single": "rt_eclipse_simpson_slant"}
+    seen = set()
+    for case, counts in ((demo_case, (1, 2, 3, 4, 5, 6, 7, 9, 13)), (small_case, (1, 4, 5, 9, 13, 14, 17, 19, 20, 22, 25, 26, 30, 31, 40))):
         engine.init(case.tcfg)
         try:
             assert trm.get_cut() == "slant" and trm.get_integ() == 1
             o = orc.OracleEngine(case.tcfg)
-            for c, n, want in table:
-                if c is not case:
-                    continue
+            ncol = (trm.get_no_samples() + 63) // 64
+            for n in counts:
+                want = trm.lib().bartrt_kernel_choice(len(case.opmol), n * ncol).decode()
+                seen.add(want)
                 profs = walkers(case, n, seed=60 + n)
                 engine.walked_begin()
                 got = engine.run_batch(profs)
                 kname = engine.walked_end()[2]
-                assert want in kname, (n, kname)
+                assert name_of[want] in kname, (n, want, kname)
                 ref = o.run_batch(profs[:2])
                 np.testing.assert_allclose(got[:2], ref, rtol=RTOL, atol=1e-12 * np.abs(ref).max(), err_msg=kname)
         finally:
             trm.free_memory()
+    assert len(seen) >= 3, seen          # the counts above do cross the table's boundaries
 
 
 def test_preparation_folded_into_the_layer_parallel_kernels(demo_case, small_case, tmp_path):

@@ -32,9 +32,12 @@ def test_prefetch_is_bit_identical_through_every_kernel(small_case, integ):
             engine.run_batch_dev(d_prof[0], next_prof=d_prof[1])
             assert torch.equal(engine.run_batch_dev(d_prof[3]), ref[3]), n
             # same buffer, other walker count: not a match either
-            engine.run_batch_dev(d_prof[0], next_prof=d_prof[1])
             if n > 1:
-                assert torch.equal(engine.run_batch_dev(d_prof[1][: n - 1].contiguous()), ref[1][: n - 1]), n
+                # (its own reference: one walker less may be another kernel's launch -- csrc/kernel_table.inc)
+                fewer = d_prof[1][: n - 1].contiguous()
+                want = engine.run_batch_dev(fewer).clone()
+                engine.run_batch_dev(d_prof[0], next_prof=d_prof[1])
+                assert torch.equal(engine.run_batch_dev(fewer), want), n
             # a request withdrawn
             trm.check(trm.lib().bartrt_prefetch_profiles_dev(C.c_void_p(d_prof[2].data_ptr()), 0))
             assert torch.equal(engine.run_batch_dev(d_prof[2]), ref[2])

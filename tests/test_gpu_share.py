@@ -239,9 +239,9 @@ def test_a_late_worker_gets_the_bits_of_the_full_batch(tmp_path):
     REGISTERED workers, not for the profiles that happened to post together (the reference's worker calls its own
     engine, the same chain is the same bits every run: code/BARTfunc.py:363)."""
     from bart_amd import engine, synth, transit_module as trm
-    # 37 columns per walker: ten walkers = 370 columns (the adjacent-rows range), one walker = 37 (32 rows per step),
-    # nine = 333: three different kernels if the batch that formed were to choose
-    case = synth.make_case(str(tmp_path / "s"), nlayers=40, nwave=2330, extra_keys={"shareOpacity": ""})
+    # 40 columns per walker: ten walkers = 400 columns (the single-wave kernel), nine = 360 and one = 40 (rows on adjacent
+    # lanes, csrc/kernel_table.inc): different kernels if the batch that formed were to choose
+    case = synth.make_case(str(tmp_path / "s"), nlayers=40, nwave=2530, extra_keys={"shareOpacity": ""})
     (tmp_path / "o").mkdir()
     steps = 60
     procs = [start_worker(case.tcfg, r, steps, os.path.join(str(tmp_path / "o"), "w%d.npy" % r),

@@ -7,8 +7,7 @@ angles) and writes the table the library reads: bart_amd/csrc/kernel_table.inc (
 
 Every variant is forced in turn (BARTRT_KERNEL: the switch is read once per process, so each (grid, variant) is a child
 process of this script) on each tuning grid and walker count; the figure is the STEP -- preparation + RT kernel, a hundred
-steps queued back to back, wall clock -- median of --repeats windows (the RT kernel's own HIP-event time is recorded too).  Per class of table-molecule count (one or two / three
-and more) the winner at every measured column count becomes an interval of the table; a variant must beat the interval's
+steps queued back to back, wall clock -- median of --repeats windows (the RT kernel's own HIP-event time is recorded too).  Per class of table-molecule count (one or two / three or four / five and more) the winner at every measured column count becomes an interval of the table; a variant must beat the interval's
 current holder by 3 % to take over (no flapping on noise); where an adjacent-rows variant wins, the best OTHER variant is
 recorded as the entry's fallback.  Beyond the last measured column count the single-wave kernel serves everything.
 
@@ -36,7 +35,18 @@ TUNE = [
     (10000, 4, 100, (1, 2, 3, 4)),                             # the headline grid: 157
     (5000, 4, 100, (1, 2, 3, 4, 5, 6, 7)),                     # 79
     (2424, 4, 100, (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16)),   # the WASP-12b grid: 38
+    # five and more table molecules: heavier steps move the crossovers (six molecules, 7 000 samples, 330 columns: the
+    # four-molecule table's choice was 18 % behind the best variant)
+    # (their single-wave kernel is slow -- sixteen loads per layer in flight three deep, it spills: 102-110 us where four
+    # molecules take 68 -- so the layer-parallel forms hold out to ~2 000 columns: the sweep goes to 4 000)
+    (10000, 6, 100, (1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16, 20, 26)),
+    (5000, 6, 100, (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 20, 26, 32, 40)),
+    (2424, 6, 100, (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24, 28, 40, 54, 70)),
 ]
+# classes of table-molecule count: (name of the table's array, note, predicate)
+CLASSES = [("few", "kSlantSimpsonFewMol", "one or two table molecules", lambda m: m <= 2),
+           ("mid", "kSlantSimpsonMidMol", "three or four", lambda m: 3 <= m <= 4),
+           ("many", "kSlantSimpsonManyMol", "five and more", lambda m: m >= 5)]
 
 
 def case_for(W, M, L):
@@ -115,10 +125,10 @@ def measure(grids, repeats, with_default=False):
 def build_table(rows, margin=0.03):
     """-> {"few": [(max_columns, variant, fallback), ...], "many": [...]} and the per-point figures."""
     out, points = {}, {}
-    for cls, pick in (("few", lambda r: r["M"] <= 2), ("many", lambda r: r["M"] >= 3)):
+    for cls, _arr, _note, pick in CLASSES:
         by_col = {}
         for r in rows:
-            if pick(r) and r["forced"]:
+            if pick(r["M"]) and r["forced"]:
                 by_col.setdefault(r["columns"], {}).setdefault(VARIANTS[r["forced"]], []).append(r["us"])
         cols = sorted(by_col)
         pts = []
@@ -165,8 +175,8 @@ def write_inc(table, record, grids):
 //   variants: kVarSingle rt_eclipse_simpson_slant; kVarRows4 / 8 / 16 / 32 rt_eclipse_quad<ALLR> with that many layers
 //   per step; kVarAdj8 / 16 rt_eclipse_qadj (rows on adjacent lanes)
 """ % (record, ", ".join("(%d, %d, %d)" % g[:3] for g in grids))
-    txt += arr("kSlantSimpsonFewMol", table["few"], "one or two table molecules")
-    txt += arr("kSlantSimpsonManyMol", table["many"], "three and more")
+    for cls, name, note, _pick in CLASSES:
+        txt += arr(name, table[cls], note)
     open(os.path.join(ROOT, "bart_amd", "csrc", "kernel_table.inc"), "w").write(txt)
 
 

@@ -95,7 +95,9 @@ constexpr long kAllColumns = 0x7fffffffffffffffL;
 constexpr int slant_sched(int M, int C, int dflt) { return 2 * M + 2 * C > 12 ? 0 : dflt; }
 #include "kernel_table.inc"
 inline const KernelChoice &slant_simpson_choice(int M, long columns) {
-  const KernelChoice *t = M <= 2 ? kSlantSimpsonFewMol : M <= 4 ? kSlantSimpsonMidMol : kSlantSimpsonManyMol;
+  static constexpr const KernelChoice *const tables[6] = {kSlantSimpsonM1, kSlantSimpsonM2, kSlantSimpsonM3,
+                                                          kSlantSimpsonM4, kSlantSimpsonM5, kSlantSimpsonM6};
+  const KernelChoice *t = tables[M < 1 ? 0 : M > 6 ? 5 : M - 1];   // (no table molecules: cross sections only -- the lightest table)
   int i = 0;
   while (columns > t[i].max_columns) i++;   // (the last entry holds kAllColumns)
   return t[i];

@@ -24,14 +24,13 @@ def test_the_table_is_well_formed():
         assert set(seen) <= names
         assert seen[-1] == "single" and L.bartrt_kernel_choice(M, 10 ** 9).decode() == "single"
         assert L.bartrt_kernel_choice(M, -5).decode() == seen[0]
-    for c in (40, 100, 200, 300, 400):                   # classes: one or two / three or four / five and more
-        assert L.bartrt_kernel_choice(1, c) == L.bartrt_kernel_choice(2, c)
-        assert L.bartrt_kernel_choice(3, c) == L.bartrt_kernel_choice(4, c)
-        assert L.bartrt_kernel_choice(5, c) == L.bartrt_kernel_choice(9, c)
+    for c in (40, 100, 200, 300, 400, 900):              # seven and more molecules read the sixth table; none, the first
+        assert L.bartrt_kernel_choice(6, c) == L.bartrt_kernel_choice(9, c)
+        assert L.bartrt_kernel_choice(0, c) == L.bartrt_kernel_choice(1, c)
     rec = os.path.join(ROOT, "profiles", "r06_kernel_table.json")
     if os.path.exists(rec):
         table = json.load(open(rec))["table"]
-        for cls, M in (("few", 1), ("mid", 4), ("many", 6)):
+        for cls, M in [("m%d" % m, m) for m in range(1, 7)]:
             lo = 0
             for bound, variant, _fallback in table[cls]:
                 hi = bound if bound is not None else lo + 1000

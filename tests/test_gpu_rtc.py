@@ -76,8 +76,10 @@ def test_shapes_outside_the_aot_set_are_instantiated_and_match_the_oracle(tmp_pa
         shape = os.path.basename(os.path.dirname(key.split("|")[0]))
         # (rule 2 has no adjacent-rows form: its wide batch is past the layer-parallel kernels' range at 350 columns already)
         if shape in wide and (key.endswith("|80") or (key.endswith("|70") and shape == "m7c4i2")):
-            # the single-wave kernels spill on these shapes: their BATCHES stay with the generic kernel (measured equal or faster)
-            assert "generic" in kname, (key, kname)
+            # the single-wave kernels spill on these shapes: their BATCHES never take one -- the generic kernel (measured
+            # equal or faster), or a layer-parallel instantiation while the measured table still names one
+            assert "generic" in kname or ("instantiated at run time" in kname and "simpson_slant" not in kname
+                                          and "rt_eclipse_fast" not in kname), (key, kname)
         else:
             assert "generic" not in kname and "instantiated at run time" in kname, (key, kname)
     for name, (c, integ, cut) in cases.items():

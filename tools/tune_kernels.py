@@ -7,7 +7,7 @@ angles) and writes the table the library reads: bart_amd/csrc/kernel_table.inc (
 
 Every variant is forced in turn (BARTRT_KERNEL: the switch is read once per process, so each (grid, variant) is a child
 process of this script) on each tuning grid and walker count; the figure is the STEP -- preparation + RT kernel, a hundred
-steps queued back to back, wall clock -- median of --repeats windows (the RT kernel's own HIP-event time is recorded too).  Per class of table-molecule count (one or two / three or four / five and more) the winner at every measured column count becomes an interval of the table; a variant must beat the interval's
+steps queued back to back, wall clock -- median of --repeats windows (the RT kernel's own HIP-event time is recorded too).  Per table-molecule count (1 .. 6; seven and more read the sixth table) the winner at every measured column count becomes an interval of the table; a variant must beat the interval's
 current holder by 3 % to take over (no flapping on noise); where an adjacent-rows variant wins, the best OTHER variant is
 recorded as the entry's fallback.  Beyond the last measured column count the single-wave kernel serves everything.
 
@@ -30,23 +30,28 @@ ENUM = {"single": "kVarSingle", "rows4": "kVarRows4", "rows8": "kVarRows8", "row
         "rows32": "kVarRows32", "adj8": "kVarAdj8", "adj16": "kVarAdj16"}
 MOLS = ("H2O", "CO", "CO2", "CH4", "NH3", "HCN", "C2H2", "TiO", "VO")
 # tuning grids: (samples, table molecules, layers) and the walker counts timed on each (columns = walkers x ceil(W / 64))
-TUNE = [
-    (2501, 1, 100, (1, 2, 3, 4, 5, 6, 7, 8, 10, 12)),          # the demo shape: 40 columns per walker
-    (10000, 4, 100, (1, 2, 3, 4)),                             # the headline grid: 157
-    (5000, 4, 100, (1, 2, 3, 4, 5, 6, 7)),                     # 79
-    (2424, 4, 100, (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16)),   # the WASP-12b grid: 38
-    # five and more table molecules: heavier steps move the crossovers (six molecules, 7 000 samples, 330 columns: the
-    # four-molecule table's choice was 18 % behind the best variant)
-    # (their single-wave kernel is slow -- sixteen loads per layer in flight three deep, it spills: 102-110 us where four
-    # molecules take 68 -- so the layer-parallel forms hold out to ~2 000 columns: the sweep goes to 4 000)
-    (10000, 6, 100, (1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16, 20, 26)),
-    (5000, 6, 100, (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 20, 26, 32, 40)),
-    (2424, 6, 100, (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24, 28, 40, 54, 70)),
-]
-# classes of table-molecule count: (name of the table's array, note, predicate)
-CLASSES = [("few", "kSlantSimpsonFewMol", "one or two table molecules", lambda m: m <= 2),
-           ("mid", "kSlantSimpsonMidMol", "three or four", lambda m: 3 <= m <= 4),
-           ("many", "kSlantSimpsonManyMol", "five and more", lambda m: m >= 5)]
+def _walkers(percol, upto):
+    """Walker counts whose column counts cover [percol, upto] about every 40 columns (every count while that is finer)."""
+    out, last = [], -10 ** 9
+    n = 1
+    while n * percol <= upto:
+        if n * percol - last >= 38 or n <= 4:
+            out.append(n)
+            last = n * percol
+        n += 1
+    return tuple(out)
+
+
+# tuning grids: (samples, table molecules, layers) and the walker counts timed on each (columns = walkers x ceil(W / 64)).
+# One table per table-molecule count, 1 .. 6 (seven and more read the sixth): the crossovers move with the weight of a
+# step and not monotonically -- two variants 5 % apart with four molecules are 24 % apart with three.  The sweep goes to
+# 700 columns, past the single-wave kernel's take-over at every count.
+TUNE = [(2501, 1, 100, _walkers(40, 700)), (5000, 1, 100, _walkers(79, 700))]
+for _m in (2, 3, 4, 5, 6):
+    TUNE += [(10000, _m, 100, _walkers(157, 700)), (5000, _m, 100, _walkers(79, 700)), (2424, _m, 100, _walkers(38, 700))]
+# classes of table-molecule count: (key, name of the table's array, note, predicate)
+CLASSES = [("m%d" % m, "kSlantSimpsonM%d" % m, "%d table molecule%s%s" % (m, "s" if m > 1 else "", " and more" if m == 6 else ""),
+            (lambda mm: (lambda x: x == mm))(m)) for m in range(1, 7)]
 
 
 def case_for(W, M, L):

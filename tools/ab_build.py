@@ -15,7 +15,7 @@ name, src, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
 b.build()
 own = [] if "--no-file-flags" in extra else b.EXTRA_FLAGS.get(src, [])     # (e.g. the max-ILP scheduling option)
 extra = [x for x in extra if x != "--no-file-flags"]
-flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", *own, *extra]
+flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", b.ANGLE_FLAG, "-cuid=ab_" + name, *own, *extra]
 obj = os.path.join(b.CSRC, "ab_%s.o" % name)
 subprocess.check_call([b._hipcc(), *flags, "-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj])
 objs = []
@@ -24,6 +24,7 @@ for s in b.SOURCES:
         objs += [os.path.join(b.CSRC, n + ".o") for n, _ in b.VARIANTS[s]]
     else:
         objs.append(obj if s == src else os.path.join(b.CSRC, os.path.splitext(s)[0] + ".o"))
+objs.append(os.path.join(b.CSRC, "build_id.o"))      # (the regular build's id: an A/B library is not a shipped one)
 out = os.path.join(b.HERE, "libbartrt_%s.so" % name)
 subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-o", out, *objs])
 print(out)

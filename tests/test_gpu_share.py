@@ -233,7 +233,7 @@ def test_client_refuses_what_only_an_engine_serves(tmp_path):
 
 def test_a_late_worker_gets_the_bits_of_the_full_batch(tmp_path):
     """VERDICT r5 item 3 (a, b, c): NO `BARTRT_SVC_WAIT_ALL`, the production window of 30 us, and one worker in the
-    middle of the slot range late on purpose every third step (by 300 us: ten windows).  Its profile goes out in a
+    middle of the slot range (whoever holds slot 4) late on purpose every third step (by 300 us: ten windows).  Its profile goes out in a
     launch of its own, the nine others in a launch without it -- gathered from non-consecutive slots, ONE launch -- and
     every spectrum of every step is the one a ten-walker batch call computes, bit for bit: the kernel is chosen for the
     REGISTERED workers, not for the profiles that happened to post together (the reference's worker calls its own
@@ -245,7 +245,7 @@ def test_a_late_worker_gets_the_bits_of_the_full_batch(tmp_path):
     (tmp_path / "o").mkdir()
     steps = 60
     procs = [start_worker(case.tcfg, r, steps, os.path.join(str(tmp_path / "o"), "w%d.npy" % r),
-                          ("--late-every", "3", "--late-us", "300" if r == 4 else "0"), {"BARTRT_SVC_WINDOW_US": "30"})
+                          ("--late-every", "3", "--late-us", "300", "--late-slot", "4"), {"BARTRT_SVC_WINDOW_US": "30"})
              for r in range(10)]
     try:
         ready = [expect(p, "ready") for p in procs]

@@ -8,7 +8,7 @@ tests/test_gpu_share.py; talks to its parent over stdin / stdout:
     child  -> "done {json}"      after its steps
     parent -> "bye"              once every child is done (the grid's owner must outlive the others' use)
 usage: mc3_child.py <transit.cfg> <rank> <nsteps> [<out.npy>] [--radius km] [--cloudtop log10bar]
-                    [--scattering flag value] [--until-error] [--late-every K --late-us U]
+                    [--scattering flag value] [--until-error] [--late-every K --late-us U [--late-slot S]]
 The setters are this process's own trm.set_radius / set_cloudtop / set_scattering (code/BARTfunc.py:350-360);
 --until-error: keep calling until the engine refuses (a chain-service client whose owner has died), report it."""
 import argparse
@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--until-error", action="store_true")
     ap.add_argument("--late-every", type=int, default=0, help="this worker is late for every K-th step ...")
     ap.add_argument("--late-us", type=float, default=0.0, help="... by this many microseconds (a straggler on purpose)")
+    ap.add_argument("--late-slot", type=int, default=-1, help="... only if this process holds that slot of the chain service "
+                                                              "(slots go by arrival: the straggler is named by slot, not by rank)")
     a = ap.parse_args()
     tcfg, rank, nsteps, out = a.tcfg, a.rank, a.nsteps, a.out
     from bart_amd import transit_module as trm
@@ -90,7 +92,7 @@ def main():
     t0 = time.perf_counter()
     first, differ = None, 0      # the chain's profile is the same every step: so must its spectrum be, bit for bit
     for i in range(nsteps):
-        if a.late_every and i % a.late_every == a.late_every - 1:
+        if a.late_every and i % a.late_every == a.late_every - 1 and (a.late_slot < 0 or a.late_slot == svc["slot"]):
             t_late = time.perf_counter() + a.late_us * 1e-6
             while time.perf_counter() < t_late:
                 pass

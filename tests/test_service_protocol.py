@@ -161,5 +161,5 @@ def test_seventy_chains_all_get_a_slot(harness):
     assert all("attach_error" not in r and r["done"] == 12 and r["bad"] == 0 for r in rep), [r for r in rep if r.get("bad") or "attach_error" in r]
     assert sorted(r["slot"] for r in rep) == list(range(n))           # lowest slots first, one each
     owner = [r for r in rep if r["owner"]][0]
-    assert owner["served"] == n * 12 and owner["batches"] < n * 12 // 4
+    assert owner["served"] == n * 12 and owner["batches"] < n * 12 // 2     # (batched: far fewer rounds than calls)
     assert not leftovers(key)

@@ -285,3 +285,33 @@ def test_a_late_worker_gets_the_bits_of_the_full_batch(tmp_path):
     for r in range(10):
         assert np.array_equal(spec[r][1], batch[r]), r
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("bartrt_svc_")]
+
+
+def test_setters_ride_with_their_profile_through_a_gathered_launch(tmp_path):
+    """The per-client overrides (radius, cloud top) in the round-6 paths: the production window, no BARTRT_SVC_WAIT_ALL,
+    and whoever holds slot 2 late every other step -- so the others' profiles AND overrides go out gathered from
+    non-consecutive slots (csrc/svc.hip svc_gather), the straggler's alone -- against engines that carry each setter."""
+    from bart_amd import engine, synth, transit_module as trm
+    case = synth.make_case(str(tmp_path / "s"), nlayers=40, nwave=600, extra_keys={"shareOpacity": ""})
+    (tmp_path / "o").mkdir()
+    late = ("--late-every", "2", "--late-us", "300", "--late-slot", "2")
+    extra = {0: late, 1: ("--radius", "95000.0") + late, 2: ("--cloudtop", "-1.5") + late, 3: ("--radius", "99000.0") + late,
+             4: ("--cloudtop", "-0.5") + late}
+    ready, done, spec = run_workers(case.tcfg, 5, 40, str(tmp_path / "o"), env={"BARTRT_SVC_WINDOW_US": "30"}, extra=extra)
+    stats = max((d["service_stats"] for d in done), key=lambda s: s["launches"])
+    assert stats["gathered"] > 0, stats
+    assert [d["steps_that_differ_from_the_first"] for d in done] == [0] * 5, done
+    try:
+        prof0 = case.profiles().ravel()
+        for r in range(5):
+            engine.init(own_engine_cfg(case, tmp_path))
+            n, L = trm.get_no_samples(), engine.nlayers()
+            if r == 1: trm.set_radius(95000.0)
+            if r == 2: trm.set_cloudtop(-1.5)
+            if r == 3: trm.set_radius(99000.0)
+            if r == 4: trm.set_cloudtop(-0.5)
+            want = trm.run_transit(worker_profile(prof0, L, r), n)
+            trm.free_memory()
+            np.testing.assert_allclose(spec[r][1], want, rtol=1e-11, atol=1e-13 * np.abs(want).max(), err_msg=str(r))
+    finally:
+        trm.free_memory()

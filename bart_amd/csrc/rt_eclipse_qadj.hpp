@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BARTRT_QADJ
   // Loads in flight ahead of the step that uses them: the next step's.  (Two steps ahead -- a third register slot, 256
   // registers with a handful of spills at four molecules -- was measured in round 5: no gain on either grid, 35.2 -> 36.6 us
   // for one walker at W = 1e4.  Nor does the launch react to the max-ILP schedule or to a table that fits the Infinity
-  // Cache: MEASUREMENTS.md, round 5.)
+  // Cache: MEASUREMENTS_ARCHIVE.md, round 5.)
   double rbuf[2][NR];
   int slast = 0;   // the last step walked
   load_layer(clampk(qe), rbuf[0]);

@@ -97,7 +97,7 @@ int bartrt_get_integ(int *rule);
  * engine's call structure is recalled to have -- the optical depth is computed per ray angle, the
  * cut inside that loop; every angle ends on its own layer and rule 1 pads one unit of slant depth.
  * 0 = the vertical depth: the column ends on one layer for every ray angle.  Both run specialised
- * kernels (rules 0, 1 and 2; the slant cut costs 1.10-1.18x per launch, MEASUREMENTS.md); under rule 0
+ * kernels (rules 0, 1 and 2; the slant cut costs 1.10-1.18x per launch, MEASUREMENTS_ARCHIVE.md); under rule 0
  * the two differ by about exp(-toomuch) of the flux, under rule 1 (the default) by far more -- the padded
  * point moves with the cut: 4.6e-3 relative on a 40-layer synthetic column at toomuch 10 (and spline
  * against linear CIA 3.5e-3: the round-4 change of defaults moved spectra at the 0.5 % level).  Also

@@ -1,6 +1,6 @@
 """Independent chain groups on one GPU: G processes, each stepping its own batch of ten walkers through
 engine.run_batch_dev back to back (the headline workload of bench.py), started together.  A ten-walker launch leaves
-478 of the 1 024 SIMDs idle from half-time on (MEASUREMENTS.md, "columns that migrate"): launches of ANOTHER process fill
+478 of the 1 024 SIMDs idle from half-time on (MEASUREMENTS_ARCHIVE.md, "columns that migrate"): launches of ANOTHER process fill
 them, which one process's own launches -- ordered on its stream -- cannot.  A chain group needs its step's results before
 it proposes the next, so this is not the headline's metric (one group, `value` of bench.py); it is what a user running
 several independent groups (BART's `nchains` split over runs, or several retrievals) gets per GPU.

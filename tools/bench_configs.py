@@ -47,6 +47,30 @@ def _time_launches(engine, torch, d_prof, out, steps, warm=5, prefetch=False):
     return dt / steps, kms / max(nl, 1) / 1e3
 
 
+def step_launch_bytes(case, d_params, nfilters):
+    """The byte model of ONE step's RT launch (bench.launch_byte_model: every table row the launch's walkers read, once
+    per launch, down to where each wave stopped) for the legs that go through the per-step callable: the step's own
+    profiles (bartrt_step_profiles_dev on the same parameters) and the kernels' walked-layer record of that step."""
+    import ctypes as C
+    import torch
+    import bench
+    from bart_amd import engine, transit_module as trm
+    n, npars = d_params.shape
+    prof = torch.empty((n, engine.nprof()), dtype=torch.float64, device=d_params.device)
+    status = torch.empty(n, dtype=torch.int32, device=d_params.device)
+    trm.check(trm.lib().bartrt_step_profiles_dev(C.c_void_p(d_params.data_ptr()), n, npars, C.c_void_p(prof.data_ptr()),
+                                                 C.c_void_p(status.data_ptr()), None))
+    engine.walked_begin()
+    engine.step_batch_dev(d_params, nfilters)
+    torch.cuda.synchronize()
+    walked, wpc, kname = engine.walked_end()
+    ok = status.cpu().numpy() == 0
+    m = bench.launch_byte_model(case, prof.cpu().numpy()[ok], walked[ok], wpc, len(case.wn),
+                                spline=trm.get_cia_interp() == "spline")
+    return {"unique_bytes_per_launch": m["unique_bytes"], "effective_bytes_per_launch": m["effective_bytes"],
+            "layers_walked_frac": m["layers_walked_frac"], "kernel": kname, "walkers_in_the_model": int(ok.sum())}
+
+
 KAPPA_TEXT = {
     "survey8d": "SURVEY 8d's opacity model to the letter (exp(N(-25,3)) cm2/g, CIA 1e-45 exp(N(0,1))): transparent "
                 "column, every layer walked",
@@ -182,6 +206,7 @@ def wasp12b_step(integ):
         kms, nl = engine.timing_end()
         kern_s = kms / max(nl, 1) / 1e3
         alg = engine.algorithmic_bytes(n)
+        lb = step_launch_bytes(case, d_par[0], w.nfilters)
         return {
             "workload": "BASELINE config 4's per-GPU work: WASP-12b shape (100 layers x 2424 samples, 4 molecules, "
                         "4 filters), 10 walkers per step through the per-step callable (parameters -> T(p), "
@@ -193,6 +218,9 @@ def wasp12b_step(integ):
                          "achieved": alg / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": alg / kern_s / 1e9 / PEAK_HBM_GBS,
                          "survey8d_algorithmic_bytes_per_launch": alg,
+                         "unique_bytes_per_launch": lb["unique_bytes_per_launch"],
+                         "frac_unique_bytes": lb["unique_bytes_per_launch"] / kern_s / 1e9 / PEAK_HBM_GBS,
+                         "kernel": lb["kernel"], "layers_walked_frac": lb["layers_walked_frac"],
                          "rt_kernel_share_of_step": kern_s / dt,
                          "note": "8d bytes give no credit for the planes the ten walkers share (served by L2): an "
                                  "upper bound on the launch's DRAM traffic"}}
@@ -275,6 +303,16 @@ def full_step_10(integ, headline_dir=None, kappa="survey8d"):
         b1, _ = engine.step_batch_dev(d_par[0], w.nfilters); b1 = b1.clone()
         b2, _ = engine.step_batch_dev(d_par[0], w.nfilters)
         torch.cuda.synchronize()
+        # the RT launch of a step against the HBM roofline, on the launch's own unique bytes ("the line gives no
+        # unique_bytes for that leg -- its fraction cannot be recomputed")
+        lb = step_launch_bytes(case, d_par[0], w.nfilters)
+        ks = out["queued_back_to_back"]["rt_kernel_us"] * 1e-6
+        out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": lb["unique_bytes_per_launch"] / ks / 1e9,
+                           "frac": lb["unique_bytes_per_launch"] / ks / 1e9 / PEAK_HBM_GBS, **lb,
+                           "avg_launch_us": out["queued_back_to_back"]["rt_kernel_us"],
+                           "note": "the step's walkers are a cluster around one point of parameter space (sigma 0.2-0.5 "
+                                   "dex): they share more temperature planes than bench.py's prior-wide draws, fewer unique "
+                                   "bytes per launch, a shorter launch"}
         out["workload"] = ("whole step at the headline shape: 100 layers x 1e4 samples, 4 molecules, 10 filters, energy "
                            "balance on, 10 walkers per step, integ %d; parameters in, band fluxes out, on the device" % integ)
         out["accepted_in_last_batch"] = int((status.cpu().numpy() == 0).sum())
